@@ -1,0 +1,717 @@
+// conv_igemm.hip -- implicit-GEMM convolution on the CDNA4 matrix cores.
+//
+// One kernel serves Conv2D/Conv3D forward (K.layers/convolutional.py:148-182 -> TFB:3128-3165,
+// TFB:3277-3314) and, with the flipped/transposed filter, the data gradient of every stride-1 conv.
+// GEMM view: M = N*Do*Ho*Wo output pixels, N = Cout, K = taps*Cin (k = tap*Cin + c, channels fastest,
+// which is the contiguous axis of the channels-last activations).
+//
+// Tile: BM x BN outputs per 256-thread workgroup (4 wave64), K staged 128 bytes per row per step
+// (64 bf16 / 32 f32) through double-buffered LDS with a 16-byte-chunk XOR swizzle; operands reach the
+// MFMA as one 16-byte LDS read per lane per k-group (v_mfma_f32_16x16x32_bf16, or 4x
+// v_mfma_f32_16x16x4_f32 in the exact-f32 parity mode).  The operand gather applies, on the fly,
+// the BN(+Scale)+ReLU affine of the producing layer, nearest up-sampling, the skip add and zero padding,
+// so none of those tensors is ever materialised in HBM.
+#include "conv_common.h"
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int BK = 8 * CH;
+  constexpr int A_IT = BM / 32;
+  constexpr int B_IT = (BN + 31) / 32;
+  constexpr int WM = BM / WAVES_M;
+  constexpr int WN = BN / WAVES_N;
+  constexpr int TM = WM / 16;
+  constexpr int TN = WN / 16;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BM % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int kc = tid & 7;
+  const int r0 = tid >> 3;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ sp = (const T*)p.skip;
+  const T* __restrict__ wp = (const T*)p.w;
+  const bool has_pro = p.pro_a != nullptr;
+  const bool has_skip = p.skip != nullptr;
+
+  // ---- per-row (output pixel) state, fixed for the whole K loop ----
+  int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const long long m = m0 + r0 + i * 32;
+    if (m < p.M) {
+      const int ow = (int)(m % p.Wo);
+      long long t = m / p.Wo;
+      const int oh = (int)(t % p.Ho);
+      t /= p.Ho;
+      const int od = (int)(t % p.Do);
+      rn[i] = (int)(t / p.Do);
+      rid[i] = od * p.sd - p.pd;
+      rih[i] = oh * p.sh - p.ph;
+      riw[i] = ow * p.sw - p.pw;
+    } else {
+      rn[i] = 0;
+      rid[i] = -(1 << 28);
+      rih[i] = -(1 << 28);
+      riw[i] = -(1 << 28);
+    }
+  }
+
+  // ---- per-thread k state: this thread always stages 16-byte chunk `kc` of the K tile ----
+  int k = kc * CH;
+  int c, kd, kh, kw;
+  {
+    const int tap = k / p.Cin;
+    c = k - tap * p.Cin;
+    kw = tap % p.KW;
+    const int t = tap / p.KW;
+    kh = t % p.KH;
+    kd = t / p.KH;
+  }
+
+  u32x4 areg[A_IT], sreg[A_IT], breg[B_IT];
+  float pa[CH], pb[CH];
+  unsigned okmask = 0;
+
+  auto load_tile = [&]() {
+    okmask = 0;
+    const bool kvalid = kd < p.KD;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
+      const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                      (unsigned)iw < (unsigned)p.We;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      u32x4 s = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const long long src =
+            (((long long)rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw);
+        v = *(const u32x4*)(xp + src * p.ldx + c);
+        if (has_skip) {
+          const long long e = (((long long)rn[i] * p.De + id) * p.He + ih) * p.We + iw;
+          s = *(const u32x4*)(sp + e * p.ldskip + c);
+        }
+        okmask |= 1u << i;
+      }
+      areg[i] = v;
+      sreg[i] = s;
+    }
+    if (has_pro && kvalid) {
+#pragma unroll
+      for (int j = 0; j < CH; j += 4) {
+        const f32x4 a4 = *(const f32x4*)(p.pro_a + c + j);
+        const f32x4 b4 = *(const f32x4*)(p.pro_b + c + j);
+        pa[j] = a4.x; pa[j + 1] = a4.y; pa[j + 2] = a4.z; pa[j + 3] = a4.w;
+        pb[j] = b4.x; pb[j + 1] = b4.y; pb[j + 2] = b4.z; pb[j + 3] = b4.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int row = r0 + j * 32;
+      const int col = n0 + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < BN && col < p.Cout && k < p.Ktot) v = *(const u32x4*)(wp + (long long)col * p.Ktot + k);
+      breg[j] = v;
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + BM * 128;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      u32x4 v = areg[i];
+      if ((has_pro || has_skip) && ((okmask >> i) & 1u)) {
+        float f[CH], g[CH];
+        Chunk<T>::unpack(v, f);
+        if (has_pro) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            f[j] = pa[j] * f[j] + pb[j];
+            if (p.pro_relu) f[j] = f[j] > 0.f ? f[j] : 0.f;
+          }
+        }
+        if (has_skip) {
+          Chunk<T>::unpack(sreg[i], g);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) f[j] += g[j];
+        }
+        v = Chunk<T>::pack(f);
+      }
+      *(u32x4*)(As + lds_chunk_off(r0 + i * 32, kc)) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int row = r0 + j * 32;
+      if (row < BN) *(u32x4*)(Bs + lds_chunk_off(row, kc)) = breg[j];
+    }
+  };
+
+  auto advance = [&]() {
+    k += BK;
+    c += BK;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      if (++kw == p.KW) {
+        kw = 0;
+        if (++kh == p.KH) {
+          kh = 0;
+          ++kd;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.Ktot + BK - 1) / BK;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      advance();
+      load_tile();
+    }
+    {
+      const char* As = smem + buf * STAGE;
+      const char* Bs = As + BM * 128;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int chunk = kg * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(As + lds_chunk_off(wm * WM + i * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(Bs + lds_chunk_off(wn * WN + j * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, dropout, optional accumulate, store ----
+  T* __restrict__ yp = (T*)p.y;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[n];
+        if (p.drop_scale != 0.f) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, p.drop_seed);
+          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
+        }
+        T* q = yp + m * p.ldy + n;
+        if (p.accumulate) v += Chunk<T>::load1(q);
+        Chunk<T>::store1(q, v);
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// filter gradient.  GEMM view: rows = Cout, cols = k (tap*Cin + c), contraction over output pixels.
+// Both operands are channel-contiguous in HBM but the MFMA wants them pixel-contiguous per lane, so the
+// staging pass transposes on the way into LDS ([channel][pixel] tiles, same 128-byte rows / swizzle).
+// The pixel range is split across blockIdx.z; partial results are accumulated with float atomics.
+__device__ __forceinline__ int wg_swz(int row) { return (row ^ (row >> 3)) & 7; }
+
+template <typename T, int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int PX = 8 * CH;          // pixels per step = elements per 128-byte LDS row
+  constexpr int BKC = 128;            // k columns per workgroup
+  constexpr int NCC = BKC / CH;       // 16-byte chunk columns of the x tile
+  constexpr int X_IT = PX * NCC / 256;
+  constexpr int NDC = BCO / CH;       // chunk columns of the dy tile
+  constexpr int D_IT = (PX * NDC + 255) / 256;
+  constexpr int TM = BCO / 16;
+  constexpr int TN = 2;
+  constexpr int STAGE = (BCO + BKC) * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ sp = (const T*)p.skip;
+  const T* __restrict__ dyp = (const T*)p.y;
+  const bool has_pro = p.pro_a != nullptr;
+  const bool has_skip = p.skip != nullptr;
+
+  const int kcol0 = blockIdx.x * BKC;
+  const int co0 = blockIdx.y * BCO;
+  const long long m_begin = (long long)blockIdx.z * rows_per_split;
+  long long m_end = m_begin + rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  // ---- fixed k column of this thread (x tile) ----
+  const int kcc = tid % NCC;
+  const int pxl = tid / NCC;
+  const int kk = kcol0 + kcc * CH;
+  const bool kvalid = kk < p.Ktot;
+  int c = 0, kd = 0, kh = 0, kw = 0;
+  if (kvalid) {
+    const int tap = kk / p.Cin;
+    c = kk - tap * p.Cin;
+    kw = tap % p.KW;
+    const int t = tap / p.KW;
+    kh = t % p.KH;
+    kd = t / p.KH;
+  }
+  float pa[CH], pb[CH];
+  if (has_pro && kvalid) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { pa[j] = p.pro_a[c + j]; pb[j] = p.pro_b[c + j]; }
+  }
+  // ---- per pixel-slot state (x tile) ----
+  int sn[X_IT], sod[X_IT], soh[X_IT], sow[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const long long m = m_begin + pxl + i * (256 / NCC);
+    const int ow = (int)(m % p.Wo);
+    long long t = m / p.Wo;
+    const int oh = (int)(t % p.Ho);
+    t /= p.Ho;
+    sod[i] = (int)(t % p.Do);
+    sn[i] = (int)(t / p.Do);
+    soh[i] = oh;
+    sow[i] = ow;
+  }
+
+  u32x4 xreg[X_IT], sreg[X_IT], dreg[D_IT];
+  unsigned okmask = 0;
+
+  auto load_tile = [&](long long mt) {
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const long long m = mt + pxl + i * (256 / NCC);
+      const int id = sod[i] * p.sd - p.pd + kd, ih = soh[i] * p.sh - p.ph + kh, iw = sow[i] * p.sw - p.pw + kw;
+      const bool ok = kvalid && m < m_end && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                      (unsigned)iw < (unsigned)p.We;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      u32x4 s = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const long long src =
+            (((long long)sn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw);
+        v = *(const u32x4*)(xp + src * p.ldx + c);
+        if (has_skip) {
+          const long long e = (((long long)sn[i] * p.De + id) * p.He + ih) * p.We + iw;
+          s = *(const u32x4*)(sp + e * p.ldskip + c);
+        }
+        okmask |= 1u << i;
+      }
+      xreg[i] = v;
+      sreg[i] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < D_IT; ++j) {
+      const int q = tid + j * 256;
+      const int dcc = q % NDC;
+      const int dpx = q / NDC;
+      const long long m = mt + dpx;
+      const int co = co0 + dcc * CH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (dpx < PX && m < m_end && co < p.Cout) v = *(const u32x4*)(dyp + m * p.ldy + co);
+      dreg[j] = v;
+    }
+  };
+
+  auto advance_pixels = [&]() {
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      sow[i] += PX;
+      while (sow[i] >= p.Wo) {
+        sow[i] -= p.Wo;
+        if (++soh[i] == p.Ho) {
+          soh[i] = 0;
+          if (++sod[i] == p.Do) {
+            sod[i] = 0;
+            ++sn[i];
+          }
+        }
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* At = smem + buf * STAGE;       // [BCO][PX]  dy^T
+    char* Bt = At + BCO * 128;           // [BKC][PX]  x_eff^T
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      float f[CH];
+      Chunk<T>::unpack(xreg[i], f);
+      if ((okmask >> i) & 1u) {
+        if (has_pro) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            f[j] = pa[j] * f[j] + pb[j];
+            if (p.pro_relu) f[j] = f[j] > 0.f ? f[j] : 0.f;
+          }
+        }
+        if (has_skip) {
+          float g[CH];
+          Chunk<T>::unpack(sreg[i], g);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) f[j] += g[j];
+        }
+      }
+      const int px = pxl + i * (256 / NCC);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int row = kcc * CH + j;
+        T* q = (T*)(Bt + row * 128 + (((px / CH) ^ wg_swz(row)) << 4)) + (px % CH);
+        Chunk<T>::store1(q, f[j]);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < D_IT; ++jj) {
+      const int q = tid + jj * 256;
+      const int dcc = q % NDC;
+      const int dpx = q / NDC;
+      if (dpx < PX) {
+        float f[CH];
+        Chunk<T>::unpack(dreg[jj], f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const int row = dcc * CH + j;
+          T* qq = (T*)(At + row * 128 + (((dpx / CH) ^ wg_swz(row)) << 4)) + (dpx % CH);
+          Chunk<T>::store1(qq, f[j]);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (int)((m_end - m_begin + PX - 1) / PX);
+  if (nsteps > 0) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < nsteps;
+    if (more) {
+      advance_pixels();
+      load_tile(m_begin + (long long)(st + 1) * PX);
+    }
+    {
+      const char* At = smem + buf * STAGE;
+      const char* Bt = At + BCO * 128;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int chunk = kg * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = i * 16 + (lane & 15);
+          af[i] = *(const u32x4*)(At + row * 128 + ((chunk ^ wg_swz(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = wave * 32 + j * 16 + (lane & 15);
+          bf[j] = *(const u32x4*)(Bt + row * 128 + ((chunk ^ wg_swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int kcol = kcol0 + wave * 32 + j * 16 + (lane & 15);
+        if (kcol < p.Ktot) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
+      }
+    }
+}
+
+// =====================================================================================
+// strided data gradient (only the stride-2 stems need it; tiny share of the FLOPs): direct gather form,
+// one thread per (input pixel, 16-byte channel chunk).  w is the forward filter [Cout][T][Cin] in dtype T.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_dgrad_strided_kernel(ConvK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.Cin / CH;
+  const long long total = (long long)p.N * p.Di * p.Hi * p.Wi * ncc;
+  const T* __restrict__ dyp = (const T*)p.y;
+  const T* __restrict__ wp = (const T*)p.w;
+  T* __restrict__ dxp = (T*)p.x;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(q % ncc);
+    long long pix = q / ncc;
+    const int iw = (int)(pix % p.Wi);
+    long long t = pix / p.Wi;
+    const int ih = (int)(t % p.Hi);
+    t /= p.Hi;
+    const int id = (int)(t % p.Di);
+    const int n = (int)(t / p.Di);
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+    for (int kd = 0; kd < p.KD; ++kd) {
+      const int td = id + p.pd - kd;
+      if (td < 0 || td % p.sd) continue;
+      const int od = td / p.sd;
+      if (od >= p.Do) continue;
+      for (int kh = 0; kh < p.KH; ++kh) {
+        const int th = ih + p.ph - kh;
+        if (th < 0 || th % p.sh) continue;
+        const int oh = th / p.sh;
+        if (oh >= p.Ho) continue;
+        for (int kw = 0; kw < p.KW; ++kw) {
+          const int tw = iw + p.pw - kw;
+          if (tw < 0 || tw % p.sw) continue;
+          const int ow = tw / p.sw;
+          if (ow >= p.Wo) continue;
+          const long long m = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+          const int tap = (kd * p.KH + kh) * p.KW + kw;
+          const T* dyr = dyp + m * p.ldy;
+          const T* wr = wp + (long long)tap * p.Cin + cc * CH;
+          for (int co = 0; co < p.Cout; ++co) {
+            const float g = Chunk<T>::load1(dyr + co);
+            float wv[CH];
+            Chunk<T>::unpack(*(const u32x4*)(wr + (long long)co * p.Ktot), wv);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[j] += g * wv[j];
+          }
+        }
+      }
+    }
+    T* o = dxp + pix * p.ldx + cc * CH;
+    if (p.accumulate) {
+      float old[CH];
+      Chunk<T>::unpack(*(const u32x4*)o, old);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += old[j];
+    }
+    *(u32x4*)o = Chunk<T>::pack(acc);
+  }
+}
+
+// =====================================================================================
+// filter preparation: float32 master [Cout][T][Cin] -> compute dtype forward copy (same layout) and the
+// data-gradient filter [Cin][T flipped][Cout].
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ wm, int Cout, int Tn, int Cin,
+                                                         T* __restrict__ wf, T* __restrict__ wd) {
+  const long long total = (long long)Cout * Tn * Cin;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(q % Cin);
+    const long long t2 = q / Cin;
+    const int t = (int)(t2 % Tn);
+    const int co = (int)(t2 / Tn);
+    const float v = wm[q];
+    if (wf) Chunk<T>::store1(wf + q, v);
+    if (wd) Chunk<T>::store1(wd + ((long long)ci * Tn + (Tn - 1 - t)) * Cout + co, v);
+  }
+}
+
+// ------------------------------------------------------------------ host-side dispatch
+#include "hdu_host.h"
+
+static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
+  if (!d) return hdu_set_error(HDU_ERR_ARG, "conv: null descriptor");
+  if (d->dtype != HDU_BF16 && d->dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "conv: bad dtype");
+  const int ch = d->dtype == HDU_BF16 ? 8 : 4;
+  if (d->Cin <= 0 || d->Cin % ch) return hdu_set_error(HDU_ERR_ARG, "conv: Cin must be a positive multiple of the 16-byte chunk");
+  if (d->ldx % ch || (d->skip && d->ldskip % ch)) return hdu_set_error(HDU_ERR_ARG, "conv: input pixel stride must be a multiple of the 16-byte chunk");
+  if (wgrad && (d->ldy % ch || d->Cout % ch)) return hdu_set_error(HDU_ERR_ARG, "conv_wgrad: dy stride / Cout must be multiples of the 16-byte chunk");
+  if ((uintptr_t)d->x % 16 || (uintptr_t)d->w % 16 || (d->skip && (uintptr_t)d->skip % 16))
+    return hdu_set_error(HDU_ERR_ARG, "conv: x / w / skip must be 16-byte aligned");
+  if ((d->ud | d->uh | d->uw) & ~1) return hdu_set_error(HDU_ERR_ARG, "conv: upsample shifts must be 0 or 1");
+  if (d->KD <= 0 || d->KH <= 0 || d->KW <= 0 || d->sd <= 0 || d->sh <= 0 || d->sw <= 0)
+    return hdu_set_error(HDU_ERR_ARG, "conv: bad kernel/stride");
+  if ((d->pro_a == nullptr) != (d->pro_b == nullptr)) return hdu_set_error(HDU_ERR_ARG, "conv: pro_a/pro_b must both be set");
+  k->x = d->x; k->skip = d->skip; k->w = d->w; k->y = d->y;
+  k->pro_a = d->pro_a; k->pro_b = d->pro_b; k->bias = d->bias;
+  k->ldx = d->ldx; k->ldskip = d->ldskip; k->ldy = d->ldy;
+  k->N = d->N; k->Di = d->Di; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin;
+  k->ud = d->ud; k->uh = d->uh; k->uw = d->uw;
+  k->De = d->Di << d->ud; k->He = d->Hi << d->uh; k->We = d->Wi << d->uw;
+  k->KD = d->KD; k->KH = d->KH; k->KW = d->KW;
+  k->sd = d->sd; k->sh = d->sh; k->sw = d->sw;
+  k->pd = d->pd; k->ph = d->ph; k->pw = d->pw;
+  k->Do = d->Do; k->Ho = d->Ho; k->Wo = d->Wo; k->Cout = d->Cout;
+  const int eDo = (k->De + 2 * d->pd - d->KD) / d->sd + 1;
+  const int eHo = (k->He + 2 * d->ph - d->KH) / d->sh + 1;
+  const int eWo = (k->We + 2 * d->pw - d->KW) / d->sw + 1;
+  if (eDo != d->Do || eHo != d->Ho || eWo != d->Wo)
+    return hdu_set_error(HDU_ERR_ARG, "conv: output dims inconsistent with input dims / kernel / stride / pad");
+  k->M = (long long)d->N * d->Do * d->Ho * d->Wo;
+  k->Ktot = d->KD * d->KH * d->KW * d->Cin;
+  k->pro_relu = d->pro_relu; k->accumulate = d->accumulate;
+  if (d->drop_keep > 0.f && d->drop_keep < 1.f) {
+    k->drop_scale = 1.f / d->drop_keep;
+    k->drop_thresh = (unsigned)((double)d->drop_keep * 4294967296.0);
+  } else {
+    k->drop_scale = 0.f;
+    k->drop_thresh = 0xffffffffu;
+  }
+  k->drop_seed = d->drop_seed;
+  return 0;
+}
+
+template <typename T, int BM, int BN, int WMv, int WNv>
+static void launch_igemm(const ConvK& k, hipStream_t s) {
+  dim3 grid((unsigned)((k.M + BM - 1) / BM), (unsigned)((k.Cout + BN - 1) / BN), 1);
+  HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+}
+
+template <typename T>
+static void dispatch_igemm(const ConvK& k, hipStream_t s) {
+  // pick the N tile that wastes the fewest padded output channels; ties -> widest tile
+  const int cands[4] = {128, 64, 48, 32};
+  int best = 64;
+  long long best_cost = -1;
+  for (int i = 0; i < 4; ++i) {
+    const int bn = cands[i];
+    if (bn == 128 && (k.Cout < 256 || k.M < 4096)) continue;
+    const long long padded = (long long)((k.Cout + bn - 1) / bn) * bn;
+    if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = bn; }
+  }
+  if (k.M <= 2048 && best != 128) {
+    // small images: 64-row tiles give more workgroups
+    switch (best) {
+      case 64: launch_igemm<T, 64, 64, 2, 2>(k, s); return;
+      case 48: launch_igemm<T, 64, 48, 4, 1>(k, s); return;
+      default: launch_igemm<T, 64, 32, 2, 2>(k, s); return;
+    }
+  }
+  switch (best) {
+    case 128: launch_igemm<T, 128, 128, 2, 2>(k, s); return;
+    case 64: launch_igemm<T, 128, 64, 4, 1>(k, s); return;
+    case 48: launch_igemm<T, 128, 48, 4, 1>(k, s); return;
+    default: launch_igemm<T, 128, 32, 4, 1>(k, s); return;
+  }
+}
+
+extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
+  ConvK k;
+  if (int e = fill_convk(d, &k, false)) return e;
+  if (!d->y) return hdu_set_error(HDU_ERR_ARG, "conv_fprop: null output");
+  if (k.M == 0) return 0;
+  if (d->dtype == HDU_BF16) dispatch_igemm<bf16_t>(k, (hipStream_t)stream);
+  else dispatch_igemm<float>(k, (hipStream_t)stream);
+  return hdu_check_launch("conv_fprop");
+}
+
+template <typename T, int BCO>
+static void launch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
+  constexpr int PX = 8 * Chunk<T>::CH;
+  const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
+  // enough pixel splits to fill the chip (~4 workgroups per CU), each a multiple of the pixel step
+  long long want = 1024 / ((long long)gx * gy);
+  if (want < 1) want = 1;
+  long long steps = (k.M + PX - 1) / PX;
+  if (want > steps) want = steps;
+  long long steps_per = (steps + want - 1) / want;
+  const long long rows_per = steps_per * PX;
+  const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);
+  HDU_LAUNCH((conv_wgrad_kernel<T, BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
+}
+
+template <typename T>
+static void dispatch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
+  const int cands[3] = {64, 48, 32};
+  int best = 64;
+  long long best_cost = -1;
+  for (int i = 0; i < 3; ++i) {
+    const long long padded = (long long)((k.Cout + cands[i] - 1) / cands[i]) * cands[i];
+    if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = cands[i]; }
+  }
+  if (best == 64) launch_wgrad<T, 64>(k, dw, s);
+  else if (best == 48) launch_wgrad<T, 48>(k, dw, s);
+  else launch_wgrad<T, 32>(k, dw, s);
+}
+
+extern "C" int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream) {
+  ConvK k;
+  if (int e = fill_convk(d, &k, true)) return e;
+  if (!dw || !d->y) return hdu_set_error(HDU_ERR_ARG, "conv_wgrad: null dw / dy");
+  if ((uintptr_t)d->y % 16) return hdu_set_error(HDU_ERR_ARG, "conv_wgrad: dy must be 16-byte aligned");
+  if (k.M == 0) return 0;
+  if (d->dtype == HDU_BF16) dispatch_wgrad<bf16_t>(k, dw, (hipStream_t)stream);
+  else dispatch_wgrad<float>(k, dw, (hipStream_t)stream);
+  return hdu_check_launch("conv_wgrad");
+}
+
+extern "C" int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream) {
+  ConvK k;
+  if (int e = fill_convk(d, &k, false)) return e;
+  if (d->ud | d->uh | d->uw) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: upsampled input not supported");
+  if (!d->x || !d->y) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: null dx / dy");
+  const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * (d->Cin / (d->dtype == HDU_BF16 ? 8 : 4));
+  if (total == 0) return 0;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (d->dtype == HDU_BF16)
+    HDU_LAUNCH((conv_dgrad_strided_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  else
+    HDU_LAUNCH((conv_dgrad_strided_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
+  return hdu_check_launch("conv_dgrad_strided");
+}
+
+extern "C" int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, void* w_f, void* w_d,
+                               void* stream) {
+  if (!w_master || Cout <= 0 || T <= 0 || Cin <= 0) return hdu_set_error(HDU_ERR_ARG, "weight_prep: bad args");
+  const long long total = (long long)Cout * T * Cin;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == HDU_BF16)
+    HDU_LAUNCH((weight_prep_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_master,
+               Cout, T, Cin, (bf16_t*)w_f, (bf16_t*)w_d);
+  else if (dtype == HDU_F32)
+    HDU_LAUNCH((weight_prep_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_master,
+               Cout, T, Cin, (float*)w_f, (float*)w_d);
+  else
+    return hdu_set_error(HDU_ERR_ARG, "weight_prep: bad dtype");
+  return hdu_check_launch("weight_prep");
+}

@@ -1,0 +1,130 @@
+// hdu_platform.h -- build-target glue.
+//
+// The product build is gfx950 only (hipcc --offload-arch=gfx950).  The same
+// sources also compile for x86 with -DHDU_EMU against tests/hipemu (test
+// infrastructure: lets the CPU-only test tier execute kernel logic).  There is
+// no other platform and no runtime dispatch between the two.
+#pragma once
+
+#ifdef HDU_EMU
+#include "hipemu.h"
+#define HDU_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define HDU_DYN_SMEM(name) char* name = hipemu::g_cur->dyn_smem
+#define HDU_LANE() (hipemu::g_cur->lane)
+#define HDU_LAUNCH_OK() 0
+#else
+#include <hip/hip_runtime.h>
+#define HDU_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define HDU_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define HDU_LANE() ((int)(threadIdx.x & 63))
+#define HDU_LAUNCH_OK() ((int)hipGetLastError())
+#endif
+
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef HDU_EMU
+typedef __bf16 hdu_bf16x8 __attribute__((ext_vector_type(8)));
+#endif
+
+
+// NOTE: never __builtin_bit_cast a vector-element lvalue (v.y) directly -- clang reads element 0 of the
+// vector's storage.  These by-value helpers force an rvalue.
+__host__ __device__ __forceinline__ float hdu_u2f(unsigned u) { return __builtin_bit_cast(float, u); }
+__host__ __device__ __forceinline__ unsigned hdu_f2u(float f) { return __builtin_bit_cast(unsigned, f); }
+
+// ---- bf16 storage helpers (raw 16-bit patterns; round-to-nearest-even) ----
+typedef unsigned short bf16_t;
+
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  unsigned u = hdu_f2u(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+// ---- 16-byte chunk <-> float lanes, per storage type ----
+template <typename T> struct Chunk;  // CH elements per 16 bytes
+
+template <> struct Chunk<float> {
+  static constexpr int CH = 4;
+  __device__ __forceinline__ static void unpack(u32x4 v, float* f) {
+    f[0] = hdu_u2f(v.x); f[1] = hdu_u2f(v.y);
+    f[2] = hdu_u2f(v.z); f[3] = hdu_u2f(v.w);
+  }
+  __device__ __forceinline__ static u32x4 pack(const float* f) {
+    return u32x4{hdu_f2u(f[0]), hdu_f2u(f[1]),
+                 hdu_f2u(f[2]), hdu_f2u(f[3])};
+  }
+  __device__ __forceinline__ static float load1(const float* p) { return *p; }
+  __device__ __forceinline__ static void store1(float* p, float v) { *p = v; }
+};
+
+template <> struct Chunk<bf16_t> {
+  static constexpr int CH = 8;
+  __device__ __forceinline__ static void unpack(u32x4 v, float* f) {
+    f[0] = hdu_u2f(v.x << 16); f[1] = hdu_u2f(v.x & 0xffff0000u);
+    f[2] = hdu_u2f(v.y << 16); f[3] = hdu_u2f(v.y & 0xffff0000u);
+    f[4] = hdu_u2f(v.z << 16); f[5] = hdu_u2f(v.z & 0xffff0000u);
+    f[6] = hdu_u2f(v.w << 16); f[7] = hdu_u2f(v.w & 0xffff0000u);
+  }
+  __device__ __forceinline__ static u32x4 pack(const float* f) {
+    return u32x4{(unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16),
+                 (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16),
+                 (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16),
+                 (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16)};
+  }
+  __device__ __forceinline__ static float load1(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ __forceinline__ static void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// ---- MFMA wrappers: one "k-group" = 16 bytes of k per lane for A and B ----
+// bf16: one v_mfma_f32_16x16x32_bf16 (K=32); f32: four v_mfma_f32_16x16x4_f32
+// (K=16, lane's 4 consecutive k are fed as 4 successive k-slices; A and B use
+// the same permutation of k so the contraction is unchanged).
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16_t> {
+  __device__ __forceinline__ static f32x4 kgroup(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef HDU_EMU
+    return hipemu_mfma_16x16x32_bf16(__builtin_bit_cast(hipemu_u16x8, a), __builtin_bit_cast(hipemu_u16x8, b), c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hdu_bf16x8, a),
+                                                   __builtin_bit_cast(hdu_bf16x8, b), c, 0, 0, 0);
+#endif
+  }
+};
+template <> struct Mma<float> {
+  __device__ __forceinline__ static f32x4 kgroup(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef HDU_EMU
+    c = hipemu_mfma_16x16x4_f32(hdu_u2f(a.x), hdu_u2f(b.x), c);
+    c = hipemu_mfma_16x16x4_f32(hdu_u2f(a.y), hdu_u2f(b.y), c);
+    c = hipemu_mfma_16x16x4_f32(hdu_u2f(a.z), hdu_u2f(b.z), c);
+    c = hipemu_mfma_16x16x4_f32(hdu_u2f(a.w), hdu_u2f(b.w), c);
+#else
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(hdu_u2f(a.x), hdu_u2f(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(hdu_u2f(a.y), hdu_u2f(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(hdu_u2f(a.z), hdu_u2f(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(hdu_u2f(a.w), hdu_u2f(b.w), c, 0, 0, 0);
+#endif
+    return c;
+  }
+};
+
+// counter-based hash RNG for dropout masks (stateless; fwd and bwd regenerate the same mask)
+__host__ __device__ __forceinline__ unsigned hdu_hash32(unsigned long long idx, unsigned seed) {
+  unsigned long long z = idx + 0x9E3779B97F4A7C15ull * (unsigned long long)(seed + 1u);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (unsigned)(z >> 32);
+}

@@ -1,0 +1,918 @@
+// rowops.hip -- the HBM-bound kernels of the hot path: per-channel reductions (BN statistics, BN
+// backward sums, bias gradients), the BN(+Scale) fold / backward coefficient kernels, element-wise
+// apply kernels, pooling, nearest-upsample gradient, weighted cross-entropy, Nesterov SGD and the
+// 2.5D <-> 3D plumbing.  All activations are channels-last rows [M][ld]; every thread moves 16-byte
+// chunks (8 bf16 / 4 f32) so a wavefront touches contiguous 1 KiB runs whenever C allows it.
+#include "hdu_host.h"
+
+// ====================================================================== per-channel reductions
+enum { RED_STATS = 0, RED_BNBWD = 1, RED_COLSUM = 2 };
+
+struct RedK {
+  const void* x;
+  const void* dz;
+  long long ldx, lddz, M, rows_per_block;
+  int C;
+  int relu;
+  const float* a;
+  const float* b;
+  const float* mean;
+  const float* rstd;
+  float* partial;  // [gridDim.x][2][C]
+};
+
+template <typename T, int MODE, int COLS>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[2][ROWS][COLS * CH];
+  const int tid = threadIdx.x;
+  const int cc = tid % COLS;
+  const int rl = tid / COLS;
+  const int c0 = (blockIdx.y * COLS + cc) * CH;
+  const bool active = c0 < p.C;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dzp = (const T*)p.dz;
+
+  float s1[CH], s2[CH], k0[CH], k1[CH], k2[CH], k3[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; k0[j] = 0.f; k1[j] = 0.f; k2[j] = 0.f; k3[j] = 0.f; }
+  if (active) {
+    if (MODE == RED_STATS) {
+      // shifted sums: the shift (row 0 of the tensor) removes the cancellation of E[x^2]-E[x]^2
+      Chunk<T>::unpack(*(const u32x4*)(xp + c0), k0);
+    } else if (MODE == RED_BNBWD) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        k0[j] = p.a[c0 + j]; k1[j] = p.b[c0 + j]; k2[j] = p.mean[c0 + j]; k3[j] = p.rstd[c0 + j];
+      }
+    }
+    const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+    long long r_end = r_begin + p.rows_per_block;
+    if (r_end > p.M) r_end = p.M;
+    for (long long r = r_begin + rl; r < r_end; r += ROWS) {
+      float f[CH];
+      Chunk<T>::unpack(*(const u32x4*)(xp + r * p.ldx + c0), f);
+      if (MODE == RED_STATS) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float d = f[j] - k0[j]; s1[j] += d; s2[j] += d * d; }
+      } else if (MODE == RED_BNBWD) {
+        float g[CH];
+        Chunk<T>::unpack(*(const u32x4*)(dzp + r * p.lddz + c0), g);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float s = k0[j] * f[j] + k1[j];
+          const float gg = (!p.relu || s > 0.f) ? g[j] : 0.f;
+          s1[j] += gg;
+          s2[j] += gg * ((f[j] - k2[j]) * k3[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) s1[j] += f[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { red[0][rl][cc * CH + j] = s1[j]; red[1][rl][cc * CH + j] = s2[j]; }
+  __syncthreads();
+  for (int q = tid; q < 2 * COLS * CH; q += 256) {
+    const int s = q / (COLS * CH);
+    const int col = q % (COLS * CH);
+    const int c = blockIdx.y * COLS * CH + col;
+    if (c < p.C) {
+      float t = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < ROWS; ++r) t += red[s][r][col];
+      p.partial[((long long)blockIdx.x * 2 + s) * p.C + c] = t;
+    }
+  }
+}
+
+// sums the per-block partials in double and post-processes per mode
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              long long M, const void* x, float* __restrict__ o1,
+                                                              float* __restrict__ o2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    a1 += (double)partial[((long long)b * 2 + 0) * C + c];
+    a2 += (double)partial[((long long)b * 2 + 1) * C + c];
+  }
+  if (MODE == RED_STATS) {
+    const double shift = (double)Chunk<T>::load1((const T*)x + c);
+    const double m1 = a1 / (double)M;
+    double var = a2 / (double)M - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    o1[c] = (float)(shift + m1);
+    o2[c] = (float)var;
+  } else {
+    o1[c] = (float)a1;
+    if (o2) o2[c] = (float)a2;
+  }
+}
+
+static int red_cols_for(int nchunks) {
+  int cols = 4;
+  while (cols < nchunks && cols < 32) cols <<= 1;
+  return cols;
+}
+static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx, unsigned* gy, long long* rpb) {
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  const int nchunks = (C + ch - 1) / ch;
+  *cols = red_cols_for(nchunks);
+  *gy = (unsigned)((nchunks + *cols - 1) / *cols);
+  const int rows = 256 / *cols;
+  long long want = 2048 / *gy;
+  if (want < 1) want = 1;
+  long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);  // >= 4 rows per thread
+  if (maxb < 1) maxb = 1;
+  if (want > maxb) want = maxb;
+  *rpb = (M + want - 1) / want;
+  if (*rpb < 1) *rpb = 1;
+  *gx = (unsigned)((M + *rpb - 1) / *rpb);
+  if (*gx < 1) *gx = 1;
+}
+
+extern "C" size_t hdu_reduce_ws_bytes(int64_t M, int C) {
+  // geometry upper bound over both dtypes
+  size_t best = 0;
+  for (int dt = 0; dt < 2; ++dt) {
+    int cols; unsigned gx, gy; long long rpb;
+    red_geometry(dt, M, C, &cols, &gx, &gy, &rpb);
+    size_t b = (size_t)gx * 2 * (size_t)C * sizeof(float);
+    if (b > best) best = b;
+  }
+  return best + 256;
+}
+
+template <typename T, int MODE>
+static int run_reduce(RedK k, int cols, unsigned gx, unsigned gy, hipStream_t s) {
+  switch (cols) {
+    case 4: HDU_LAUNCH((reduce_rows_kernel<T, MODE, 4>), dim3(gx, gy), dim3(256), 0, s, k); break;
+    case 8: HDU_LAUNCH((reduce_rows_kernel<T, MODE, 8>), dim3(gx, gy), dim3(256), 0, s, k); break;
+    case 16: HDU_LAUNCH((reduce_rows_kernel<T, MODE, 16>), dim3(gx, gy), dim3(256), 0, s, k); break;
+    default: HDU_LAUNCH((reduce_rows_kernel<T, MODE, 32>), dim3(gx, gy), dim3(256), 0, s, k); break;
+  }
+  return 0;
+}
+
+template <int MODE>
+static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_t ws_bytes, hipStream_t s,
+                        const char* what) {
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "reduce: bad dtype");
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if (k.C <= 0 || k.C % ch || k.ldx % ch || (k.dz && k.lddz % ch))
+    return hdu_set_error(HDU_ERR_ARG, "reduce: C and pixel strides must be multiples of the 16-byte chunk");
+  if (k.M <= 0) return hdu_set_error(HDU_ERR_ARG, "reduce: M must be positive");
+  int cols; unsigned gx, gy; long long rpb;
+  red_geometry(dtype, k.M, k.C, &cols, &gx, &gy, &rpb);
+  if (!ws || ws_bytes < (size_t)gx * 2 * (size_t)k.C * sizeof(float))
+    return hdu_set_error(HDU_ERR_WORKSPACE, "reduce: workspace too small (see hdu_reduce_ws_bytes)");
+  k.rows_per_block = rpb;
+  k.partial = (float*)ws;
+  const unsigned fb = (unsigned)((k.C + 255) / 256);
+  if (dtype == HDU_BF16) {
+    run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
+    HDU_LAUNCH((reduce_finalize_kernel<bf16_t, MODE>), dim3(fb), dim3(256), 0, s, (const float*)ws, (int)gx, k.C,
+               k.M, k.x, o1, o2);
+  } else {
+    run_reduce<float, MODE>(k, cols, gx, gy, s);
+    HDU_LAUNCH((reduce_finalize_kernel<float, MODE>), dim3(fb), dim3(256), 0, s, (const float*)ws, (int)gx, k.C, k.M,
+               k.x, o1, o2);
+  }
+  return hdu_check_launch(what);
+}
+
+extern "C" int hdu_bn_stats(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* mean, float* var,
+                            void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !mean || !var) return hdu_set_error(HDU_ERR_ARG, "bn_stats: null pointer");
+  RedK k{};
+  k.x = x; k.ldx = ldx; k.M = M; k.C = C;
+  return reduce_entry<RED_STATS>(dtype, k, mean, var, ws, ws_bytes, (hipStream_t)stream, "bn_stats");
+}
+
+extern "C" int hdu_bn_bwd_reduce(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
+                                 int C, const float* a, const float* b, int relu, const float* mean,
+                                 const float* rstd, float* s1, float* s2, void* ws, size_t ws_bytes, void* stream) {
+  if (!dz || !x || !a || !b || !mean || !rstd || !s1 || !s2) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_reduce: null pointer");
+  RedK k{};
+  k.x = x; k.ldx = ldx; k.dz = dz; k.lddz = lddz; k.M = M; k.C = C;
+  k.a = a; k.b = b; k.mean = mean; k.rstd = rstd; k.relu = relu;
+  return reduce_entry<RED_BNBWD>(dtype, k, s1, s2, ws, ws_bytes, (hipStream_t)stream, "bn_bwd_reduce");
+}
+
+extern "C" int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws,
+                          size_t ws_bytes, void* stream) {
+  if (!x || !out) return hdu_set_error(HDU_ERR_ARG, "colsum: null pointer");
+  RedK k{};
+  k.x = x; k.ldx = ldx; k.M = M; k.C = C;
+  return reduce_entry<RED_COLSUM>(dtype, k, out, nullptr, ws, ws_bytes, (hipStream_t)stream, "colsum");
+}
+
+// ====================================================================== BN fold / backward coefficients
+__global__ __launch_bounds__(256) void bn_fold_kernel(int C, const float* mean, const float* var, const float* gamma,
+                                                      const float* beta, float eps, const float* sgamma,
+                                                      const float* sbeta, float* a, float* b, float* rstd,
+                                                      float* mov_mean, float* mov_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], v = var[c];
+  const float r = 1.0f / sqrtf(v + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  const float be = beta ? beta[c] : 0.f;
+  const float sg = sgamma ? sgamma[c] : 1.f;
+  const float sb = sbeta ? sbeta[c] : 0.f;
+  // tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
+  const float inv = g * r;
+  a[c] = sg * inv;
+  b[c] = sg * (be - mu * inv) + sb;
+  if (rstd) rstd[c] = r;
+  if (mov_mean) mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
+  if (mov_var) mov_var[c] -= (mov_var[c] - v) * (1.f - momentum);
+}
+
+extern "C" int hdu_bn_fold(int C, const float* mean, const float* var, const float* gamma, const float* beta,
+                           float eps, const float* sgamma, const float* sbeta, float* a, float* b, float* rstd,
+                           float* mov_mean, float* mov_var, float momentum, void* stream) {
+  if (C <= 0 || !mean || !var || !a || !b) return hdu_set_error(HDU_ERR_ARG, "bn_fold: bad args");
+  HDU_LAUNCH(bn_fold_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, mean, var,
+             gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum);
+  return hdu_check_launch("bn_fold");
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(int C, float invM, int batch_stats, const float* s1,
+                                                          const float* s2, const float* gamma, const float* beta,
+                                                          const float* sgamma, const float* rstd, float* k1,
+                                                          float* k2, float* k3, float* dgamma, float* dbeta,
+                                                          float* dsgamma, float* dsbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float g = gamma ? gamma[c] : 1.f;
+  const float be = beta ? beta[c] : 0.f;
+  const float sg = sgamma ? sgamma[c] : 1.f;
+  const float r = rstd[c];
+  const float S1 = s1 ? s1[c] : 0.f, S2 = s2 ? s2[c] : 0.f;
+  const float kk = sg * g * r;
+  k1[c] = kk;
+  k2[c] = batch_stats ? kk * S1 * invM : 0.f;
+  k3[c] = batch_stats ? kk * r * S2 * invM : 0.f;
+  // y = g*xhat + beta ; z = sg*y + sb :  d sg = sum g_s*y = g*S2 + beta*S1 ; d sb = S1 ; d g = sg*S2 ; d beta = sg*S1
+  if (dgamma) dgamma[c] = sg * S2;
+  if (dbeta) dbeta[c] = sg * S1;
+  if (dsgamma) dsgamma[c] = g * S2 + be * S1;
+  if (dsbeta) dsbeta[c] = S1;
+}
+
+extern "C" int hdu_bn_bwd_coef(int C, int64_t M, int batch_stats, const float* s1, const float* s2,
+                               const float* gamma, const float* beta, const float* sgamma, const float* rstd,
+                               float* k1, float* k2, float* k3, float* dgamma, float* dbeta, float* dsgamma,
+                               float* dsbeta, void* stream) {
+  if (C <= 0 || M <= 0 || !rstd || !k1 || !k2 || !k3) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_coef: bad args");
+  if (batch_stats && (!s1 || !s2)) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_coef: batch_stats needs s1/s2");
+  HDU_LAUNCH(bn_bwd_coef_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C,
+             1.0f / (float)M, batch_stats, s1, s2, gamma, beta, sgamma, rstd, k1, k2, k3, dgamma, dbeta, dsgamma,
+             dsbeta);
+  return hdu_check_launch("bn_bwd_coef");
+}
+
+// ====================================================================== element-wise row kernels
+struct RowK {
+  const void* x;
+  const void* dz;
+  void* out;
+  long long ldx, lddz, ldo, M;
+  int C;
+  int relu, accumulate;
+  const float* a;
+  const float* b;
+  const float* mean;
+  const float* k1;
+  const float* k2;
+  const float* k3;
+  float drop_scale;
+  unsigned drop_thresh, drop_seed;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = p.M * ncc;
+  const T* __restrict__ xp = (const T*)p.x;
+  T* __restrict__ op = (T*)p.out;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    const long long m = q / ncc;
+    float f[CH];
+    Chunk<T>::unpack(*(const u32x4*)(xp + m * p.ldx + c0), f);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float s = p.a ? p.a[c0 + j] * f[j] + p.b[c0 + j] : f[j];
+      if (p.relu) s = s > 0.f ? s : 0.f;
+      f[j] = s;
+    }
+    *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = p.M * ncc;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dzp = (const T*)p.dz;
+  T* __restrict__ op = (T*)p.out;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    const long long m = q / ncc;
+    float f[CH], g[CH];
+    Chunk<T>::unpack(*(const u32x4*)(xp + m * p.ldx + c0), f);
+    Chunk<T>::unpack(*(const u32x4*)(dzp + m * p.lddz + c0), g);
+    float o[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = c0 + j;
+      const float s = p.a[c] * f[j] + p.b[c];
+      const float gg = (!p.relu || s > 0.f) ? g[j] : 0.f;
+      float d = p.k1[c] * gg - p.k2[c] - p.k3[c] * (f[j] - p.mean[c]);
+      if (p.drop_scale != 0.f) {
+        const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.C + (unsigned)c, p.drop_seed);
+        d = h < p.drop_thresh ? d * p.drop_scale : 0.f;
+      }
+      o[j] = d;
+    }
+    T* dst = op + m * p.ldo + c0;
+    if (p.accumulate) {
+      float old[CH];
+      Chunk<T>::unpack(*(const u32x4*)dst, old);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) o[j] += old[j];
+    }
+    *(u32x4*)dst = Chunk<T>::pack(o);
+  }
+}
+
+static int rowk_check(int dtype, const RowK& k, const char* what) {
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, what);
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if (k.C <= 0 || k.C % ch || k.ldx % ch || k.ldo % ch || (k.dz && k.lddz % ch) || k.M < 0)
+    return hdu_set_error(HDU_ERR_ARG, what);
+  return 0;
+}
+
+extern "C" int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, const float* a,
+                              const float* b, int relu, void* z, int64_t ldz, void* stream) {
+  RowK k{};
+  k.x = x; k.ldx = ldx; k.out = z; k.ldo = ldz; k.M = M; k.C = C; k.a = a; k.b = b; k.relu = relu;
+  if (!x || !z || ((a == nullptr) != (b == nullptr))) return hdu_set_error(HDU_ERR_ARG, "affine_act: bad pointers");
+  if (int e = rowk_check(dtype, k, "affine_act: C / strides must be multiples of the 16-byte chunk")) return e;
+  if (M == 0) return 0;
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  const unsigned g = hdu_grid_1d(M * (C / ch), 256, 4096);
+  if (dtype == HDU_BF16) HDU_LAUNCH((affine_act_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
+  else HDU_LAUNCH((affine_act_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
+  return hdu_check_launch("affine_act");
+}
+
+extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
+                                int C, const float* a, const float* b, int relu, const float* mean, const float* k1,
+                                const float* k2, const float* k3, void* dx, int64_t lddx, int accumulate,
+                                float drop_keep, uint32_t drop_seed, void* stream) {
+  RowK k{};
+  k.x = x; k.ldx = ldx; k.dz = dz; k.lddz = lddz; k.out = dx; k.ldo = lddx; k.M = M; k.C = C;
+  k.a = a; k.b = b; k.relu = relu; k.mean = mean; k.k1 = k1; k.k2 = k2; k.k3 = k3; k.accumulate = accumulate;
+  if (drop_keep > 0.f && drop_keep < 1.f) {
+    k.drop_scale = 1.f / drop_keep;
+    k.drop_thresh = (unsigned)((double)drop_keep * 4294967296.0);
+  }
+  k.drop_seed = drop_seed;
+  if (!x || !dz || !dx || !a || !b || !mean || !k1 || !k2 || !k3) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_apply: null pointer");
+  if (int e = rowk_check(dtype, k, "bn_bwd_apply: C / strides must be multiples of the 16-byte chunk")) return e;
+  if (M == 0) return 0;
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  const unsigned g = hdu_grid_1d(M * (C / ch), 256, 4096);
+  if (dtype == HDU_BF16) HDU_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
+  else HDU_LAUNCH((bn_bwd_apply_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
+  return hdu_check_launch("bn_bwd_apply");
+}
+
+// ====================================================================== pooling / resampling
+struct PoolK {
+  const void* x;
+  const void* dy;
+  void* out;
+  long long ldx, lddy, ldo;
+  int N, D, H, W, C;      // input dims
+  int Do, Ho, Wo;
+  int accumulate;
+  int ud, uh, uw;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = (long long)p.N * p.Do * p.Ho * p.Wo * ncc;
+  const T* __restrict__ xp = (const T*)p.x;
+  T* __restrict__ op = (T*)p.out;
+  const int kdn = p.D == 1 ? 1 : 3, pdd = p.D == 1 ? 0 : 1, sdd = p.D == 1 ? 1 : 2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    long long t = q / ncc;
+    const long long opix = t;
+    const int ow = (int)(t % p.Wo); t /= p.Wo;
+    const int oh = (int)(t % p.Ho); t /= p.Ho;
+    const int od = (int)(t % p.Do);
+    const int n = (int)(t / p.Do);
+    float best[CH];
+    bool any_pad = false;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) best[j] = -3.0e38f;
+    for (int kd = 0; kd < kdn; ++kd) {
+      const int id = od * sdd - pdd + kd;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow * 2 - 1 + kw;
+          if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
+            float f[CH];
+            Chunk<T>::unpack(*(const u32x4*)(xp + ((((long long)n * p.D + id) * p.H + ih) * p.W + iw) * p.ldx + c0), f);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) best[j] = f[j] > best[j] ? f[j] : best[j];
+          } else {
+            any_pad = true;
+          }
+        }
+      }
+    }
+    if (any_pad) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) best[j] = best[j] > 0.f ? best[j] : 0.f;  // the explicit zero padding competes
+    }
+    *(u32x4*)(op + opix * p.ldo + c0) = Chunk<T>::pack(best);
+  }
+}
+
+// gather form of the max-pool gradient: each input pixel visits the <=2 (x2 x2) windows covering it and takes
+// the window's gradient iff it is the first maximal element of that window in scan order.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = (long long)p.N * p.D * p.H * p.W * ncc;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dyp = (const T*)p.dy;
+  T* __restrict__ op = (T*)p.out;
+  const int kdn = p.D == 1 ? 1 : 3, pdd = p.D == 1 ? 0 : 1, sdd = p.D == 1 ? 1 : 2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    long long t = q / ncc;
+    const long long ipix = t;
+    const int iw = (int)(t % p.W); t /= p.W;
+    const int ih = (int)(t % p.H); t /= p.H;
+    const int id = (int)(t % p.D);
+    const int n = (int)(t / p.D);
+    float me[CH], acc[CH];
+    Chunk<T>::unpack(*(const u32x4*)(xp + ipix * p.ldx + c0), me);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+    const int od_lo = p.D == 1 ? 0 : (id > 0 ? (id - 1 + 1) / 2 : 0), od_hi = p.D == 1 ? 0 : (id + 1) / 2;
+    const int oh_lo = ih / 2, oh_hi = (ih + 1) / 2;
+    const int ow_lo = iw / 2, ow_hi = (iw + 1) / 2;
+    for (int od = od_lo; od <= od_hi && od < p.Do; ++od)
+      for (int oh = oh_lo; oh <= oh_hi && oh < p.Ho; ++oh)
+        for (int ow = ow_lo; ow <= ow_hi && ow < p.Wo; ++ow) {
+          // recompute the window: is `me` its first maximum?
+          bool win[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) win[j] = true;
+          bool before = true;
+          for (int kd = 0; kd < kdn; ++kd) {
+            const int jd = od * sdd - pdd + kd;
+            for (int kh = 0; kh < 3; ++kh) {
+              const int jh = oh * 2 - 1 + kh;
+              for (int kw = 0; kw < 3; ++kw) {
+                const int jw = ow * 2 - 1 + kw;
+                const bool inb = (unsigned)jd < (unsigned)p.D && (unsigned)jh < (unsigned)p.H && (unsigned)jw < (unsigned)p.W;
+                if (inb && jd == id && jh == ih && jw == iw) { before = false; continue; }
+                float f[CH];
+                if (inb) {
+                  Chunk<T>::unpack(*(const u32x4*)(xp + ((((long long)n * p.D + jd) * p.H + jh) * p.W + jw) * p.ldx + c0), f);
+                } else {
+#pragma unroll
+                  for (int j = 0; j < CH; ++j) f[j] = 0.f;  // padding element
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                  if (before ? (f[j] >= me[j]) : (f[j] > me[j])) win[j] = false;
+                }
+              }
+            }
+          }
+          float g[CH];
+          Chunk<T>::unpack(*(const u32x4*)(dyp + ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.lddy + c0), g);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] += win[j] ? g[j] : 0.f;
+        }
+    T* dst = op + ipix * p.ldo + c0;
+    if (p.accumulate) {
+      float old[CH];
+      Chunk<T>::unpack(*(const u32x4*)dst, old);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += old[j];
+    }
+    *(u32x4*)dst = Chunk<T>::pack(acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(PoolK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = (long long)p.N * p.D * p.Ho * p.Wo * ncc;
+  const T* __restrict__ xp = (const T*)p.x;
+  T* __restrict__ op = (T*)p.out;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    long long t = q / ncc;
+    const long long opix = t;
+    const int ow = (int)(t % p.Wo); t /= p.Wo;
+    const int oh = (int)(t % p.Ho); t /= p.Ho;   // t = n*D + d
+    const long long base = (t * p.H + oh * 2) * p.W + ow * 2;
+    float s[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[CH];
+      Chunk<T>::unpack(*(const u32x4*)(xp + (base + (i >> 1) * p.W + (i & 1)) * p.ldx + c0), f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) s[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s[j] *= 0.25f;
+    *(u32x4*)(op + opix * p.ldo + c0) = Chunk<T>::pack(s);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(PoolK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = (long long)p.N * p.D * p.H * p.W * ncc;
+  const T* __restrict__ dyp = (const T*)p.dy;
+  T* __restrict__ op = (T*)p.out;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    long long t = q / ncc;
+    const long long ipix = t;
+    const int iw = (int)(t % p.W); t /= p.W;
+    const int ih = (int)(t % p.H); t /= p.H;
+    float g[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) g[j] = 0.f;
+    if ((ih >> 1) < p.Ho && (iw >> 1) < p.Wo) {
+      Chunk<T>::unpack(*(const u32x4*)(dyp + ((t * p.Ho + (ih >> 1)) * p.Wo + (iw >> 1)) * p.lddy + c0), g);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) g[j] *= 0.25f;
+    }
+    T* dst = op + ipix * p.ldo + c0;
+    if (p.accumulate) {
+      float old[CH];
+      Chunk<T>::unpack(*(const u32x4*)dst, old);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) g[j] += old[j];
+    }
+    *(u32x4*)dst = Chunk<T>::pack(g);
+  }
+}
+
+// dz[n,d,h,w] = sum over children of the up-sampled gradient
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(PoolK p) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = p.C / CH;
+  const long long total = (long long)p.N * p.D * p.H * p.W * ncc;
+  const T* __restrict__ gp = (const T*)p.dy;
+  T* __restrict__ op = (T*)p.out;
+  const int He = p.H << p.uh, We = p.W << p.uw, De = p.D << p.ud;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(q % ncc) * CH;
+    long long t = q / ncc;
+    const long long ipix = t;
+    const int w = (int)(t % p.W); t /= p.W;
+    const int h = (int)(t % p.H); t /= p.H;
+    const int d = (int)(t % p.D);
+    const int n = (int)(t / p.D);
+    float s[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s[j] = 0.f;
+    for (int a = 0; a <= p.ud; ++a)
+      for (int b = 0; b <= p.uh; ++b)
+        for (int c = 0; c <= p.uw; ++c) {
+          const long long e = (((long long)n * De + ((d << p.ud) + a)) * He + ((h << p.uh) + b)) * We + ((w << p.uw) + c);
+          float f[CH];
+          Chunk<T>::unpack(*(const u32x4*)(gp + e * p.lddy + c0), f);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) s[j] += f[j];
+        }
+    T* dst = op + ipix * p.ldo + c0;
+    if (p.accumulate) {
+      float old[CH];
+      Chunk<T>::unpack(*(const u32x4*)dst, old);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) s[j] += old[j];
+    }
+    *(u32x4*)dst = Chunk<T>::pack(s);
+  }
+}
+
+static int poolk_check(int dtype, const PoolK& k, const char* what) {
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, what);
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if (k.C <= 0 || k.C % ch || k.ldx % ch || k.ldo % ch || k.lddy % ch || k.N <= 0 || k.D <= 0 || k.H <= 0 || k.W <= 0)
+    return hdu_set_error(HDU_ERR_ARG, what);
+  return 0;
+}
+
+#define HDU_POOL_LAUNCH(kern, items)                                                                   \
+  do {                                                                                                 \
+    const int ch_ = dtype == HDU_BF16 ? 8 : 4;                                                         \
+    const unsigned g_ = hdu_grid_1d((long long)(items) * (C / ch_), 256, 8192);                        \
+    if (dtype == HDU_BF16) HDU_LAUNCH((kern<bf16_t>), dim3(g_), dim3(256), 0, (hipStream_t)stream, k); \
+    else HDU_LAUNCH((kern<float>), dim3(g_), dim3(256), 0, (hipStream_t)stream, k);                    \
+  } while (0)
+
+extern "C" int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
+                                  int64_t ldy, void* stream) {
+  PoolK k{};
+  k.x = x; k.ldx = ldx; k.out = y; k.ldo = ldy; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
+  k.Do = D == 1 ? 1 : (D - 1) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1;
+  if (!x || !y) return hdu_set_error(HDU_ERR_ARG, "maxpool_fwd: null pointer");
+  if (int e = poolk_check(dtype, k, "maxpool_fwd: bad dims / strides")) return e;
+  HDU_POOL_LAUNCH(maxpool_fwd_kernel, (long long)N * k.Do * k.Ho * k.Wo);
+  return hdu_check_launch("maxpool_fwd");
+}
+
+extern "C" int hdu_maxpool3s2_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, int N, int D,
+                                  int H, int W, int C, void* dx, int64_t lddx, int accumulate, void* stream) {
+  PoolK k{};
+  k.x = x; k.ldx = ldx; k.dy = dy; k.lddy = lddy; k.out = dx; k.ldo = lddx; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
+  k.Do = D == 1 ? 1 : (D - 1) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1; k.accumulate = accumulate;
+  if (!x || !dy || !dx) return hdu_set_error(HDU_ERR_ARG, "maxpool_bwd: null pointer");
+  if (int e = poolk_check(dtype, k, "maxpool_bwd: bad dims / strides")) return e;
+  HDU_POOL_LAUNCH(maxpool_bwd_kernel, (long long)N * D * H * W);
+  return hdu_check_launch("maxpool_bwd");
+}
+
+extern "C" int hdu_avgpool2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
+                                int64_t ldy, void* stream) {
+  PoolK k{};
+  k.x = x; k.ldx = ldx; k.out = y; k.ldo = ldy; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
+  k.Do = D; k.Ho = H / 2; k.Wo = W / 2;
+  if (!x || !y) return hdu_set_error(HDU_ERR_ARG, "avgpool_fwd: null pointer");
+  if (int e = poolk_check(dtype, k, "avgpool_fwd: bad dims / strides")) return e;
+  HDU_POOL_LAUNCH(avgpool_fwd_kernel, (long long)N * D * k.Ho * k.Wo);
+  return hdu_check_launch("avgpool_fwd");
+}
+
+extern "C" int hdu_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, int N, int D, int H, int W, int C, void* dx,
+                                int64_t lddx, int accumulate, void* stream) {
+  PoolK k{};
+  k.dy = dy; k.lddy = lddy; k.out = dx; k.ldo = lddx; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
+  k.Do = D; k.Ho = H / 2; k.Wo = W / 2; k.accumulate = accumulate;
+  if (!dy || !dx) return hdu_set_error(HDU_ERR_ARG, "avgpool_bwd: null pointer");
+  if (int e = poolk_check(dtype, k, "avgpool_bwd: bad dims / strides")) return e;
+  HDU_POOL_LAUNCH(avgpool_bwd_kernel, (long long)N * D * H * W);
+  return hdu_check_launch("avgpool_bwd");
+}
+
+extern "C" int hdu_upsample_bwd(int dtype, const void* dxe, int64_t lddxe, int N, int D, int H, int W, int C, int ud,
+                                int uh, int uw, void* dz, int64_t lddz, int accumulate, void* stream) {
+  PoolK k{};
+  k.dy = dxe; k.lddy = lddxe; k.out = dz; k.ldo = lddz; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
+  k.ud = ud; k.uh = uh; k.uw = uw; k.accumulate = accumulate;
+  if (!dxe || !dz || ((ud | uh | uw) & ~1)) return hdu_set_error(HDU_ERR_ARG, "upsample_bwd: bad args");
+  if (int e = poolk_check(dtype, k, "upsample_bwd: bad dims / strides")) return e;
+  HDU_POOL_LAUNCH(upsample_bwd_kernel, (long long)N * D * H * W);
+  return hdu_check_launch("upsample_bwd");
+}
+
+// ====================================================================== weighted cross-entropy (loss.py:5-46)
+template <typename T>
+__global__ __launch_bounds__(256) void wce_kernel(const T* __restrict__ logits, long long ldl,
+                                                  const uint8_t* __restrict__ labels, long long M, float w0, float w1,
+                                                  float w2, float grad_scale, T* __restrict__ dlogits, long long lddl,
+                                                  int Cpad, float* __restrict__ partial) {
+  __shared__ float red[4][256];
+  float lsum = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+    const float z0 = Chunk<T>::load1(logits + i * ldl), z1 = Chunk<T>::load1(logits + i * ldl + 1),
+                z2 = Chunk<T>::load1(logits + i * ldl + 2);
+    const int lab = labels[i];
+    const float mx = fmaxf(z0, fmaxf(z1, z2));
+    const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
+    const float inv = 1.f / (e0 + e1 + e2);
+    const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (lab <= 2) {
+      const float pc = lab == 0 ? p0 : (lab == 1 ? p1 : p2);
+      const float w = lab == 0 ? w0 : (lab == 1 ? w1 : w2);
+      const float pcl = fminf(fmaxf(pc, 1e-10f), 1.0f);
+      lsum += -w * logf(pcl);
+      n0 += lab == 0; n1 += lab == 1; n2 += lab == 2;
+      if (pc >= 1e-10f && pc <= 1.0f) {  // tf.clip_by_value passes the gradient only inside the range
+        const float gs = grad_scale * w;
+        d0 = gs * (p0 - (lab == 0 ? 1.f : 0.f));
+        d1 = gs * (p1 - (lab == 1 ? 1.f : 0.f));
+        d2 = gs * (p2 - (lab == 2 ? 1.f : 0.f));
+      }
+    }
+    if (dlogits) {
+      T* o = dlogits + i * lddl;
+      Chunk<T>::store1(o, d0); Chunk<T>::store1(o + 1, d1); Chunk<T>::store1(o + 2, d2);
+      for (int j = 3; j < Cpad; ++j) Chunk<T>::store1(o + j, 0.f);
+    }
+  }
+  red[0][threadIdx.x] = lsum; red[1][threadIdx.x] = n0; red[2][threadIdx.x] = n1; red[3][threadIdx.x] = n2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[(long long)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void wce_finalize_kernel(const float* __restrict__ partial, int nblk, float* loss_sum, float* class_count) {
+  const int q = threadIdx.x;
+  if (q >= 4) return;
+  double a = 0.0;
+  for (int b = 0; b < nblk; ++b) a += (double)partial[(long long)b * 4 + q];
+  if (q == 0) *loss_sum += (float)a;
+  else if (class_count) class_count[q - 1] += (float)a;
+}
+
+extern "C" int hdu_wce_loss(int dtype, const void* logits, int64_t ldl, const uint8_t* labels, int64_t M, float w0,
+                            float w1, float w2, float grad_scale, void* dlogits, int64_t lddl, int C_pad,
+                            float* loss_sum, float* class_count, void* ws, size_t ws_bytes, void* stream) {
+  if (!logits || !labels || !loss_sum || M <= 0 || ldl < 3) return hdu_set_error(HDU_ERR_ARG, "wce_loss: bad args");
+  if (dlogits && (lddl < C_pad || C_pad < 3)) return hdu_set_error(HDU_ERR_ARG, "wce_loss: bad dlogits stride");
+  const unsigned g = hdu_grid_1d(M, 256, 2048);
+  if (!ws || ws_bytes < (size_t)g * 4 * sizeof(float)) return hdu_set_error(HDU_ERR_WORKSPACE, "wce_loss: workspace too small (32 KiB)");
+  if (dtype == HDU_BF16)
+    HDU_LAUNCH((wce_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, (long long)ldl,
+               labels, (long long)M, w0, w1, w2, grad_scale, (bf16_t*)dlogits, (long long)lddl, C_pad, (float*)ws);
+  else if (dtype == HDU_F32)
+    HDU_LAUNCH((wce_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)logits, (long long)ldl,
+               labels, (long long)M, w0, w1, w2, grad_scale, (float*)dlogits, (long long)lddl, C_pad, (float*)ws);
+  else
+    return hdu_set_error(HDU_ERR_ARG, "wce_loss: bad dtype");
+  HDU_LAUNCH(wce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, (int)g, loss_sum,
+             class_count);
+  return hdu_check_launch("wce_loss");
+}
+
+// ====================================================================== Nesterov SGD (K.optimizers.py:168-185)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ v,
+                                                  const float* __restrict__ g, long long n, float lr, float mom,
+                                                  float gs) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * gs;
+    const float vn = mom * v[i] - lr * gr;
+    v[i] = vn;
+    p[i] = p[i] + mom * vn - lr * gr;
+  }
+}
+
+extern "C" int hdu_sgd_nesterov(float* p, float* v, const float* g, int64_t n, float lr, float momentum,
+                                float grad_scale, void* stream) {
+  if (!p || !v || !g || n < 0) return hdu_set_error(HDU_ERR_ARG, "sgd: bad args");
+  if (n == 0) return 0;
+  HDU_LAUNCH(sgd_kernel, dim3(hdu_grid_1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, v, g, (long long)n, lr,
+             momentum, grad_scale);
+  return hdu_check_launch("sgd");
+}
+
+// ====================================================================== 2.5D <-> 3D plumbing and boundary casts
+template <typename T>
+__global__ __launch_bounds__(256) void slab25d_kernel(const float* __restrict__ vol, int D, int H, int W,
+                                                      T* __restrict__ out, int Cpad) {
+  const long long HW = (long long)H * W, total = (long long)D * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / HW);
+    const long long hw = i % HW;
+    const int km = k > 0 ? k - 1 : 0, kp = k < D - 1 ? k + 1 : D - 1;
+    T* o = out + i * Cpad;
+    Chunk<T>::store1(o, vol[km * HW + hw]);
+    Chunk<T>::store1(o + 1, vol[k * HW + hw]);
+    Chunk<T>::store1(o + 2, vol[kp * HW + hw]);
+    for (int j = 3; j < Cpad; ++j) Chunk<T>::store1(o + j, 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void make_input3d_kernel(const float* __restrict__ vol, const T* __restrict__ lg,
+                                                           long long ldl, float scale, long long M, T* __restrict__ out,
+                                                           int Cpad) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+    T* o = out + i * Cpad;
+    Chunk<T>::store1(o, vol[i]);
+    for (int j = 0; j < 3; ++j) Chunk<T>::store1(o + 1 + j, scale * Chunk<T>::load1(lg + i * ldl + j));
+    for (int j = 4; j < Cpad; ++j) Chunk<T>::store1(o + j, 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void make_input3d_bwd_kernel(const T* __restrict__ din, int Cpad, float scale,
+                                                               long long M, T* __restrict__ dlg, long long lddl,
+                                                               int Cpad_l, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (long long)gridDim.x * blockDim.x) {
+    T* o = dlg + i * lddl;
+    for (int j = 0; j < 3; ++j) {
+      float v = scale * Chunk<T>::load1(din + i * Cpad + 1 + j);
+      if (accumulate) v += Chunk<T>::load1(o + j);
+      Chunk<T>::store1(o + j, v);
+    }
+    if (!accumulate)
+      for (int j = 3; j < Cpad_l; ++j) Chunk<T>::store1(o + j, 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, long long M, int C,
+                                                       T* __restrict__ dst, long long ldd, int Cpad) {
+  const long long total = M * Cpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long long m = i / Cpad;
+    Chunk<T>::store1(dst + m * ldd + c, c < C ? src[m * C + c] : 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_out_kernel(const T* __restrict__ src, long long lds, long long M, int C,
+                                                       float* __restrict__ dst) {
+  const long long total = M * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long m = i / C;
+    dst[i] = Chunk<T>::load1(src + m * lds + c);
+  }
+}
+
+#define HDU_T_LAUNCH(T, kern, n, ...) \
+  HDU_LAUNCH((kern<T>), dim3(hdu_grid_1d((n), 256, 4096)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+#define HDU_CHECK_DTYPE(what) \
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, what ": bad dtype")
+
+extern "C" int hdu_slab25d(int dtype, const float* vol, int D, int H, int W, void* out, int Cpad, void* stream) {
+  if (!vol || !out || D <= 0 || H <= 0 || W <= 0 || Cpad < 3) return hdu_set_error(HDU_ERR_ARG, "slab25d: bad args");
+  if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, slab25d_kernel, (long long)D * H * W, vol, D, H, W, (bf16_t*)out, Cpad); }
+  else { HDU_T_LAUNCH(float, slab25d_kernel, (long long)D * H * W, vol, D, H, W, (float*)out, Cpad); }
+  return hdu_check_launch("slab25d");
+}
+
+extern "C" int hdu_make_input3d(int dtype, const float* vol, const void* logits2d, int64_t ldl, float scale, int D,
+                                int H, int W, void* out, int Cpad, void* stream) {
+  if (!vol || !logits2d || !out || Cpad < 4 || ldl < 3) return hdu_set_error(HDU_ERR_ARG, "make_input3d: bad args");
+  const long long M = (long long)D * H * W;
+  if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, make_input3d_kernel, M, vol, (const bf16_t*)logits2d, (long long)ldl, scale, M, (bf16_t*)out, Cpad); }
+  else { HDU_T_LAUNCH(float, make_input3d_kernel, M, vol, (const float*)logits2d, (long long)ldl, scale, M, (float*)out, Cpad); }
+  return hdu_check_launch("make_input3d");
+}
+
+extern "C" int hdu_make_input3d_bwd(int dtype, const void* dinput3d, int Cpad, float scale, int64_t M, void* dlogits2d,
+                                    int64_t lddl, int Cpad_l, int accumulate, void* stream) {
+  if (!dinput3d || !dlogits2d || Cpad < 4 || lddl < 3) return hdu_set_error(HDU_ERR_ARG, "make_input3d_bwd: bad args");
+  if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, make_input3d_bwd_kernel, M, (const bf16_t*)dinput3d, Cpad, scale, (long long)M, (bf16_t*)dlogits2d, (long long)lddl, Cpad_l, accumulate); }
+  else { HDU_T_LAUNCH(float, make_input3d_bwd_kernel, M, (const float*)dinput3d, Cpad, scale, (long long)M, (float*)dlogits2d, (long long)lddl, Cpad_l, accumulate); }
+  return hdu_check_launch("make_input3d_bwd");
+}
+
+extern "C" int hdu_cast_pad(int dtype, const float* src, int64_t M, int C, void* dst, int64_t lddst, int Cpad,
+                            void* stream) {
+  if (!src || !dst || C <= 0 || Cpad < C || lddst < Cpad) return hdu_set_error(HDU_ERR_ARG, "cast_pad: bad args");
+  if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, cast_pad_kernel, M * Cpad, src, (long long)M, C, (bf16_t*)dst, (long long)lddst, Cpad); }
+  else { HDU_T_LAUNCH(float, cast_pad_kernel, M * Cpad, src, (long long)M, C, (float*)dst, (long long)lddst, Cpad); }
+  return hdu_check_launch("cast_pad");
+}
+
+extern "C" int hdu_cast_out(int dtype, const void* src, int64_t ldsrc, int64_t M, int C, float* dst, void* stream) {
+  if (!src || !dst || C <= 0 || ldsrc < C) return hdu_set_error(HDU_ERR_ARG, "cast_out: bad args");
+  if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, cast_out_kernel, M * C, (const bf16_t*)src, (long long)ldsrc, (long long)M, C, dst); }
+  else { HDU_T_LAUNCH(float, cast_out_kernel, M * C, (const float*)src, (long long)ldsrc, (long long)M, C, dst); }
+  return hdu_check_launch("cast_out");
+}

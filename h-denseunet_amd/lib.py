@@ -1,0 +1,148 @@
+"""ctypes binding of libhdu.so (the C-ABI declared in include/hdu.h).
+
+The product library is `libhdu.so` next to this file, built for gfx950 by `build.sh hip` /
+`__graft_entry__.build()`.  If it is missing, loading fails loudly -- there is no CPU fallback on the
+product path.  `use_emulator_for_tests()` is test infrastructure: it binds the x86 emulator build of the
+*same kernel sources* (tests/hipemu) so the CPU-only test tier can execute kernel logic; it must be
+called explicitly and is never reached from bench.py or __graft_entry__.smoke().
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+HDU_BF16 = 0
+HDU_F32 = 1
+
+c_int, c_i64, c_f, c_p, c_u32, c_sz = (ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p,
+                                       ctypes.c_uint32, ctypes.c_size_t)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("x", c_p), ("ldx", c_i64),
+        ("N", c_int), ("Di", c_int), ("Hi", c_int), ("Wi", c_int), ("Cin", c_int),
+        ("ud", c_int), ("uh", c_int), ("uw", c_int),
+        ("skip", c_p), ("ldskip", c_i64),
+        ("pro_a", c_p), ("pro_b", c_p), ("pro_relu", c_int),
+        ("w", c_p),
+        ("KD", c_int), ("KH", c_int), ("KW", c_int),
+        ("sd", c_int), ("sh", c_int), ("sw", c_int),
+        ("pd", c_int), ("ph", c_int), ("pw", c_int),
+        ("y", c_p), ("ldy", c_i64),
+        ("Do", c_int), ("Ho", c_int), ("Wo", c_int), ("Cout", c_int),
+        ("bias", c_p),
+        ("accumulate", c_int),
+        ("drop_keep", c_f),
+        ("drop_seed", c_u32),
+    ]
+
+
+_SIGS = {
+    "hdu_last_error": (ctypes.c_char_p, []),
+    "hdu_backend": (ctypes.c_char_p, []),
+    "hdu_abi_version": (c_int, []),
+    "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
+    "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
+    "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
+    "hdu_weight_prep": (c_int, [c_int, c_p, c_int, c_int, c_int, c_p, c_p, c_p]),
+    "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
+    "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),
+    "hdu_bn_fold": (c_int, [c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "hdu_bn_bwd_reduce": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
+                                  c_p, c_sz, c_p]),
+    "hdu_bn_bwd_coef": (c_int, [c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                c_p, c_p]),
+    "hdu_bn_bwd_apply": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
+                                 c_p, c_i64, c_int, c_f, c_u32, c_p]),
+    "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
+    "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
+    "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),
+    "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64,
+                                   c_int, c_p]),
+    "hdu_avgpool2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),
+    "hdu_avgpool2_bwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_p]),
+    "hdu_upsample_bwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p,
+                                 c_i64, c_int, c_p]),
+    "hdu_wce_loss": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_f, c_f, c_f, c_f, c_p, c_i64, c_int, c_p, c_p, c_p,
+                             c_sz, c_p]),
+    "hdu_sgd_nesterov": (c_int, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_p]),
+    "hdu_slab25d": (c_int, [c_int, c_p, c_int, c_int, c_int, c_p, c_int, c_p]),
+    "hdu_make_input3d": (c_int, [c_int, c_p, c_p, c_i64, c_f, c_int, c_int, c_int, c_p, c_int, c_p]),
+    "hdu_make_input3d_bwd": (c_int, [c_int, c_p, c_int, c_f, c_i64, c_p, c_i64, c_int, c_int, c_p]),
+    "hdu_cast_pad": (c_int, [c_int, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p]),
+    "hdu_cast_out": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+_lib = None
+_backend = None
+
+
+class HduError(RuntimeError):
+    pass
+
+
+def product_library_path():
+    return os.path.join(_HERE, "libhdu.so")
+
+
+def emulator_library_path():
+    return os.path.join(_ROOT, "tests", "hipemu", "libhdu_emu.so")
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(path=None):
+    """Bind the product library (gfx950).  Raises if it has not been built."""
+    global _lib, _backend
+    path = path or product_library_path()
+    if not os.path.exists(path):
+        raise HduError(
+            "libhdu.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    _lib = _bind(path)
+    _backend = _lib.hdu_backend().decode()
+    return _lib
+
+
+def use_emulator_for_tests():
+    """TEST INFRASTRUCTURE ONLY: bind the x86 emulator build of the kernel sources."""
+    global _lib, _backend
+    path = emulator_library_path()
+    if not os.path.exists(path):
+        raise HduError("emulator library not built: run ./build.sh emu")
+    _lib = _bind(path)
+    _backend = _lib.hdu_backend().decode()
+    assert _backend == "emu-x86"
+    return _lib
+
+
+def get():
+    if _lib is None:
+        load()
+    return _lib
+
+
+def backend():
+    get()
+    return _backend
+
+
+def is_emulator():
+    return backend() == "emu-x86"
+
+
+def check(code, what=""):
+    if code != 0:
+        raise HduError("%s failed (%d): %s" % (what or "hdu call", code, get().hdu_last_error().decode()))

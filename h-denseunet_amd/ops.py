@@ -1,0 +1,252 @@
+"""Thin Python wrappers over the C-ABI (include/hdu.h).  torch tensors are storage only: every wrapper
+hands raw device pointers + sizes to libhdu.so and launches on torch's current stream."""
+import ctypes
+
+import torch
+
+from . import lib as _l
+from .lib import HDU_BF16, HDU_F32, ConvDesc, check
+
+_TORCH_DT = {HDU_BF16: torch.bfloat16, HDU_F32: torch.float32}
+CHUNK = {HDU_BF16: 8, HDU_F32: 4}
+
+
+def device():
+    """Storage device of the bound library: cuda for the product, cpu only under the test emulator."""
+    if _l.is_emulator():
+        return torch.device("cpu")
+    if not torch.cuda.is_available():
+        raise _l.HduError("libhdu.so (gfx950) is bound but no GPU is visible; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream():
+    if _l.is_emulator():
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def cpad(c, dtype):
+    ch = CHUNK[dtype]
+    return (c + ch - 1) // ch * ch
+
+
+def fptr(t):
+    """pointer of a float32 tensor (or None)"""
+    if t is None:
+        return None
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Act:
+    """Channels-last activation view [N][D][H][W][C] with pixel stride `ld` inside a flat buffer."""
+    __slots__ = ("buf", "off", "N", "D", "H", "W", "C", "ld", "dtype")
+
+    def __init__(self, buf, off, N, D, H, W, C, ld, dtype):
+        self.buf, self.off, self.N, self.D, self.H, self.W, self.C, self.ld, self.dtype = buf, off, N, D, H, W, C, ld, dtype
+
+    @staticmethod
+    def alloc(N, D, H, W, C, dtype, ld=None, zero=False):
+        ld = ld or C
+        n = N * D * H * W * ld
+        buf = (torch.zeros if zero else torch.empty)(n, dtype=_TORCH_DT[dtype], device=device())
+        return Act(buf, 0, N, D, H, W, C, ld, dtype)
+
+    @property
+    def M(self):
+        return self.N * self.D * self.H * self.W
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr() + self.off * self.buf.element_size())
+
+    def slab(self, c0, C):
+        assert c0 % CHUNK[self.dtype] == 0 and c0 + C <= self.ld
+        return Act(self.buf, self.off + c0, self.N, self.D, self.H, self.W, C, self.ld, self.dtype)
+
+    def like(self, C=None, zero=False):
+        return Act.alloc(self.N, self.D, self.H, self.W, C or self.C, self.dtype, zero=zero)
+
+    def rows(self, m0, m1):
+        """row sub-range (whole leading-dimension slices only make sense for N/D splits)"""
+        a = Act(self.buf, self.off + m0 * self.ld, 1, 1, 1, m1 - m0, self.C, self.ld, self.dtype)
+        return a
+
+    def to_torch(self):
+        """float32 [N,D,H,W,C] copy (host-side helper for tests / boundary)"""
+        full = self.buf[self.off:self.off + (self.M - 1) * self.ld + self.C] if self.M else self.buf[:0]
+        idx = torch.arange(self.M, device=self.buf.device)[:, None] * self.ld + torch.arange(self.C, device=self.buf.device)[None, :]
+        return full[idx].float().reshape(self.N, self.D, self.H, self.W, self.C)
+
+    def from_torch(self, t):
+        t = t.reshape(self.M, self.C).to(self.buf.dtype).to(self.buf.device)
+        idx = torch.arange(self.M, device=self.buf.device)[:, None] * self.ld + torch.arange(self.C, device=self.buf.device)[None, :]
+        self.buf[self.off:][idx.reshape(-1)] = t.reshape(-1)
+        return self
+
+
+def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
+              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0):
+    """x: Act (stored input), y: Act (output), K=(KD,KH,KW)."""
+    d = ConvDesc()
+    d.dtype = x.dtype
+    d.x, d.ldx = x.ptr, x.ld
+    d.N, d.Di, d.Hi, d.Wi, d.Cin = x.N, x.D, x.H, x.W, x.C
+    d.ud, d.uh, d.uw = up
+    if skip is not None:
+        d.skip, d.ldskip = skip.ptr, skip.ld
+    if pro is not None:
+        d.pro_a, d.pro_b, d.pro_relu = fptr(pro[0]), fptr(pro[1]), 1 if relu else 0
+    d.w = w_ptr
+    d.KD, d.KH, d.KW = K
+    d.sd, d.sh, d.sw = stride
+    d.pd, d.ph, d.pw = pad
+    d.y, d.ldy = y.ptr, y.ld
+    d.Do, d.Ho, d.Wo, d.Cout = y.D, y.H, y.W, y.C
+    d.bias = fptr(bias)
+    d.accumulate = 1 if accumulate else 0
+    d.drop_keep = drop_keep
+    d.drop_seed = drop_seed
+    return d
+
+
+def conv_fprop(d):
+    check(_l.get().hdu_conv_fprop(ctypes.byref(d), stream()), "hdu_conv_fprop")
+
+
+def conv_wgrad(d, dw):
+    check(_l.get().hdu_conv_wgrad(ctypes.byref(d), fptr(dw), stream()), "hdu_conv_wgrad")
+
+
+def conv_dgrad_strided(d):
+    check(_l.get().hdu_conv_dgrad_strided(ctypes.byref(d), stream()), "hdu_conv_dgrad_strided")
+
+
+def weight_prep(dtype, w_master, Cout, T, Cin, w_f, w_d):
+    check(_l.get().hdu_weight_prep(dtype, fptr(w_master), Cout, T, Cin,
+                                   ctypes.c_void_p(w_f.data_ptr()) if w_f is not None else None,
+                                   ctypes.c_void_p(w_d.data_ptr()) if w_d is not None else None, stream()),
+          "hdu_weight_prep")
+
+
+class Workspace:
+    """Reduction scratch shared by all stats / loss calls of one model (stream-ordered reuse)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = max(int(nbytes), 1 << 16)
+        self.buf = torch.empty(self.nbytes // 4 + 64, dtype=torch.float32, device=device())
+
+    @property
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr())
+
+
+def reduce_ws_bytes(M, C):
+    return _l.get().hdu_reduce_ws_bytes(M, C)
+
+
+def bn_stats(x, mean, var, ws):
+    check(_l.get().hdu_bn_stats(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(mean), fptr(var), ws.ptr, ws.nbytes, stream()),
+          "hdu_bn_stats")
+
+
+def bn_fold(C, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean=None, mov_var=None, momentum=0.99):
+    check(_l.get().hdu_bn_fold(C, fptr(mean), fptr(var), fptr(gamma), fptr(beta), eps, fptr(sgamma), fptr(sbeta),
+                               fptr(a), fptr(b), fptr(rstd), fptr(mov_mean), fptr(mov_var), momentum, stream()),
+          "hdu_bn_fold")
+
+
+def bn_bwd_reduce(dz, x, a, b, relu, mean, rstd, s1, s2, ws):
+    check(_l.get().hdu_bn_bwd_reduce(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
+                                     fptr(mean), fptr(rstd), fptr(s1), fptr(s2), ws.ptr, ws.nbytes, stream()),
+          "hdu_bn_bwd_reduce")
+
+
+def bn_bwd_coef(C, M, batch_stats, s1, s2, gamma, beta, sgamma, rstd, k1, k2, k3, dgamma=None, dbeta=None,
+                dsgamma=None, dsbeta=None):
+    check(_l.get().hdu_bn_bwd_coef(C, M, 1 if batch_stats else 0, fptr(s1), fptr(s2), fptr(gamma), fptr(beta),
+                                   fptr(sgamma), fptr(rstd), fptr(k1), fptr(k2), fptr(k3), fptr(dgamma), fptr(dbeta),
+                                   fptr(dsgamma), fptr(dsbeta), stream()), "hdu_bn_bwd_coef")
+
+
+def bn_bwd_apply(dz, x, a, b, relu, mean, k1, k2, k3, dx, accumulate=False, drop_keep=1.0, drop_seed=0):
+    check(_l.get().hdu_bn_bwd_apply(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
+                                    fptr(mean), fptr(k1), fptr(k2), fptr(k3), dx.ptr, dx.ld, 1 if accumulate else 0,
+                                    drop_keep, drop_seed, stream()), "hdu_bn_bwd_apply")
+
+
+def affine_act(x, a, b, relu, z):
+    check(_l.get().hdu_affine_act(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0, z.ptr, z.ld,
+                                  stream()), "hdu_affine_act")
+
+
+def colsum(x, out, ws):
+    check(_l.get().hdu_colsum(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(out), ws.ptr, ws.nbytes, stream()), "hdu_colsum")
+
+
+def maxpool_fwd(x, y):
+    check(_l.get().hdu_maxpool3s2_fwd(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, y.ptr, y.ld, stream()),
+          "hdu_maxpool3s2_fwd")
+
+
+def maxpool_bwd(x, dy, dx, accumulate=False):
+    check(_l.get().hdu_maxpool3s2_bwd(x.dtype, x.ptr, x.ld, dy.ptr, dy.ld, x.N, x.D, x.H, x.W, x.C, dx.ptr, dx.ld,
+                                      1 if accumulate else 0, stream()), "hdu_maxpool3s2_bwd")
+
+
+def avgpool_fwd(x, y):
+    check(_l.get().hdu_avgpool2_fwd(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, y.ptr, y.ld, stream()),
+          "hdu_avgpool2_fwd")
+
+
+def avgpool_bwd(dy, dx, accumulate=False):
+    check(_l.get().hdu_avgpool2_bwd(dx.dtype, dy.ptr, dy.ld, dx.N, dx.D, dx.H, dx.W, dx.C, dx.ptr, dx.ld,
+                                    1 if accumulate else 0, stream()), "hdu_avgpool2_bwd")
+
+
+def upsample_bwd(dxe, dz, up, accumulate=False):
+    check(_l.get().hdu_upsample_bwd(dz.dtype, dxe.ptr, dxe.ld, dz.N, dz.D, dz.H, dz.W, dz.C, up[0], up[1], up[2],
+                                    dz.ptr, dz.ld, 1 if accumulate else 0, stream()), "hdu_upsample_bwd")
+
+
+def wce_loss(logits, labels_u8, row0, M, weights, grad_scale, dlogits, loss_sum, class_count, ws):
+    esz = logits.buf.element_size()
+    lp = ctypes.c_void_p(logits.buf.data_ptr() + (logits.off + row0 * logits.ld) * esz)
+    dp = None
+    ldd = 0
+    cp = 0
+    if dlogits is not None:
+        dp = ctypes.c_void_p(dlogits.buf.data_ptr() + (dlogits.off + row0 * dlogits.ld) * esz)
+        ldd, cp = dlogits.ld, dlogits.C
+    check(_l.get().hdu_wce_loss(logits.dtype, lp, logits.ld, ctypes.c_void_p(labels_u8.data_ptr() + row0), M,
+                                weights[0], weights[1], weights[2], grad_scale, dp, ldd, cp, fptr(loss_sum),
+                                fptr(class_count), ws.ptr, ws.nbytes, stream()), "hdu_wce_loss")
+
+
+def sgd_nesterov(p, v, g, lr, momentum, grad_scale=1.0):
+    check(_l.get().hdu_sgd_nesterov(fptr(p), fptr(v), fptr(g), p.numel(), lr, momentum, grad_scale, stream()),
+          "hdu_sgd_nesterov")
+
+
+def slab25d(vol_f32, D, H, W, out):
+    check(_l.get().hdu_slab25d(out.dtype, fptr(vol_f32), D, H, W, out.ptr, out.ld, stream()), "hdu_slab25d")
+
+
+def make_input3d(vol_f32, logits2d, scale, out):
+    check(_l.get().hdu_make_input3d(out.dtype, fptr(vol_f32), logits2d.ptr, logits2d.ld, scale, out.D, out.H, out.W,
+                                    out.ptr, out.ld, stream()), "hdu_make_input3d")
+
+
+def make_input3d_bwd(dinput3d, scale, dlogits2d, accumulate=False):
+    check(_l.get().hdu_make_input3d_bwd(dinput3d.dtype, dinput3d.ptr, dinput3d.ld, scale, dinput3d.M, dlogits2d.ptr,
+                                        dlogits2d.ld, dlogits2d.C, 1 if accumulate else 0, stream()),
+          "hdu_make_input3d_bwd")
+
+
+def cast_pad(src_f32, M, C, dst):
+    check(_l.get().hdu_cast_pad(dst.dtype, fptr(src_f32), M, C, dst.ptr, dst.ld, dst.C, stream()), "hdu_cast_pad")
+
+
+def cast_out(src, C, dst_f32):
+    check(_l.get().hdu_cast_out(src.dtype, src.ptr, src.ld, src.M, C, fptr(dst_f32), stream()), "hdu_cast_out")

@@ -1,0 +1,189 @@
+/* hdu.h -- C-ABI of libhdu.so: the MI355X (gfx950) kernels of the H-DenseUNet hot path.
+ *
+ * The reference (xmengli/H-DenseUNet) has NO native/FFI interface: its device
+ * arithmetic is TensorFlow ops reached through the vendored Keras backend
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the Keras
+ * backend / layer function (reference file:line) whose device work it replaces.
+ * "TFB" = Keras-2.0.8/keras/backend/tensorflow_backend.py, "K." = Keras-2.0.8/keras/.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / C++ types.
+ *  - All pointers are DEVICE pointers owned by the caller (no ownership transfer, no
+ *    allocation inside); work is enqueued asynchronously on `stream` (a hipStream_t).
+ *  - Return value: 0 = ok, <0 = error; hdu_last_error() gives a thread-local message.
+ *    Nothing throws or exits across the ABI.
+ *  - Activations are channels-last [N][D][H][W][C] (D = 1 for 2D), element type selected
+ *    by `dtype`; `ld*` is the element stride between consecutive pixels (>= C, lets a
+ *    tensor be a channel slab of a wider dense-block buffer).  Channel counts and slab
+ *    offsets must be multiples of 16 bytes / sizeof(element) (8 for bf16, 4 for f32);
+ *    the host pads the 3-/4-channel network inputs and the 3-class head to that.
+ *  - Per-channel parameter / statistics vectors are always float32.
+ */
+#ifndef HDU_H_
+#define HDU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDU_BF16 0
+#define HDU_F32 1
+
+#define HDU_OK 0
+#define HDU_ERR_ARG (-1)
+#define HDU_ERR_LAUNCH (-2)
+#define HDU_ERR_WORKSPACE (-3)
+
+const char* hdu_last_error(void);
+/* "hip-gfx950" for the product library; "emu-x86" for the CPU test build of the same sources. */
+const char* hdu_backend(void);
+int hdu_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Replaces K.layers/convolutional.py:148-182 (_Conv.call) -> TFB:3128-3165 (conv2d) /
+ * TFB:3277-3314 (conv3d) + TFB:3435-3497 (bias_add), with the layers the reference
+ * places directly in front of a conv folded into the operand gather:
+ *   BatchNormalization(+Scale)+Activation('relu')  -> per-channel  relu(pro_a[c]*x + pro_b[c])
+ *       (K.layers/normalization.py:126-190, lib/custom_layers.py:63-69, TFB:2656-2679)
+ *   UpSampling2D/3D nearest                        -> ud/uh/uw (K.layers/convolutional.py:1359,1432; TFB:1739-1827)
+ *   add([skip, up])                                -> skip      (K.layers/merge.py:207-211)
+ *   ZeroPadding2D/3D                               -> pd/ph/pw  (K.layers/convolutional.py:1584,1702; TFB:1989-2071)
+ * and Dropout (TFB:2869-2888) folded into the epilogue.
+ *   x_eff[n,d,h,w,c] = act(pro_a[c]*x[n,d>>ud,h>>uh,w>>uw,c]+pro_b[c]) + skip[n,d,h,w,c]   (0 outside)
+ *   y[n,o,co] = sum_{k,c} x_eff[n, o*s + k - p, c] * w[co][k][c]  (+ bias[co]) (* dropout mask/keep)
+ * Filter layout: [Cout][KD][KH][KW][Cin] (Keras' (kd,kh,kw,Cin,Cout) is converted on the host).
+ */
+typedef struct hdu_conv_desc {
+  int dtype;
+  const void* x;      int64_t ldx;
+  int N, Di, Hi, Wi, Cin;          /* stored (pre-upsample) input dims */
+  int ud, uh, uw;                  /* nearest-upsample shift per axis: 0 (x1) or 1 (x2) */
+  const void* skip;   int64_t ldskip;   /* optional, at the upsampled resolution, Cin channels */
+  const float* pro_a; const float* pro_b; int pro_relu; /* optional input affine (+ReLU) */
+  const void* w;                   /* [Cout][KD*KH*KW*Cin], element type = dtype */
+  int KD, KH, KW;
+  int sd, sh, sw;
+  int pd, ph, pw;
+  void* y;            int64_t ldy;
+  int Do, Ho, Wo, Cout;
+  const float* bias;               /* optional [Cout] */
+  int accumulate;                  /* y += result instead of y = result */
+  float drop_keep;                 /* 1.0 = no dropout; else keep-probability */
+  uint32_t drop_seed;
+} hdu_conv_desc;
+
+/* forward conv; also the data-gradient of every stride-1 conv (caller passes dy as x and the
+ * flipped/transposed filter from hdu_weight_prep; replaces tf.gradients of TFB:3158/3307). */
+int hdu_conv_fprop(const hdu_conv_desc* d, void* stream);
+
+/* filter gradient: dw[co][k][c] += sum_{n,o} x_eff[n,o*s+k-p,c] * dy[n,o,co]; d->y is dy (read only),
+ * dw is float32 [Cout][KD*KH*KW*Cin] and is accumulated into (atomics).  x_eff is recomputed from the raw
+ * input with the same prologue as the forward (the normalised tensor is never stored). */
+int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream);
+
+/* data-gradient of a strided conv (the 7x7x7 stride-2 stem, needed by hybridnet end2end):
+ * dx[n,i,c] (+)= sum_{o,k: o*s+k-p=i} dy[n,o,co]*w[co][k][c].  d->x is the output dx, d->y is dy. */
+int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream);
+
+/* master float32 filters [Cout][T][Cin] -> compute-dtype copies: w_f (same layout) and, if w_d != NULL,
+ * the data-gradient filter w_d [Cin][T flipped][Cout]. */
+int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, void* w_f, void* w_d, void* stream);
+
+/* ------------------------------------------------------------------ batch normalisation
+ * K.layers/normalization.py:126-190 -> TFB:1620-1664 (normalize_batch_in_training = tf.nn.moments +
+ * tf.nn.batch_normalization), TFB:1667-1684 (inference), TFB:915-927 (moving_average_update);
+ * Scale: lib/custom_layers.py:63-69.
+ */
+size_t hdu_reduce_ws_bytes(int64_t M, int C);
+
+/* per-channel mean and biased variance over M pixels (tf.nn.moments, TFB:1635) */
+int hdu_bn_stats(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* mean, float* var, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* fold BN (+ optional Scale) into one per-channel affine  y = a*x + b :
+ *   rstd = rsqrt(var+eps); a = sg*g*rstd; b = sg*(beta - mean*g*rstd) + sb      (sg=1, sb=0 when NULL)
+ * and, when mov_mean != NULL, the training-mode moving-statistics update  m -= (m - batch)*(1-momentum). */
+int hdu_bn_fold(int C, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                const float* sgamma, const float* sbeta, float* a, float* b, float* rstd, float* mov_mean,
+                float* mov_var, float momentum, void* stream);
+
+/* backward of  z = relu?(a*x+b)  where a,b came from hdu_bn_fold: per-channel sums
+ *   s1 = sum g, s2 = sum g*(x-mean)*rstd,  g = dz * [a*x+b > 0]  */
+int hdu_bn_bwd_reduce(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                      const float* a, const float* b, int relu, const float* mean, const float* rstd, float* s1,
+                      float* s2, void* ws, size_t ws_bytes, void* stream);
+
+/* per-channel coefficients of dx = k1*g - k2 - k3*(x-mean) and the parameter gradients.
+ * batch_stats=1: training-mode BN (TFB:1635-1640): k1=sg*g*rstd, k2=k1*s1/M, k3=k1*rstd*s2/M;
+ * batch_stats=0: frozen/inference BN: k1=sg*g*rstd, k2=k3=0.  Any of the d* outputs may be NULL. */
+int hdu_bn_bwd_coef(int C, int64_t M, int batch_stats, const float* s1, const float* s2, const float* gamma,
+                    const float* beta, const float* sgamma, const float* rstd, float* k1, float* k2, float* k3,
+                    float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* stream);
+
+/* dx (+)= (k1*g - k2 - k3*(x-mean)) * dropmask   (g as above; dropout mask of the conv that produced x) */
+int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                     const float* a, const float* b, int relu, const float* mean, const float* k1,
+                     const float* k2, const float* k3, void* dx, int64_t lddx, int accumulate, float drop_keep,
+                     uint32_t drop_seed, void* stream);
+
+/* materialise z = relu?(a*x+b) (needed where the activation is consumed by pooling / as a skip / HFF operand) */
+int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, const float* a, const float* b,
+                   int relu, void* z, int64_t ldz, void* stream);
+
+/* per-channel column sum: out[c] = sum_m x[m][c]   (bias gradients) */
+int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws, size_t ws_bytes,
+               void* stream);
+
+/* ------------------------------------------------------------------ pooling / resampling
+ * K.layers/pooling.py:166-433 -> TFB:3354-3432.  Max pool: ZeroPadding(1) + 3x3(x3) stride 2 VALID; the zero
+ * padding takes part in the max (denseunet.py:169-170, denseunet3d.py:135-136).  D==1 selects the 2D window.
+ * Avg pool: 2x2 stride 2 over (H,W); depth is not pooled (denseunet3d.py:102). */
+int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
+                       int64_t ldy, void* stream);
+int hdu_maxpool3s2_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, int N, int D, int H,
+                       int W, int C, void* dx, int64_t lddx, int accumulate, void* stream);
+int hdu_avgpool2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
+                     int64_t ldy, void* stream);
+int hdu_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, int N, int D, int H, int W, int C, void* dx,
+                     int64_t lddx, int accumulate, void* stream);
+/* gradient of nearest up-sampling: dz[n,d,h,w,c] = sum over the 2^(ud+uh+uw) children of dxe (low-res dims given) */
+int hdu_upsample_bwd(int dtype, const void* dxe, int64_t lddxe, int N, int D, int H, int W, int C, int ud, int uh,
+                     int uw, void* dz, int64_t lddz, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ loss  (loss.py:5-46)
+ * rows i with label c_i in {0,1,2}: L = -(1/count) * sum_i w[c_i]*log(clip(softmax(z_i)[c_i],1e-10,1));
+ * dlogits[i][j] = grad_scale*w[c_i]*(p_j - [j==c_i]) inside the clip range, else 0 (tf.clip_by_value gradient).
+ * loss_sum receives sum_i w[c_i]*(-log p) (the caller divides by the global count); class_count[3] += #rows.
+ * logits/dlogits have ld >= 3 (channels beyond 3 of dlogits are written as 0 up to C_pad). */
+int hdu_wce_loss(int dtype, const void* logits, int64_t ldl, const uint8_t* labels, int64_t M, float w0, float w1,
+                 float w2, float grad_scale, void* dlogits, int64_t lddl, int C_pad, float* loss_sum,
+                 float* class_count, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ optimiser (K.optimizers.py:155-186)
+ * v = momentum*v - lr*g ; p = p + momentum*v - lr*g  (Nesterov), g = grad_scale * grad. */
+int hdu_sgd_nesterov(float* p, float* v, const float* g, int64_t n, float lr, float momentum, float grad_scale,
+                     void* stream);
+
+/* ------------------------------------------------------------------ 2.5D <-> 3D plumbing
+ * denseunet3d.py:396-425 / hybridnet.py:382-411 (slice/concat/transpose lambdas).
+ * vol: [D][H][W] float32 (one volume).  slab25d: out[k][h][w][0..2] = vol[clamp(k-1)], vol[k], vol[clamp(k+1)];
+ * channels 3..Cpad-1 = 0. */
+int hdu_slab25d(int dtype, const float* vol, int D, int H, int W, void* out, int Cpad, void* stream);
+/* input3d[d][h][w] = (vol, scale*logit0, scale*logit1, scale*logit2, 0...) ; logits2d is [D][H][W][ldl] */
+int hdu_make_input3d(int dtype, const float* vol, const void* logits2d, int64_t ldl, float scale, int D, int H,
+                     int W, void* out, int Cpad, void* stream);
+/* backward of the above w.r.t. logits2d: dlogits2d[...,j] (+)= scale * dinput3d[...,1+j] */
+int hdu_make_input3d_bwd(int dtype, const void* dinput3d, int Cpad, float scale, int64_t M, void* dlogits2d,
+                         int64_t lddl, int Cpad_l, int accumulate, void* stream);
+
+/* dtype conversion / layout helpers for the boundary (float32 channels-last in, compute dtype out, and back) */
+int hdu_cast_pad(int dtype, const float* src, int64_t M, int C, void* dst, int64_t lddst, int Cpad, void* stream);
+int hdu_cast_out(int dtype, const void* src, int64_t ldsrc, int64_t M, int C, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDU_H_ */

@@ -1,0 +1,188 @@
+// hipemu.cpp -- TEST INFRASTRUCTURE ONLY (see hipemu.h).
+#include "hipemu.h"
+
+#include <ucontext.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace hipemu {
+
+thread_local ThreadCtx* g_cur = nullptr;
+
+namespace {
+
+constexpr size_t kStack = 256 * 1024;
+constexpr size_t kSlot = 64;  // bytes per lane in a wave exchange buffer
+
+struct Fiber {
+  ucontext_t uc;
+  ThreadCtx ctx;
+  bool done = false;
+  char* stack = nullptr;
+};
+
+struct WaveState {
+  int arrived = 0;
+  unsigned gen = 0;
+  int alive = 64;
+  alignas(16) char buf[64 * kSlot];
+};
+
+struct BlockRun {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  std::vector<WaveState> waves;
+  int bar_arrived = 0;
+  unsigned bar_gen = 0;
+  int alive = 0;
+  Fiber* running = nullptr;
+  const std::function<void()>* body = nullptr;
+  unsigned long progress = 0;
+};
+
+thread_local BlockRun* t_run = nullptr;
+
+void yield_to_sched() {
+  BlockRun* r = t_run;
+  Fiber* f = r->running;
+  swapcontext(&f->uc, &r->sched);
+  g_cur = &f->ctx;
+}
+
+void fiber_main() {
+  BlockRun* r = t_run;
+  Fiber* f = r->running;
+  g_cur = &f->ctx;
+  (*r->body)();
+  f->done = true;
+  r->alive--;
+  r->waves[f->ctx.wave].alive--;
+  r->progress++;
+  swapcontext(&f->uc, &r->sched);
+}
+
+}  // namespace
+
+void sync_threads() {
+  BlockRun* r = t_run;
+  r->bar_arrived++;
+  r->progress++;
+  const unsigned my = r->bar_gen;
+  if (r->bar_arrived >= r->alive) {
+    r->bar_arrived = 0;
+    r->bar_gen++;
+    return;
+  }
+  while (r->bar_gen == my) {
+    yield_to_sched();
+    if (r->bar_gen == my && r->bar_arrived >= r->alive) {  // someone exited meanwhile
+      r->bar_arrived = 0;
+      r->bar_gen++;
+    }
+  }
+}
+
+void wave_barrier() {
+  BlockRun* r = t_run;
+  WaveState& w = r->waves[g_cur->wave];
+  w.arrived++;
+  r->progress++;
+  const unsigned my = w.gen;
+  if (w.arrived >= w.alive) {
+    w.arrived = 0;
+    w.gen++;
+    return;
+  }
+  while (w.gen == my) yield_to_sched();
+}
+
+const char* wave_exchange(const void* mine, size_t nbytes, size_t* slot_stride) {
+  if (nbytes > kSlot) { fprintf(stderr, "hipemu: exchange payload too large\n"); abort(); }
+  BlockRun* r = t_run;
+  WaveState& w = r->waves[g_cur->wave];
+  std::memcpy(w.buf + (size_t)g_cur->lane * kSlot, mine, nbytes);
+  wave_barrier();
+  *slot_stride = kSlot;
+  return w.buf;
+}
+
+void wave_release() { wave_barrier(); }
+
+static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigned bx, unsigned by,
+                      unsigned bz, size_t dyn_smem_bytes) {
+  const unsigned nthreads = block.x * block.y * block.z;
+  BlockRun run;
+  run.body = &body;
+  run.fibers.resize(nthreads);
+  run.waves.resize((nthreads + 63) / 64);
+  run.alive = (int)nthreads;
+  std::vector<char> smem(dyn_smem_bytes + 64);
+  char* smem_aligned = (char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
+  t_run = &run;
+  for (unsigned t = 0; t < nthreads; ++t) {
+    Fiber& f = run.fibers[t];
+    f.stack = (char*)malloc(kStack);
+    f.ctx.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+    f.ctx.bid = {bx, by, bz};
+    f.ctx.bdim = {block.x, block.y, block.z};
+    f.ctx.gdim = {grid.x, grid.y, grid.z};
+    f.ctx.dyn_smem = smem_aligned;
+    f.ctx.lane = (int)(t & 63);
+    f.ctx.wave = (int)(t >> 6);
+    getcontext(&f.uc);
+    f.uc.uc_stack.ss_sp = f.stack;
+    f.uc.uc_stack.ss_size = kStack;
+    f.uc.uc_link = nullptr;
+    makecontext(&f.uc, (void (*)())fiber_main, 0);
+  }
+  for (unsigned w = 0; w < run.waves.size(); ++w) {
+    unsigned lo = w * 64, hi = lo + 64 > nthreads ? nthreads : lo + 64;
+    run.waves[w].alive = (int)(hi - lo);
+  }
+  while (run.alive > 0) {
+    const unsigned long before = run.progress;
+    for (unsigned t = 0; t < nthreads; ++t) {
+      Fiber& f = run.fibers[t];
+      if (f.done) continue;
+      run.running = &f;
+      swapcontext(&run.sched, &f.uc);
+    }
+    if (run.progress == before && run.alive > 0) {
+      fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): %d threads alive, barrier %d arrived\n", bx, by, bz,
+              run.alive, run.bar_arrived);
+      abort();
+    }
+  }
+  for (auto& f : run.fibers) free(f.stack);
+  t_run = nullptr;
+  g_cur = nullptr;
+}
+
+void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<void()>& body) {
+  const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
+  if (nblocks == 0) return;
+  unsigned nthr = std::thread::hardware_concurrency();
+  if (const char* e = getenv("HIPEMU_THREADS")) nthr = (unsigned)atoi(e);
+  if (nthr < 1) nthr = 1;
+  if (nthr > nblocks) nthr = (unsigned)nblocks;
+  std::atomic<unsigned long> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      unsigned long b = next.fetch_add(1);
+      if (b >= nblocks) break;
+      unsigned bx = (unsigned)(b % grid.x), by = (unsigned)((b / grid.x) % grid.y),
+               bz = (unsigned)(b / ((unsigned long)grid.x * grid.y));
+      run_block(body, grid, block, bx, by, bz, dyn_smem_bytes);
+    }
+  };
+  if (nthr == 1) { worker(); return; }
+  std::vector<std::thread> pool;
+  for (unsigned i = 0; i < nthr; ++i) pool.emplace_back(worker);
+  for (auto& t : pool) t.join();
+}
+
+}  // namespace hipemu

@@ -1,0 +1,481 @@
+"""Op-level parity of every C-ABI kernel against a float64 torch/numpy restatement of the Keras/TF op
+semantics.  Each test runs twice: under the x86 emulator build of the kernel
+sources (CPU tier) and, marked `gpu`, on the gfx950 library."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+BF16, F32 = 0, 1
+DT = [pytest.param(F32, id="f32"), pytest.param(BF16, id="bf16")]
+
+
+def ops_mod():
+    return importlib.import_module("h-denseunet_amd.ops")
+
+
+def rnd(shape, seed, scale=1.0, dtype=F32):
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+    if dtype == BF16:
+        t = t.to(torch.bfloat16).double()
+    else:
+        t = t.float().double()
+    return t
+
+
+def q(t, dtype):
+    return t.to(torch.bfloat16).double() if dtype == BF16 else t.float().double()
+
+
+def tol(dtype):
+    return (2e-2, 2e-2) if dtype == BF16 else (2e-5, 2e-5)
+
+
+def assert_close(got, ref, dtype, scale=None, what=""):
+    rt, at = tol(dtype)
+    s = float(ref.abs().max()) if scale is None else scale
+    err = (got.double() - ref).abs()
+    lim = at * max(s, 1e-6) + rt * ref.abs()
+    bad = err > lim
+    assert not bad.any(), "%s: %d/%d mismatches, max err %.3e (scale %.3e)" % (what, int(bad.sum()), bad.numel(), float(err.max()), s)
+
+
+def mkact(ops, t, dtype, ld=None, coff=0):
+    """t: [N,D,H,W,C] float64 -> Act (optionally as a slab of a wider buffer)"""
+    N, D, H, W, C = t.shape
+    if ld is None:
+        a = ops.Act.alloc(N, D, H, W, C, dtype)
+    else:
+        big = ops.Act.alloc(N, D, H, W, ld, dtype, zero=True)
+        big.buf.fill_(7.0)  # poison the other channels
+        a = big.slab(coff, C)
+    a.from_torch(t)
+    return a
+
+
+def dev(ops, t):
+    return t.float().contiguous().to(ops.device())
+
+
+def ref_xeff(x, up, skip, pro, relu, dtype):
+    xe = x
+    if pro is not None:
+        xe = xe * pro[0] + pro[1]
+        if relu:
+            xe = xe.clamp_min(0)
+    for ax, u in zip((1, 2, 3), up):
+        if u:
+            xe = xe.repeat_interleave(2, dim=ax)
+    if skip is not None:
+        xe = xe + skip
+    return q(xe, dtype)  # the kernel feeds the MFMA in the storage dtype
+
+
+def ref_conv(xe, w, stride, pad, bias):
+    y = F.conv3d(xe.permute(0, 4, 1, 2, 3), w.permute(0, 4, 1, 2, 3), stride=stride, padding=pad)
+    y = y.permute(0, 2, 3, 4, 1)
+    if bias is not None:
+        y = y + bias
+    return y
+
+
+CONV_CASES = [
+    # N, D, H, W, Cin, Cout, K, stride, pad, up, skip, pro, bias, ld_in, ld_out
+    dict(N=2, D=1, H=9, W=11, Cin=16, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=True, bias=False, ldin=40, ldout=64, id="dense3x3_2d_slab"),
+    dict(N=1, D=1, H=8, W=8, Cin=72, Cout=192, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=True, bias=False, ldin=96, ldout=None, id="bottleneck1x1"),
+    dict(N=1, D=1, H=6, W=5, Cin=24, Cout=40, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 1, 1), skip=True, pro=True, bias=True, ldin=None, ldout=None, id="decoder_up_skip_2d"),
+    dict(N=1, D=3, H=5, W=6, Cin=16, Cout=32, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 0, 0), skip=False, pro=True, bias=False, ldin=None, ldout=48, id="dense3x3x3"),
+    dict(N=1, D=2, H=4, W=4, Cin=8, Cout=24, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(1, 1, 1), skip=False, pro=True, bias=True, ldin=None, ldout=None, id="decoder_up222_3d"),
+    dict(N=1, D=2, H=5, W=4, Cin=8, Cout=16, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 1, 1), skip=True, pro=False, bias=True, ldin=None, ldout=None, id="decoder_up221_skip_3d"),
+    dict(N=2, D=1, H=18, W=14, Cin=8, Cout=96, K=(1, 7, 7), s=(1, 2, 2), p=(0, 3, 3), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="stem7x7s2"),
+    dict(N=1, D=8, H=10, W=10, Cin=8, Cout=96, K=(7, 7, 7), s=(2, 2, 2), p=(3, 3, 3), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="stem7x7x7s2"),
+    dict(N=1, D=1, H=40, W=36, Cin=64, Cout=8, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=True, bias=True, ldin=None, ldout=None, id="classifier_pad8"),
+    dict(N=1, D=1, H=70, W=66, Cin=32, Cout=264, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="wide_bn128"),
+]
+
+
+def build_conv_case(ops, cs, dtype, seed=0):
+    K, s, p, up = cs["K"], cs["s"], cs["p"], cs["up"]
+    N, D, H, W, Cin, Cout = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cin"], cs["Cout"]
+    x = rnd((N, D, H, W, Cin), seed + 1, 1.0, dtype)
+    De, He, We = D << up[0], H << up[1], W << up[2]
+    skip = rnd((N, De, He, We, Cin), seed + 2, 0.5, dtype) if cs["skip"] else None
+    pro = (rnd((Cin,), seed + 3, 1.0).abs() + 0.5, rnd((Cin,), seed + 4, 0.3)) if cs["pro"] else None
+    if pro is not None:
+        pro = (pro[0].float().double(), pro[1].float().double())
+    w = rnd((Cout,) + K + (Cin,), seed + 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cin), dtype)
+    bias = rnd((Cout,), seed + 6, 0.5).float().double() if cs["bias"] else None
+    Do = (De + 2 * p[0] - K[0]) // s[0] + 1
+    Ho = (He + 2 * p[1] - K[1]) // s[1] + 1
+    Wo = (We + 2 * p[2] - K[2]) // s[2] + 1
+    xa = mkact(ops, x, dtype, cs["ldin"], 8 if cs["ldin"] else 0)
+    sa = mkact(ops, skip, dtype) if skip is not None else None
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    return dict(x=x, skip=skip, pro=pro, w=w, bias=bias, xa=xa, sa=sa, wt=wt, out_dims=(N, Do, Ho, Wo, Cout))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES])
+def test_conv_fprop(hdu, cs, dtype):
+    ops = ops_mod()
+    b = build_conv_case(ops, cs, dtype)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    if cs["ldout"]:
+        big = ops.Act.alloc(N, Do, Ho, Wo, cs["ldout"], dtype, zero=True)
+        big.buf.fill_(3.0)
+        ya = big.slab(8, Cout)
+    else:
+        big = None
+        ya = ops.Act.alloc(N, Do, Ho, Wo, Cout, dtype)
+    pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+    bias = dev(ops, b["bias"]) if b["bias"] is not None else None
+    import ctypes
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), ya, cs["K"], cs["s"], cs["p"], cs["up"], b["sa"], pro, True, bias)
+    ops.conv_fprop(d)
+    xe = ref_xeff(b["x"], cs["up"], b["skip"], b["pro"], True, dtype)
+    ref = ref_conv(xe, b["w"], cs["s"], cs["p"], b["bias"])
+    assert_close(ya.to_torch().cpu(), ref, dtype, what="fprop")
+    if big is not None:  # neighbouring slab channels untouched
+        full = big.to_torch().cpu()
+        assert float((full[..., :8] - 3.0).abs().max()) == 0.0
+        assert float((full[..., 8 + Cout:] - 3.0).abs().max()) == 0.0
+    # accumulate mode
+    d.accumulate = 1
+    ops.conv_fprop(d)
+    assert_close(ya.to_torch().cpu(), q(ref, dtype) * 2, dtype, scale=2 * float(ref.abs().max()), what="fprop accumulate")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES])
+def test_conv_wgrad(hdu, cs, dtype):
+    ops = ops_mod()
+    b = build_conv_case(ops, cs, dtype, seed=100)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    dy = rnd((N, Do, Ho, Wo, Cout), 777, 1.0, dtype)
+    dya = mkact(ops, dy, dtype, cs["ldout"], 8 if cs["ldout"] else 0)
+    pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+    import ctypes
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"], b["sa"], pro, True, None)
+    dw = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+    ops.conv_wgrad(d, dw)
+    xe = ref_xeff(b["x"], cs["up"], b["skip"], b["pro"], True, dtype).requires_grad_(True)
+    wref = b["w"].clone().requires_grad_(True)
+    y = ref_conv(xe, wref, cs["s"], cs["p"], None)
+    (y * dy).sum().backward()
+    assert_close(dw.cpu(), wref.grad, F32 if dtype == F32 else BF16, what="wgrad")
+    # second call accumulates
+    ops.conv_wgrad(d, dw)
+    assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES if c["s"] == (1, 1, 1)])
+def test_conv_dgrad_via_fprop(hdu, cs, dtype):
+    """data gradient of a stride-1 conv = fprop with the flipped/transposed filter from hdu_weight_prep"""
+    ops = ops_mod()
+    import ctypes
+    K, p, up = cs["K"], cs["p"], cs["up"]
+    N, D, H, W, Cin, Cout = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cin"], cs["Cout"]
+    De, He, We = D << up[0], H << up[1], W << up[2]
+    w = rnd((Cout,) + K + (Cin,), 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cin), F32)
+    T = K[0] * K[1] * K[2]
+    tdt = torch.bfloat16 if dtype == BF16 else torch.float32
+    wf = torch.empty(Cout * T * Cin, dtype=tdt, device=ops.device())
+    wd = torch.empty(Cout * T * Cin, dtype=tdt, device=ops.device())
+    ops.weight_prep(dtype, dev(ops, w).reshape(-1), Cout, T, Cin, wf, wd)
+    assert_close(wf.cpu().reshape(w.shape), w, dtype, what="weight_prep fwd copy")
+    dy = rnd((N, De, He, We, Cout), 9, 1.0, dtype)   # stride 1 + same-size padding cases only produce De,He,We
+    Do, Ho, Wo = De + 2 * p[0] - K[0] + 1, He + 2 * p[1] - K[1] + 1, We + 2 * p[2] - K[2] + 1
+    dy = rnd((N, Do, Ho, Wo, Cout), 9, 1.0, dtype)
+    dya = mkact(ops, dy, dtype)
+    dxe = ops.Act.alloc(N, De, He, We, Cin, dtype)
+    d = ops.conv_desc(dya, ctypes.c_void_p(wd.data_ptr()), dxe, K, (1, 1, 1), (K[0] - 1 - p[0], K[1] - 1 - p[1], K[2] - 1 - p[2]))
+    ops.conv_fprop(d)
+    xe = torch.zeros((N, De, He, We, Cin), dtype=torch.float64, requires_grad=True)
+    y = ref_conv(xe, q(w, dtype), (1, 1, 1), p, None)
+    (y * dy).sum().backward()
+    assert_close(dxe.to_torch().cpu(), xe.grad, dtype, what="dgrad")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_dgrad_strided(hdu, dtype):
+    ops = ops_mod()
+    import ctypes
+    N, D, H, W, Cin, Cout, K, s, p = 1, 8, 10, 10, 8, 16, (7, 7, 7), (2, 2, 2), (3, 3, 3)
+    w = rnd((Cout,) + K + (Cin,), 5, 0.05, dtype)
+    Do, Ho, Wo = [(n + 6 - 7) // 2 + 1 for n in (D, H, W)]
+    dy = rnd((N, Do, Ho, Wo, Cout), 9, 1.0, dtype)
+    dya = mkact(ops, dy, dtype)
+    dx = ops.Act.alloc(N, D, H, W, Cin, dtype)
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    d = ops.conv_desc(dx, ctypes.c_void_p(wt.data_ptr()), dya, K, s, p)
+    ops.conv_dgrad_strided(d)
+    xe = torch.zeros((N, D, H, W, Cin), dtype=torch.float64, requires_grad=True)
+    (ref_conv(xe, w, s, p, None) * dy).sum().backward()
+    assert_close(dx.to_torch().cpu(), xe.grad, dtype, what="dgrad strided")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dropout_epilogue_consistent(hdu, dtype):
+    """conv epilogue dropout mask == mask regenerated by bn_bwd_apply; keep fraction plausible"""
+    ops = ops_mod()
+    import ctypes
+    N, D, H, W, Cin, Cout = 1, 1, 24, 24, 16, 32
+    x = rnd((N, D, H, W, Cin), 1, 1.0, dtype)
+    w = rnd((Cout, 1, 1, 1, Cin), 2, 0.3, dtype)
+    xa = mkact(ops, x, dtype)
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    y0 = ops.Act.alloc(N, D, H, W, Cout, dtype)
+    y1 = ops.Act.alloc(N, D, H, W, Cout, dtype)
+    ops.conv_fprop(ops.conv_desc(xa, ctypes.c_void_p(wt.data_ptr()), y0, (1, 1, 1)))
+    ops.conv_fprop(ops.conv_desc(xa, ctypes.c_void_p(wt.data_ptr()), y1, (1, 1, 1), drop_keep=0.7, drop_seed=123))
+    a, b_ = y0.to_torch().cpu().double(), y1.to_torch().cpu().double()
+    mask = b_ != 0
+    frac = float(mask.double().mean())
+    assert 0.66 < frac < 0.74, frac
+    assert_close(b_[mask], q(a[mask] / 0.7, dtype), dtype, what="dropout scale")
+    # bn_bwd_apply with k1=1,k2=k3=0, a=1,b=0, no relu regenerates the same mask
+    C = Cout
+    one = torch.ones(C, device=ops.device()); zero = torch.zeros(C, device=ops.device())
+    dz = mkact(ops, torch.ones((N, D, H, W, C), dtype=torch.float64), dtype)
+    dx = ops.Act.alloc(N, D, H, W, C, dtype)
+    ops.bn_bwd_apply(dz, y0, one, zero, False, zero, one, zero, zero, dx, False, 0.7, 123)
+    m2 = dx.to_torch().cpu() != 0
+    assert bool((m2 == mask).all()) or float((m2 != mask).double().mean()) < 1e-3  # (y0==0 exactly is measure-zero)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 1, 13, 11, 48, 72, 8), (1, 3, 7, 7, 8, None, 0), (1, 1, 33, 37, 264, None, 0), (1, 1, 5, 5, 96, 128, 16)])
+def test_bn_stats_fold(hdu, dtype, shape):
+    ops = ops_mod()
+    N, D, H, W, C, ld, coff = shape
+    x = rnd((N, D, H, W, C), 3, 2.0, dtype) + q(rnd((C,), 4, 30.0), dtype)  # large per-channel offsets
+    x = q(x, dtype)
+    xa = mkact(ops, x, dtype, ld, coff)
+    mean = torch.empty(C, device=ops.device()); var = torch.empty(C, device=ops.device())
+    ws = ops.Workspace(ops.reduce_ws_bytes(xa.M, C))
+    ops.bn_stats(xa, mean, var, ws)
+    xf = x.reshape(-1, C)
+    mref = xf.mean(0)
+    vref = ((xf - mref) ** 2).mean(0)   # tf.nn.moments: biased
+    assert float((mean.cpu().double() - mref).abs().max()) < 1e-4 * (1 + float(mref.abs().max()))
+    assert float(((var.cpu().double() - vref) / vref).abs().max()) < 2e-4
+    # fold with Scale + moving stats
+    g = rnd((C,), 5, 0.5) + 1.0; be = rnd((C,), 6, 0.2); sg = rnd((C,), 7, 0.5) + 1.0; sb = rnd((C,), 8, 0.2)
+    mm = rnd((C,), 9, 1.0).float(); mv = (rnd((C,), 10, 0.4) + 1.0).float()
+    a = torch.empty(C, device=ops.device()); b = torch.empty(C, device=ops.device()); r = torch.empty(C, device=ops.device())
+    mmd, mvd = mm.clone().to(ops.device()), mv.clone().to(ops.device())
+    eps = 1.1e-5
+    ops.bn_fold(C, mean, var, dev(ops, g), dev(ops, be), eps, dev(ops, sg), dev(ops, sb), a, b, r, mmd, mvd, 0.99)
+    rr = 1 / torch.sqrt(vref + eps)
+    aref = sg * g * rr
+    bref = sg * (be - mref * g * rr) + sb
+    assert float(((a.cpu().double() - aref) / aref).abs().max()) < 2e-4
+    assert float((b.cpu().double() - bref).abs().max()) < 2e-3 * (1 + float(bref.abs().max()))
+    assert float((mmd.cpu().double() - (mm.double() - (mm.double() - mref) * 0.01)).abs().max()) < 1e-4
+    assert float((mvd.cpu().double() - (mv.double() - (mv.double() - vref) * 0.01)).abs().max()) < 1e-4
+    # normalised output has mean ~ beta', std ~ gamma' (the reference suite's own BN check, normalization_test.py:35-49)
+    z = ops.Act.alloc(N, D, H, W, C, dtype)
+    one = torch.ones(C, device=ops.device()); zero = torch.zeros(C, device=ops.device())
+    ops.bn_fold(C, mean, var, one, zero, eps, None, None, a, b, r)
+    ops.affine_act(xa, a, b, False, z)
+    zt = z.to_torch().cpu().double().reshape(-1, C)
+    assert float(zt.mean(0).abs().max()) < 1e-1 and float((zt.std(0) - 1).abs().max()) < 1e-1
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("batch_stats", [True, False])
+def test_bn_backward(hdu, dtype, batch_stats):
+    """BN(+Scale)+ReLU backward: reduce + coef + apply vs autograd of the float64 restatement"""
+    ops = ops_mod()
+    N, D, H, W, C = 2, 1, 9, 7, 24
+    eps = 1.1e-5
+    x = q(rnd((N, D, H, W, C), 3, 2.0, dtype) + 0.5, dtype)
+    dz = rnd((N, D, H, W, C), 4, 1.0, dtype)
+    g = (rnd((C,), 5, 0.5) + 1.0).float().double(); be = rnd((C,), 6, 0.2).float().double()
+    sg = (rnd((C,), 7, 0.5) + 1.0).float().double(); sb = rnd((C,), 8, 0.2).float().double()
+    mm = rnd((C,), 9, 0.5).float().double(); mv = (rnd((C,), 10, 0.4) + 1.0).float().double()
+    M = N * D * H * W
+    xa, dza = mkact(ops, x, dtype), mkact(ops, dz, dtype)
+    ws = ops.Workspace(ops.reduce_ws_bytes(M, C))
+    dv = lambda t: dev(ops, t)
+    E = lambda: torch.empty(C, device=ops.device())
+    mean, var, a, b, r, s1, s2, k1, k2, k3, dg, db, dsg, dsb = [E() for _ in range(14)]
+    if batch_stats:
+        ops.bn_stats(xa, mean, var, ws)
+    else:
+        mean.copy_(dv(mm)); var.copy_(dv(mv))
+    ops.bn_fold(C, mean, var, dv(g), dv(be), eps, dv(sg), dv(sb), a, b, r)
+    ops.bn_bwd_reduce(dza, xa, a, b, True, mean, r, s1, s2, ws)
+    ops.bn_bwd_coef(C, M, batch_stats, s1, s2, dv(g), dv(be), dv(sg), r, k1, k2, k3, dg, db, dsg, dsb)
+    dx = ops.Act.alloc(N, D, H, W, C, dtype)
+    ops.bn_bwd_apply(dza, xa, a, b, True, mean, k1, k2, k3, dx)
+    # reference
+    xr = x.clone().requires_grad_(True)
+    gr, ber, sgr, sbr = [t.clone().requires_grad_(True) for t in (g, be, sg, sb)]
+    xf = xr.reshape(-1, C)
+    if batch_stats:
+        mu = xf.mean(0); v = ((xf - mu) ** 2).mean(0)
+    else:
+        mu, v = mm, mv
+    y = (xr - mu) / torch.sqrt(v + eps) * gr + ber
+    z = (sgr * y + sbr).clamp_min(0)
+    (z * dz).sum().backward()
+    assert_close(dx.to_torch().cpu(), xr.grad, dtype, what="bn dx")
+    for got, ref, nm in ((dg, gr.grad, "dgamma"), (db, ber.grad, "dbeta"), (dsg, sgr.grad, "dsgamma"), (dsb, sbr.grad, "dsbeta")):
+        assert_close(got.cpu(), ref, dtype, what=nm)
+    # accumulate
+    ops.bn_bwd_apply(dza, xa, a, b, True, mean, k1, k2, k3, dx, True)
+    assert_close(dx.to_torch().cpu(), 2 * xr.grad, dtype, what="bn dx accumulate")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("dims", [(2, 1, 10, 12, 16), (1, 6, 8, 10, 8), (1, 5, 7, 9, 8)])
+def test_maxpool(hdu, dtype, dims):
+    ops = ops_mod()
+    N, D, H, W, C = dims
+    x = rnd((N, D, H, W, C), 3, 1.0, dtype).clamp_min(0)   # post-ReLU input as in the model
+    x = x + (x > 0) * q(rnd((N, D, H, W, C), 4, 0.01, dtype).abs(), dtype)
+    x = q(x, dtype)
+    xa = mkact(ops, x, dtype)
+    Do = 1 if D == 1 else (D - 1) // 2 + 1
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = ops.Act.alloc(N, Do, Ho, Wo, C, dtype)
+    ops.maxpool_fwd(xa, y)
+    xr = x.clone().requires_grad_(True)
+    xp = xr.permute(0, 4, 1, 2, 3)
+    if D == 1:
+        yr = F.max_pool2d(F.pad(xp[:, :, 0], (1, 1, 1, 1)), 3, 2)[:, :, None]
+    else:
+        yr = F.max_pool3d(F.pad(xp, (1, 1, 1, 1, 1, 1)), 3, 2)
+    yr = yr.permute(0, 2, 3, 4, 1)
+    assert tuple(yr.shape) == (N, Do, Ho, Wo, C)
+    assert float((y.to_torch().cpu().double() - yr).abs().max()) == 0.0
+    dy = rnd((N, Do, Ho, Wo, C), 5, 1.0, dtype)
+    (yr * dy).sum().backward()
+    dx = ops.Act.alloc(N, D, H, W, C, dtype)
+    ops.maxpool_bwd(xa, mkact(ops, dy, dtype), dx)
+    got = dx.to_torch().cpu().double()
+    # ties only happen at exactly 0 (post-ReLU) where the upstream ReLU kills the gradient: compare where x>0
+    nz = x > 0
+    assert_close(got[nz], xr.grad[nz], dtype, scale=float(xr.grad.abs().max()), what="maxpool bwd")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_avgpool_upsample(hdu, dtype):
+    ops = ops_mod()
+    N, D, H, W, C = 1, 3, 8, 6, 16
+    x = rnd((N, D, H, W, C), 3, 1.0, dtype)
+    xa = mkact(ops, x, dtype)
+    y = ops.Act.alloc(N, D, H // 2, W // 2, C, dtype)
+    ops.avgpool_fwd(xa, y)
+    ref = x.reshape(N, D, H // 2, 2, W // 2, 2, C).mean((3, 5))
+    assert_close(y.to_torch().cpu(), ref, dtype, what="avgpool")
+    dy = rnd((N, D, H // 2, W // 2, C), 4, 1.0, dtype)
+    dx = ops.Act.alloc(N, D, H, W, C, dtype)
+    ops.avgpool_bwd(mkact(ops, dy, dtype), dx)
+    refdx = dy.repeat_interleave(2, 2).repeat_interleave(2, 3) * 0.25
+    assert_close(dx.to_torch().cpu(), refdx, dtype, what="avgpool bwd")
+    # nearest up-sampling gradient == sum over children; known answer from the reference suite: UpSampling == np.repeat
+    for up in [(0, 1, 1), (1, 1, 1)]:
+        g = rnd((N, D << up[0], H << up[1], W << up[2], C), 5, 1.0, dtype)
+        dz = ops.Act.alloc(N, D, H, W, C, dtype)
+        ops.upsample_bwd(mkact(ops, g, dtype), dz, up)
+        r = g.reshape(N, D, 1 << up[0], H, 1 << up[1], W, 1 << up[2], C).sum((2, 4, 6))
+        assert_close(dz.to_torch().cpu(), r, dtype, what="upsample bwd")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_wce_loss(hdu, dtype):
+    ops = ops_mod()
+    M = 5000
+    z = rnd((1, 1, 1, M, 3), 3, 6.0, dtype)
+    z[0, 0, 0, :20, 0] = 60.0  # saturate: p(class 1/2) < 1e-10 -> clipped, zero gradient
+    z = q(z, dtype)
+    g = torch.Generator().manual_seed(5)
+    lab = torch.randint(0, 3, (M,), generator=g)
+    lab[:20] = torch.tensor([1, 2] * 10)
+    Cp = 8 if dtype == BF16 else 4
+    zz = torch.zeros((1, 1, 1, M, Cp), dtype=torch.float64); zz[..., :3] = z
+    la = mkact(ops, zz, dtype)
+    dl = ops.Act.alloc(1, 1, 1, M, Cp, dtype)
+    dl.buf.fill_(5.0)
+    loss = torch.zeros(1, device=ops.device()); cnt = torch.zeros(3, device=ops.device())
+    ws = ops.Workspace(1 << 16)
+    w = (0.78, 0.65, 8.57)
+    ops.wce_loss(la, lab.to(torch.uint8).to(ops.device()), 0, M, w, 1.0 / M, dl, loss, cnt, ws)
+    zr = z.reshape(M, 3).clone().requires_grad_(True)
+    p = torch.softmax(zr, 1)
+    lp = torch.log(torch.clamp(p, 1e-10, 1.0))
+    wt = torch.tensor(w, dtype=torch.float64)[lab]
+    L = -(wt * lp[torch.arange(M), lab]).sum() / M
+    L.backward()
+    assert abs(float(loss.cpu()) / M - float(L)) < 2e-5 * abs(float(L)) + 1e-6
+    assert cnt.cpu().tolist() == [float((lab == i).sum()) for i in range(3)]
+    got = dl.to_torch().cpu().double().reshape(M, Cp)
+    assert float(got[:, 3:].abs().max()) == 0.0
+    rt, at = tol(dtype)
+    assert float((got[:, :3] - zr.grad).abs().max()) < at * float(zr.grad.abs().max()) + 1e-9
+
+
+def test_sgd_nesterov(hdu):
+    ops = ops_mod()
+    n = 10007
+    p, v, g = rnd((n,), 1).float(), rnd((n,), 2, 0.1).float(), rnd((n,), 3).float()
+    pd, vd, gd = [t.clone().to(ops.device()) for t in (p, v, g)]
+    ops.sgd_nesterov(pd, vd, gd, 1e-3, 0.9, 0.5)
+    gs = g * 0.5
+    vn = 0.9 * v - 1e-3 * gs
+    pn = p + 0.9 * vn - 1e-3 * gs
+    assert torch.allclose(vd.cpu(), vn, rtol=1e-6, atol=1e-8) and torch.allclose(pd.cpu(), pn, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_plumbing(hdu, dtype):
+    ops = ops_mod()
+    D, H, W = 5, 4, 6
+    Cp = 8 if dtype == BF16 else 4
+    vol = rnd((D, H, W), 1, 100.0).float()
+    out = ops.Act.alloc(D, 1, H, W, Cp, dtype)
+    ops.slab25d(vol.to(ops.device()), D, H, W, out)
+    got = out.to_torch().cpu().reshape(D, H, W, Cp)
+    for k in range(D):  # denseunet3d.py:399-409: slab k = slices (k-1,k,k+1), edges replicated
+        for j, kk in enumerate((max(k - 1, 0), k, min(k + 1, D - 1))):
+            assert_close(got[k, :, :, j], q(vol[kk].double(), dtype), dtype, what="slab25d")
+    assert float(got[..., 3:].abs().max()) == 0.0
+    lg = rnd((1, D, H, W, Cp), 2, 3.0, dtype); lg[..., 3:] = 0
+    lga = mkact(ops, lg, dtype)
+    i3 = ops.Act.alloc(1, D, H, W, Cp, dtype)
+    ops.make_input3d(vol.to(ops.device()), lga, 250.0, i3)
+    g3 = i3.to_torch().cpu().double()
+    assert_close(g3[0, ..., 0], q(vol.double(), dtype), dtype, what="input3d ct")
+    assert_close(g3[0, ..., 1:4], q(lg[0, ..., :3] * 250, dtype), dtype, what="input3d logits")
+    din = rnd((1, D, H, W, Cp), 3, 1.0, dtype)
+    dl = ops.Act.alloc(1, D, H, W, Cp, dtype)
+    ops.make_input3d_bwd(mkact(ops, din, dtype), 250.0, dl)
+    assert_close(dl.to_torch().cpu()[..., :3], din[..., 1:4] * 250, dtype, what="input3d bwd")
+    # cast helpers
+    src = rnd((7, 3), 4, 5.0).float()
+    a = ops.Act.alloc(1, 1, 1, 7, Cp, dtype)
+    ops.cast_pad(src.to(ops.device()), 7, 3, a)
+    back = torch.empty(7, 3, device=ops.device())
+    ops.cast_out(a, 3, back)
+    assert_close(back.cpu(), q(src.double(), dtype), dtype, what="cast round trip")
+
+
+def test_abi_errors(hdu):
+    """bad arguments come back as error codes + message, never a crash (include/hdu.h conventions)"""
+    ops = ops_mod()
+    import ctypes
+    x = ops.Act.alloc(1, 1, 4, 4, 8, BF16)
+    y = ops.Act.alloc(1, 1, 4, 4, 8, BF16)
+    w = torch.zeros(8 * 9 * 8, dtype=torch.bfloat16, device=ops.device())
+    d = ops.conv_desc(x, ctypes.c_void_p(w.data_ptr()), y, (1, 3, 3), (1, 1, 1), (0, 0, 0))  # wrong out dims for pad 0
+    with pytest.raises(hdu.lib.HduError, match="output dims"):
+        ops.conv_fprop(d)
+    bad = ops.Act(x.buf, 0, 1, 1, 4, 4, 6, 6, BF16)
+    with pytest.raises(hdu.lib.HduError):
+        ops.affine_act(bad, None, None, True, bad)
