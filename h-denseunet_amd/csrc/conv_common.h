@@ -22,6 +22,7 @@ struct ConvK {
   float drop_scale;           // 1/keep (0 => dropout disabled)
   unsigned drop_thresh;       // keep iff hash < thresh
   unsigned drop_seed;
+  const unsigned* drop_seed_dev;
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][128 B] LDS tile.

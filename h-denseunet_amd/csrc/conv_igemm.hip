@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 
   // ---- epilogue: bias, dropout, optional accumulate, store ----
   T* __restrict__ yp = (T*)p.y;
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
         float v = acc[i][j][r];
         if (p.bias) v += p.bias[n];
         if (p.drop_scale != 0.f) {
-          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, p.drop_seed);
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
           v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
         }
         T* q = yp + m * p.ldy + n;
@@ -596,6 +597,7 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
     k->drop_thresh = 0xffffffffu;
   }
   k->drop_seed = d->drop_seed;
+  k->drop_seed_dev = d->drop_seed_dev;
   return 0;
 }
 

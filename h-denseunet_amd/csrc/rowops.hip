@@ -293,6 +293,7 @@ struct RowK {
   const float* k3;
   float drop_scale;
   unsigned drop_thresh, drop_seed;
+  const unsigned* drop_seed_dev;
 };
 
 template <typename T>
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ dzp = (const T*)p.dz;
   T* __restrict__ op = (T*)p.out;
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(q % ncc) * CH;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
       const float gg = (!p.relu || s > 0.f) ? g[j] : 0.f;
       float d = p.k1[c] * gg - p.k2[c] - p.k3[c] * (f[j] - p.mean[c]);
       if (p.drop_scale != 0.f) {
-        const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.C + (unsigned)c, p.drop_seed);
+        const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.C + (unsigned)c, dseed);
         d = h < p.drop_thresh ? d * p.drop_scale : 0.f;
       }
       o[j] = d;
@@ -382,7 +384,7 @@ extern "C" int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, 
 extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
                                 int C, const float* a, const float* b, int relu, const float* mean, const float* k1,
                                 const float* k2, const float* k3, void* dx, int64_t lddx, int accumulate,
-                                float drop_keep, uint32_t drop_seed, void* stream) {
+                                float drop_keep, uint32_t drop_seed, const uint32_t* drop_seed_dev, void* stream) {
   RowK k{};
   k.x = x; k.ldx = ldx; k.dz = dz; k.lddz = lddz; k.out = dx; k.ldo = lddx; k.M = M; k.C = C;
   k.a = a; k.b = b; k.relu = relu; k.mean = mean; k.k1 = k1; k.k2 = k2; k.k3 = k3; k.accumulate = accumulate;
@@ -391,6 +393,7 @@ extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const v
     k.drop_thresh = (unsigned)((double)drop_keep * 4294967296.0);
   }
   k.drop_seed = drop_seed;
+  k.drop_seed_dev = drop_seed_dev;
   if (!x || !dz || !dx || !a || !b || !mean || !k1 || !k2 || !k3) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_apply: null pointer");
   if (int e = rowk_check(dtype, k, "bn_bwd_apply: C / strides must be multiples of the 16-byte chunk")) return e;
   if (M == 0) return 0;

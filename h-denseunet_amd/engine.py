@@ -1,0 +1,585 @@
+"""Host-side execution engine of the hot path (replaces the slice of Keras-2.0.8/keras/engine/training.py
+that is one train / predict step: :948-967 _make_train_function, :1715-1766 train_on_batch, :1659-1713 predict).
+
+There is no graph tracer and no autodiff: a model constructor emits a static list of forward launches and, in
+reverse, hand-written backward launches; every buffer is allocated once at build time so a whole step is a
+fixed launch sequence that can be captured in one hipGraph.
+
+Layout: activations channels-last [N][D][H][W][C] in the compute dtype (bf16, or f32 in parity mode), depth-major
+for 3D (the reference's N,H,W,D,C is converted at the boundary).  Parameters live in ONE flat float32 buffer
+(trainables first) with matching gradient and velocity buffers, so the optimiser and the data-parallel gradient
+all-reduce are single flat operations.  Conv filters are stored [Cout][KD][KH][KW][Cin] (converted from Keras'
+(k..,Cin,Cout) in set_weights / get_weights).
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .lib import HDU_BF16, HDU_F32
+
+
+class Param:
+    __slots__ = ("layer", "idx", "kind", "keras_shape", "shape", "trainable", "init", "offset", "numel", "ctx", "meta")
+
+    def __init__(self, ctx, layer, idx, kind, keras_shape, shape, trainable, init, meta=None):
+        self.ctx, self.layer, self.idx, self.kind = ctx, layer, idx, kind
+        self.keras_shape, self.shape, self.trainable, self.init = tuple(keras_shape), tuple(shape), trainable, init
+        self.numel = int(np.prod(shape))
+        self.offset = None
+        self.meta = meta or {}
+
+    @property
+    def data(self):
+        return self.ctx.P[self.offset:self.offset + self.numel]
+
+    @property
+    def grad(self):
+        return self.ctx.G[self.offset:self.offset + self.numel]
+
+
+class Var:
+    """An activation (or a channel slab of a dense-block buffer) plus its gradient / statistics bookkeeping."""
+
+    def __init__(self, ctx, act, root=None, c0=0):
+        self.ctx, self.act, self.c0 = ctx, act, c0
+        self.root = root or self
+        if root is None:
+            self.grad_act = None
+            self.written = False
+            self.mean = None
+            self.var = None
+            self.needs_grad = False
+            self.drop = None  # (keep, seed) if produced through dropout
+        self.C = act.C
+
+    def slab(self, c0, C):
+        return Var(self.ctx, self.act.slab(c0, C), self.root, self.c0 + c0)
+
+    # -- gradient storage (allocated lazily at build time)
+    def require_grad(self):
+        r = self.root
+        if not r.needs_grad:
+            r.needs_grad = True
+            a = r.act
+            r.grad_act = ops.Act.alloc(a.N, a.D, a.H, a.W, a.ld, a.dtype, zero=True)
+        return self
+
+    @property
+    def grad(self):
+        return self.root.grad_act.slab(self.c0, self.C)
+
+    def grad_mode(self):
+        """returns accumulate flag for a writer into this var's gradient; first writer overwrites"""
+        r = self.root
+        acc = r.written
+        if not acc:
+            # a first write must cover the buffer from channel 0 (asserted by construction of the nets)
+            assert self.c0 == 0, "first gradient write into a shared buffer must start at channel 0"
+            if self.C != r.act.ld:
+                # partial first write: clear the rest so later slab readers see zeros
+                r.grad_act.buf.zero_()
+        r.written = True
+        return acc
+
+    # -- batch statistics of the channels of this var (shared by every consumer BN: SURVEY.md section 7)
+    def stats(self):
+        r = self.root
+        if r.mean is None:
+            dev = ops.device()
+            r.mean = torch.zeros(r.act.ld, dtype=torch.float32, device=dev)
+            r.var = torch.ones(r.act.ld, dtype=torch.float32, device=dev)
+        return r.mean[self.c0:self.c0 + self.C], r.var[self.c0:self.c0 + self.C]
+
+
+class Ctx:
+    """Build + run context of one model."""
+
+    def __init__(self, dtype, batch_shape):
+        self.dtype = dtype
+        self.ch = ops.CHUNK[dtype]
+        self.params = []
+        self.by_layer = OrderedDict()
+        self.layer_kind = OrderedDict()
+        self.fwd = []          # list of callables
+        self.bwd = []          # appended in forward order, executed reversed
+        self.vars = []
+        self.learning_phase = 1
+        self.P = self.G = self.V = None
+        self.n_trainable = 0
+        self.convs = []
+        self._scratch = {}
+        self.ws_bytes = 1 << 16
+        self.ws = None
+        self.dev = ops.device()
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)  # device step counter (dropout seed)
+        self.drop_layers = 0
+        self.dropout_enabled = True
+        self.grad_enabled = True
+        self.finalized = False
+
+    # ---------------- parameters
+    def add_param(self, layer, kind, idx, keras_shape, shape, trainable, init, meta=None):
+        p = Param(self, layer, idx, kind, keras_shape, shape, trainable, init, meta)
+        self.params.append(p)
+        self.by_layer.setdefault(layer, []).append(p)
+        self.layer_kind[layer] = kind
+        return p
+
+    def need_ws(self, M, C):
+        self.ws_bytes = max(self.ws_bytes, ops.reduce_ws_bytes(M, C))
+
+    def scratch(self, slot, N, D, H, W, C):
+        """shared backward scratch (stream-ordered reuse): one buffer per slot sized to the largest request"""
+        n = N * D * H * W * C
+        ent = self._scratch.setdefault(slot, {"n": 0, "buf": None})
+        ent["n"] = max(ent["n"], n)
+        return lambda: ops.Act(ent["buf"], 0, N, D, H, W, C, C, self.dtype)
+
+    def new_var(self, N, D, H, W, C, ld=None):
+        v = Var(self, ops.Act.alloc(N, D, H, W, C, self.dtype, ld=ld, zero=True))
+        self.vars.append(v)
+        return v
+
+    def fvec(self, C, fill=0.0):
+        return torch.full((C,), fill, dtype=torch.float32, device=self.dev)
+
+    def finalize(self, seed=4321):
+        order = [p for p in self.params if p.trainable] + [p for p in self.params if not p.trainable]
+        off = 0
+        for p in order:
+            p.offset = off
+            off += (p.numel + 3) // 4 * 4   # keep every parameter 16-byte aligned
+            if p.trainable:
+                self.n_trainable = off
+        self.P = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.G = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.V = torch.zeros(max(self.n_trainable, 4), dtype=torch.float32, device=self.dev)
+        self.ws = ops.Workspace(self.ws_bytes)
+        tdt = torch.bfloat16 if self.dtype == HDU_BF16 else torch.float32
+        for ent in self._scratch.values():
+            ent["buf"] = torch.zeros(ent["n"], dtype=tdt, device=self.dev)
+        # compute-dtype filter copies
+        tot = 0
+        for cv in self.convs:
+            cv.wf_off = tot
+            tot += cv.kernel.numel
+            if cv.need_dgrad_filter:
+                cv.wd_off = tot
+                tot += cv.kernel.numel
+        self.Wc = torch.zeros(max(tot, 8), dtype=tdt, device=self.dev)
+        self.init_weights(seed)
+        for cv in self.convs:
+            cv.bind()
+        self.finalized = True
+
+    def init_weights(self, seed):
+        """Keras initialisers (K.initializers.py): glorot_uniform for convs (:332), 'normal' = RandomNormal(0.05)
+        (:72,:429) where the reference asks for it; BN gamma=1 beta=0 mean=0 var=1; Scale gamma=1 beta=0."""
+        rng = np.random.default_rng(seed)
+        for layer, ps in self.by_layer.items():
+            arrs = []
+            for p in ps:
+                if p.init == "zeros":
+                    a = np.zeros(p.keras_shape, np.float32)
+                elif p.init == "ones":
+                    a = np.ones(p.keras_shape, np.float32)
+                elif p.init == "normal":
+                    a = rng.normal(0.0, 0.05, p.keras_shape).astype(np.float32)
+                else:
+                    ks = p.keras_shape
+                    fan_in = int(np.prod(ks[:-1]))
+                    fan_out = int(np.prod(ks[:-2])) * ks[-1]
+                    lim = math.sqrt(6.0 / (fan_in + fan_out))
+                    a = rng.uniform(-lim, lim, ks).astype(np.float32)
+                arrs.append(a)
+            self.set_layer_weights(layer, arrs)
+
+    # ---------------- Keras-shaped weight exchange (topology.py:2847-2873 ordering per layer)
+    def _to_internal(self, p, a):
+        a = np.asarray(a, np.float32)
+        if a.shape != p.keras_shape:
+            raise ValueError("layer %s weight %d: expected shape %s, got %s" % (p.layer, p.idx, p.keras_shape, a.shape))
+        if p.kind == "conv_kernel":
+            nd = a.ndim - 2
+            cin, cout = a.shape[-2], a.shape[-1]
+            cout_p, kd, kh, kw, cin_p = p.shape
+            if nd == 2:
+                k = a.transpose(3, 0, 1, 2)[:, None]            # (Cout,1,kh,kw,Cin)
+            else:
+                k = a.transpose(4, 2, 0, 1, 3)                   # Keras (kH,kW,kD,Cin,Cout) -> (Cout,kD,kH,kW,Cin)
+            out = np.zeros(p.shape, np.float32)
+            out[:cout, :, :, :, :cin] = k
+            return out
+        if p.kind == "conv_bias":
+            out = np.zeros(p.shape, np.float32)
+            out[:a.shape[0]] = a
+            return out
+        return a
+
+    def _to_keras(self, p, t):
+        a = t.detach().float().cpu().numpy().reshape(p.shape)
+        if p.kind == "conv_kernel":
+            nd = len(p.keras_shape) - 2
+            cin, cout = p.keras_shape[-2], p.keras_shape[-1]
+            k = a[:cout, :, :, :, :cin]
+            if nd == 2:
+                return np.ascontiguousarray(k[:, 0].transpose(1, 2, 3, 0))
+            return np.ascontiguousarray(k.transpose(2, 3, 1, 4, 0))
+        if p.kind == "conv_bias":
+            return a[:p.keras_shape[0]].copy()
+        return a.copy()
+
+    def set_layer_weights(self, layer, arrs):
+        ps = self.by_layer[layer]
+        if len(arrs) != len(ps):
+            raise ValueError("layer %s expects %d weight arrays, got %d" % (layer, len(ps), len(arrs)))
+        for p, a in zip(ps, arrs):
+            t = torch.from_numpy(self._to_internal(p, a).reshape(-1)).to(self.dev)
+            self.P[p.offset:p.offset + p.numel] = t
+
+    def get_layer_weights(self, layer):
+        return [self._to_keras(p, p.data) for p in self.by_layer[layer]]
+
+    def get_layer_grads(self, layer):
+        return [self._to_keras(p, p.grad) for p in self.by_layer[layer] if p.trainable]
+
+    # ---------------- step pieces
+    def prep_weights(self):
+        for cv in self.convs:
+            cv.prep()
+
+    def run_forward(self):
+        for f in self.fwd:
+            f()
+
+    def run_backward(self):
+        for v in self.vars:
+            v.written = False
+        for f in reversed(self.bwd):
+            f()
+
+
+# ======================================================================================= layers
+class BNLayer:
+    """BatchNormalization (+ optional Scale) + optional ReLU folded to a per-channel affine that the consumer
+    applies on load.  K.layers/normalization.py:126-190, lib/custom_layers.py:63-69."""
+
+    def __init__(self, ctx, name, C, eps=1e-3, momentum=0.99, mode="batch", trainable=True, scale_name=None,
+                 scale_trainable=True, relu=True):
+        self.ctx, self.name, self.C, self.eps, self.momentum, self.mode, self.relu = ctx, name, C, eps, momentum, mode, relu
+        self.trainable = trainable
+        self.gamma = ctx.add_param(name, "bn", 0, (C,), (C,), trainable, "ones")
+        self.beta = ctx.add_param(name, "bn", 1, (C,), (C,), trainable, "zeros")
+        self.mm = ctx.add_param(name, "bn", 2, (C,), (C,), False, "zeros")
+        self.mv = ctx.add_param(name, "bn", 3, (C,), (C,), False, "ones")
+        self.sg = self.sb = None
+        self.scale_trainable = scale_trainable
+        if scale_name:
+            self.sg = ctx.add_param(scale_name, "scale", 0, (C,), (C,), scale_trainable, "ones")
+            self.sb = ctx.add_param(scale_name, "scale", 1, (C,), (C,), scale_trainable, "zeros")
+        v = ctx.fvec
+        self.a, self.b, self.rstd = v(C), v(C), v(C)
+        self.s1, self.s2, self.k1, self.k2, self.k3 = v(C), v(C), v(C), v(C), v(C)
+        self.mean_used = None
+        self.batch_now = False
+
+    def any_trainable(self):
+        return self.trainable or (self.sg is not None and self.scale_trainable)
+
+    def needs_stats(self):
+        return self.mode == "batch"
+
+    def fold(self, xvar):
+        ctx = self.ctx
+        sg = self.sg.data if self.sg else None
+        sb = self.sb.data if self.sb else None
+        self.batch_now = self.mode == "batch" and ctx.learning_phase == 1
+        if self.batch_now:
+            mean, var = xvar.stats()
+            ops.bn_fold(self.C, mean, var, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a, self.b,
+                        self.rstd, self.mm.data, self.mv.data, self.momentum)
+            self.mean_used = mean
+        else:
+            ops.bn_fold(self.C, self.mm.data, self.mv.data, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a,
+                        self.b, self.rstd)
+            self.mean_used = self.mm.data
+
+    def backward(self, xvar, dz_act):
+        """dz: gradient w.r.t. relu(a*x+b) at x's resolution.  Writes x.grad and the parameter gradients."""
+        ctx = self.ctx
+        x = xvar.act
+        need_sums = self.batch_now or self.any_trainable()
+        if need_sums:
+            ops.bn_bwd_reduce(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.s1, self.s2, ctx.ws)
+        tr_bn = self.trainable
+        tr_sc = self.sg is not None and self.scale_trainable
+        ops.bn_bwd_coef(self.C, x.M, self.batch_now, self.s1 if need_sums else None, self.s2 if need_sums else None,
+                        self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.rstd, self.k1,
+                        self.k2, self.k3, self.gamma.grad if tr_bn else None, self.beta.grad if tr_bn else None,
+                        self.sg.grad if tr_sc else None, self.sb.grad if tr_sc else None)
+        if xvar.root.needs_grad:
+            acc = xvar.grad_mode()
+            drop = xvar.root.drop if (ctx.dropout_enabled and ctx.learning_phase == 1) else None
+            ops.bn_bwd_apply(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.k1, self.k2, self.k3,
+                             xvar.grad, acc, drop[0] if drop else 1.0, drop[1] if drop else 0,
+                             ctx.seed_dev if drop else None)
+
+
+class ConvLayer:
+    """[BN(+Scale)+ReLU] -> [UpSampling] -> [+skip] -> [ZeroPadding] -> Conv(+bias)(+Dropout) as ONE launch."""
+
+    def __init__(self, ctx, name, x, filters, K, stride=(1, 1, 1), pad=(0, 0, 0), bn=None, up=(0, 0, 0), skip=None,
+                 use_bias=True, out=None, init="glorot", trainable=True, dropout=0.0, keras_nd=2, cin_logical=None):
+        self.ctx, self.name, self.x, self.bn, self.up, self.skip = ctx, name, x, bn, up, skip
+        self.K, self.stride, self.pad = K, stride, pad
+        self.trainable = trainable
+        dt = ctx.dtype
+        xa = x.act
+        cin_p = xa.C
+        cin = cin_logical or cin_p
+        cout_p = ops.cpad(filters, dt)
+        De, He, We = xa.D << up[0], xa.H << up[1], xa.W << up[2]
+        Do = (De + 2 * pad[0] - K[0]) // stride[0] + 1
+        Ho = (He + 2 * pad[1] - K[1]) // stride[1] + 1
+        Wo = (We + 2 * pad[2] - K[2]) // stride[2] + 1
+        if out is None:
+            out = ctx.new_var(xa.N, Do, Ho, Wo, cout_p)
+        else:
+            assert (out.act.N, out.act.D, out.act.H, out.act.W, out.act.C) == (xa.N, Do, Ho, Wo, cout_p)
+        self.out = out
+        kshape = ((K[1], K[2]) if keras_nd == 2 else (K[1], K[2], K[0])) + (cin, filters)
+        self.kernel = ctx.add_param(name, "conv_kernel", 0, kshape, (cout_p, K[0], K[1], K[2], cin_p), trainable, init)
+        self.bias = ctx.add_param(name, "conv_bias", 1, (filters,), (cout_p,), trainable, "zeros") if use_bias else None
+        ctx.layer_kind[name] = "conv"
+        self.T = K[0] * K[1] * K[2]
+        self.cin_p, self.cout_p = cin_p, cout_p
+        self.dropout = dropout
+        if dropout > 0:
+            ctx.drop_layers += 1
+            self.drop_seed = 7919 * ctx.drop_layers
+            out.root.drop = (1.0 - dropout, self.drop_seed)
+        need_input_grad = x.root.needs_grad
+        if ctx.grad_enabled:
+            out.require_grad()
+        self.need_input_grad = need_input_grad
+        self.strided = stride != (1, 1, 1)
+        self.need_dgrad_filter = need_input_grad and not self.strided
+        self.wf_off = self.wd_off = None
+        ctx.convs.append(self)
+        if bn is not None and bn.needs_stats():
+            ctx.need_ws(xa.M, xa.C)
+        ctx.need_ws(out.act.M, cout_p)
+        if need_input_grad:
+            if bn is not None or up != (0, 0, 0):
+                self._dxe = ctx.scratch("dxe", xa.N, De, He, We, cin_p)
+            if bn is not None and up != (0, 0, 0):
+                self._dz = ctx.scratch("dz", xa.N, xa.D, xa.H, xa.W, cin_p)
+        ctx.fwd.append(self.forward)
+        ctx.bwd.append(self.backward)
+
+    # ---- bound after Ctx.finalize()
+    def bind(self):
+        ctx = self.ctx
+        esz = ctx.Wc.element_size()
+        if ctx.dtype == HDU_F32:
+            self.wf_ptr = ctypes.c_void_p(self.kernel.data.data_ptr())  # master IS the f32 forward filter
+        else:
+            self.wf_ptr = ctypes.c_void_p(ctx.Wc.data_ptr() + self.wf_off * esz)
+        self.wd_ptr = ctypes.c_void_p(ctx.Wc.data_ptr() + self.wd_off * esz) if self.need_dgrad_filter else None
+        x, out = self.x.act, self.out.act
+        pro = (self.bn.a, self.bn.b) if self.bn is not None else None
+        relu = self.bn.relu if self.bn is not None else False
+        self.d_f = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, self.up,
+                                 self.skip.act if self.skip is not None else None, pro, relu,
+                                 self.bias.data if self.bias is not None else None)
+        self.d_f_drop = None
+        if self.dropout > 0:
+            self.d_f_drop = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, self.up,
+                                          self.skip.act if self.skip is not None else None, pro, relu,
+                                          self.bias.data if self.bias is not None else None, False,
+                                          1.0 - self.dropout, self.drop_seed, ctx.seed_dev)
+
+    def prep(self):
+        ctx = self.ctx
+        if ctx.dtype == HDU_F32 and not self.need_dgrad_filter:
+            return
+        wf = None if ctx.dtype == HDU_F32 else ctx.Wc[self.wf_off:self.wf_off + self.kernel.numel]
+        wd = ctx.Wc[self.wd_off:self.wd_off + self.kernel.numel] if self.need_dgrad_filter else None
+        ops.weight_prep(ctx.dtype, self.kernel.data, self.cout_p, self.T, self.cin_p, wf, wd)
+
+    def forward(self):
+        ctx = self.ctx
+        if self.bn is not None:
+            self.bn.fold(self.x)
+        if self.d_f_drop is not None and ctx.learning_phase == 1 and ctx.dropout_enabled:
+            ops.conv_fprop(self.d_f_drop)
+        else:
+            ops.conv_fprop(self.d_f)
+
+    def backward(self):
+        ctx = self.ctx
+        out = self.out
+        if not out.root.needs_grad:
+            return
+        dy = out.grad
+        x = self.x.act
+        if self.trainable:
+            d = ops.conv_desc(x, self.wf_ptr, dy, self.K, self.stride, self.pad, self.up,
+                              self.skip.act if self.skip is not None else None,
+                              (self.bn.a, self.bn.b) if self.bn is not None else None,
+                              self.bn.relu if self.bn is not None else False)
+            ops.conv_wgrad(d, self.kernel.grad)
+            if self.bias is not None:
+                ops.colsum(dy, self.bias.grad, ctx.ws)
+        if not self.need_input_grad:
+            return
+        K, pad = self.K, self.pad
+        De, He, We = x.D << self.up[0], x.H << self.up[1], x.W << self.up[2]
+        direct = self.bn is None and self.up == (0, 0, 0)
+        skip_first = self.skip is not None and self.skip.root.needs_grad and not self.skip.root.written \
+            and self.skip.c0 == 0
+        # where does d(x_eff) go?
+        if direct:
+            tgt, acc = self.x.grad, self.x.grad_mode()
+        elif skip_first:
+            tgt, acc = self.skip.grad, self.skip.grad_mode()
+        else:
+            tgt, acc = self._dxe(), False
+        if self.strided:
+            d = ops.conv_desc(ops.Act(tgt.buf, tgt.off, x.N, x.D, x.H, x.W, x.C, tgt.ld, tgt.dtype), self.wf_ptr, dy,
+                              K, self.stride, pad, accumulate=acc)
+            ops.conv_dgrad_strided(d)
+        else:
+            d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K,
+                              (1, 1, 1), (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)
+            ops.conv_fprop(d)
+        if self.skip is not None and self.skip.root.needs_grad and not skip_first:
+            # generic fallback: add d(x_eff) into an already-written skip gradient
+            ops.upsample_bwd(tgt, self.skip.grad, (0, 0, 0), accumulate=self.skip.grad_mode())
+        if direct:
+            return
+        dz = tgt
+        if self.up != (0, 0, 0):
+            if self.bn is None:
+                ops.upsample_bwd(tgt, self.x.grad, self.up, accumulate=self.x.grad_mode())
+                return
+            dz = self._dz()
+            ops.upsample_bwd(tgt, dz, self.up)
+        if self.bn is not None:
+            self.bn.backward(self.x, dz)
+        else:
+            ops.upsample_bwd(dz, self.x.grad, (0, 0, 0), accumulate=self.x.grad_mode())
+
+
+class StatsOp:
+    """tf.nn.moments of a freshly written tensor / slab, once, shared by every consumer BN."""
+
+    def __init__(self, ctx, var):
+        self.ctx, self.var = ctx, var
+        ctx.need_ws(var.act.M, var.C)
+        var.stats()
+        ctx.fwd.append(self.forward)
+
+    def forward(self):
+        if self.ctx.learning_phase == 1:
+            mean, var = self.var.stats()
+            ops.bn_stats(self.var.act, mean, var, self.ctx.ws)
+
+
+class MaterializeLayer:
+    """z = relu(BN(+Scale)(x)) written out (where the activation feeds a pool / a skip / the HFF add)."""
+
+    def __init__(self, ctx, x, bn):
+        self.ctx, self.x, self.bn = ctx, x, bn
+        a = x.act
+        self.out = ctx.new_var(a.N, a.D, a.H, a.W, a.C)
+        if ctx.grad_enabled:
+            self.out.require_grad()
+        if bn.needs_stats():
+            ctx.need_ws(a.M, a.C)
+        ctx.fwd.append(self.forward)
+        ctx.bwd.append(self.backward)
+
+    def forward(self):
+        self.bn.fold(self.x)
+        ops.affine_act(self.x.act, self.bn.a, self.bn.b, self.bn.relu, self.out.act)
+
+    def backward(self):
+        if self.out.root.needs_grad:
+            self.bn.backward(self.x, self.out.grad)
+
+
+class MaxPoolLayer:
+    """ZeroPadding(1) + MaxPooling 3x3(x3) stride 2 (denseunet.py:169-170, denseunet3d.py:135-136)."""
+
+    def __init__(self, ctx, x, out=None):
+        self.ctx, self.x = ctx, x
+        a = x.act
+        Do = 1 if a.D == 1 else (a.D - 1) // 2 + 1
+        dims = (a.N, Do, (a.H - 1) // 2 + 1, (a.W - 1) // 2 + 1)
+        self.out = out if out is not None else ctx.new_var(*dims, a.C)
+        assert (self.out.act.N, self.out.act.D, self.out.act.H, self.out.act.W) == dims
+        if ctx.grad_enabled:
+            self.out.require_grad()
+        ctx.fwd.append(lambda: ops.maxpool_fwd(self.x.act, self.out.act))
+        ctx.bwd.append(self.backward)
+
+    def backward(self):
+        if self.out.root.needs_grad and self.x.root.needs_grad:
+            ops.maxpool_bwd(self.x.act, self.out.grad, self.x.grad, self.x.grad_mode())
+
+
+class AvgPoolLayer:
+    """AveragePooling 2x2 over (H,W) (denseunet.py:290; 3D: (2,2,1), denseunet3d.py:102)."""
+
+    def __init__(self, ctx, x, out):
+        self.ctx, self.x, self.out = ctx, x, out
+        if ctx.grad_enabled:
+            out.require_grad()
+        ctx.fwd.append(lambda: ops.avgpool_fwd(self.x.act, self.out.act))
+        ctx.bwd.append(self.backward)
+
+    def backward(self):
+        if self.out.root.needs_grad and self.x.root.needs_grad:
+            ops.avgpool_bwd(self.out.grad, self.x.grad, self.x.grad_mode())
+
+
+class LossLayer:
+    """weighted softmax cross-entropy + its gradient (loss.py:5-46) over row ranges of the logits."""
+
+    def __init__(self, ctx, logits, ranges, weights=(0.78, 0.65, 8.57)):
+        self.ctx, self.logits, self.ranges, self.weights = ctx, logits, ranges, weights
+        self.count = sum(m for _, m in ranges)
+        self.labels = torch.zeros(logits.act.M, dtype=torch.uint8, device=ctx.dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=ctx.dev)
+        self.class_count = torch.zeros(3, dtype=torch.float32, device=ctx.dev)
+        self.global_scale = 1.0   # 1/world_size under data parallelism (loss.py:44 takes the mean over ALL towers)
+        ctx.need_ws(1 << 14, 8)
+
+    def set_labels(self, lab_u8_internal):
+        """labels already in internal row order [N*D*H*W]"""
+        lab = np.asarray(lab_u8_internal).reshape(-1)
+        if lab.size != self.labels.numel():
+            raise ValueError("labels: expected %d entries, got %d" % (self.labels.numel(), lab.size))
+        if int(lab.max()) > 2 or int(lab.min()) < 0:
+            raise ValueError("labels must be in {0,1,2} (loss.py:14-21)")
+        self.labels.copy_(torch.from_numpy(lab.astype(np.uint8)).to(self.ctx.dev))
+
+    def run(self, with_grad=True):
+        self.loss_sum.zero_()
+        self.class_count.zero_()
+        dl = None
+        if with_grad:
+            self.logits.root.written = True
+            dl = self.logits.grad
+        gs = self.global_scale / float(self.count)
+        for row0, m in self.ranges:
+            ops.wce_loss(self.logits.act, self.labels, row0, m, self.weights, gs, dl, self.loss_sum, self.class_count,
+                         self.ctx.ws)
+
+    def value(self):
+        return float(self.loss_sum.item()) / float(self.count)

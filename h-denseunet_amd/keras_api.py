@@ -1,0 +1,345 @@
+"""The slice of the keras.models.Model surface the reference scripts use, over the engine.
+
+  compile(optimizer=SGD(...), loss=[fn])              K.engine/training.py:570
+  train_on_batch(x, y) / fit_generator(...)           K.engine/training.py:1715 / :1831
+  predict(x, batch_size, verbose)                     K.engine/training.py:1659
+  load_weights / save_weights / save                  K.engine/topology.py:2590 / :2555 (npz container: h5py is
+                                                      not available in this image; same layer names and per-layer
+                                                      weight order as Keras' HDF5 groups)
+  get_weights / set_weights, .inputs/.outputs shapes, summary()
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine import Ctx, LossLayer
+from .lib import HDU_BF16, HDU_F32
+from . import models as _m
+
+
+class SGD:
+    """K.optimizers.py:137-186 (Nesterov momentum form; `decay` as in :160-163)."""
+
+    def __init__(self, lr=0.01, momentum=0.0, decay=0.0, nesterov=False, **kw):
+        if not nesterov:
+            raise NotImplementedError("the reference trains with SGD(nesterov=True) (train_2ddense.py:181); only that form is built")
+        self.lr, self.momentum, self.decay, self.nesterov = float(lr), float(momentum), float(decay), True
+        self.iterations = 0
+
+
+def weighted_crossentropy(y_true, y_pred):          # loss.py:5 -- marker object: the kernel computes it
+    raise RuntimeError("marker function: pass it to Model.compile(loss=[...]); the HIP loss kernel computes it")
+
+
+def weighted_crossentropy_2ddense(y_true, y_pred):  # loss.py:27
+    raise RuntimeError("marker function: pass it to Model.compile(loss=[...]); the HIP loss kernel computes it")
+
+
+class History:
+    def __init__(self):
+        self.history = {"loss": []}
+
+
+class Model:
+    def __init__(self, kind, args_b, input_size, input_cols=None, dtype="bf16", variant=None, name=None,
+                 nb_layers2d=(6, 12, 36, 24), nb_layers3d=(3, 4, 12, 8), seed=4321):
+        self.kind = kind                  # "2d" | "hybrid"
+        self.name = name
+        self.dtype = HDU_BF16 if dtype in ("bf16", HDU_BF16) else HDU_F32
+        self.variant = variant
+        ctx = self.ctx = Ctx(self.dtype, None)
+        dt = self.dtype
+        if kind == "2d":
+            N, H, W = args_b, input_size, input_size
+            self.input_shape = (N, H, W, 3)
+            self.x_stage = torch.zeros(N * H * W * 3, dtype=torch.float32, device=ctx.dev)
+            self.x_in = ctx.new_var(N, 1, H, W, ops.cpad(3, dt))
+            ctx.fwd.append(lambda: ops.cast_pad(self.x_stage, N * H * W, 3, self.x_in.act))
+            r = _m.build_dense_unet_2d(ctx, self.x_in, variant=variant, nb_layers=nb_layers2d)
+            self.logits = r["logits"]
+            self.loss_layer = LossLayer(ctx, self.logits, [(0, N * H * W)])
+            self.output_shape = (N, H, W, 3)
+        elif kind == "hybrid":
+            if args_b != 1:
+                raise ValueError("the hybrid nets index the batch axis as the slice index: b must be 1 "
+                                 "(hybridnet.py:359-364,400-406)")
+            H = W = input_size
+            D = input_cols
+            self.input_shape = (1, H, W, D, 1)
+            self.vol = torch.zeros(D * H * W, dtype=torch.float32, device=ctx.dev)
+            self.logits = _m.build_hybrid(ctx, self.vol, D, H, W, variant=variant, nb_layers2d=nb_layers2d,
+                                          nb_layers3d=nb_layers3d)
+            # loss.py:6-7 hard-codes depth slices 1:7
+            hi = min(7, D)
+            self.loss_layer = LossLayer(ctx, self.logits, [(1 * H * W, (hi - 1) * H * W)])
+            self.output_shape = (1, H, W, D, 3)
+        else:
+            raise ValueError(kind)
+        self.logits.require_grad()
+        ctx.finalize(seed)
+        self.out_stage = torch.zeros(self.logits.act.M * 3, dtype=torch.float32, device=ctx.dev)
+        self.optimizer = None
+        self.world_size = 1
+        self._graph = None
+        self._allreduce = None
+        self.inputs = [self.input_shape]
+        self.outputs = [self.output_shape]
+        self.stop_training = False
+
+    # ------------------------------------------------------------------ boundary layout conversion
+    def _upload_x(self, x):
+        x = torch.as_tensor(np.asarray(x, dtype=np.float32)) if not torch.is_tensor(x) else x.float()
+        if tuple(x.shape) != tuple(self.input_shape):
+            raise ValueError("expected input of shape %s, got %s" % (self.input_shape, tuple(x.shape)))
+        if self.kind == "2d":
+            self.x_stage.copy_(x.reshape(-1).to(self.ctx.dev), non_blocking=True)
+        else:  # (1,H,W,D,1) -> depth-major [D][H][W]
+            self.vol.copy_(x[0, :, :, :, 0].permute(2, 0, 1).contiguous().reshape(-1).to(self.ctx.dev))
+
+    def _labels_internal(self, y):
+        y = np.asarray(y)
+        if self.kind == "2d":
+            want = self.input_shape[:3] + (1,)
+            if tuple(y.shape) != want:
+                raise ValueError("expected labels of shape %s, got %s" % (want, tuple(y.shape)))
+            return y.reshape(-1)
+        want = self.input_shape
+        if tuple(y.shape) != want:
+            raise ValueError("expected labels of shape %s, got %s" % (want, tuple(y.shape)))
+        return np.ascontiguousarray(y[0, :, :, :, 0].transpose(2, 0, 1)).reshape(-1)
+
+    def _download_logits(self):
+        a = self.logits.act
+        ops.cast_out(a, 3, self.out_stage)
+        o = self.out_stage.reshape(a.N, a.D, a.H, a.W, 3)
+        if self.kind == "2d":
+            return o[:, 0]
+        return o.permute(0, 2, 3, 1, 4)   # (1,D,H,W,3) -> (1,H,W,D,3)
+
+    # ------------------------------------------------------------------ Keras surface
+    def compile(self, optimizer, loss=None, **kw):
+        if not isinstance(optimizer, SGD):
+            raise TypeError("optimizer must be SGD (the reference uses SGD(lr=1e-3, momentum=0.9, nesterov=True))")
+        self.optimizer = optimizer
+        fns = loss if isinstance(loss, (list, tuple)) else [loss]
+        for fn in fns:
+            if fn is not None and getattr(fn, "__name__", "") not in ("weighted_crossentropy", "weighted_crossentropy_2ddense"):
+                raise ValueError("loss must be loss.weighted_crossentropy / weighted_crossentropy_2ddense")
+
+    def set_data_parallel(self, world_size, allreduce):
+        """one process per GPU: `allreduce(flat_grad_tensor)` sums gradients over ranks (RCCL); the loss of the
+        merged batch is a mean over ALL towers (multi_gpu.py:65-68 + loss.py:44)."""
+        self.world_size = world_size
+        self._allreduce = allreduce
+        self.loss_layer.global_scale = 1.0 / world_size
+
+    def _step_device(self):
+        ctx = self.ctx
+        ctx.learning_phase = 1
+        ctx.seed_dev.add_(1)
+        ctx.prep_weights()
+        ctx.run_forward()
+        ctx.G[:ctx.n_trainable].zero_()
+        self.loss_layer.run(True)
+        ctx.run_backward()
+
+    def _step_update(self):
+        ctx, opt = self.ctx, self.optimizer
+        lr = opt.lr
+        if opt.decay > 0:
+            lr = lr * (1.0 / (1.0 + opt.decay * opt.iterations))
+        ops.sgd_nesterov(ctx.P[:ctx.n_trainable], ctx.V[:ctx.n_trainable], ctx.G[:ctx.n_trainable], lr, opt.momentum)
+        opt.iterations += 1
+
+    def train_step_resident(self):
+        """one fwd+bwd+SGD step on the inputs / labels already resident in HBM (what bench.py times)."""
+        if self.optimizer is None:
+            raise RuntimeError("compile() the model first")
+        if self._graph is not None:
+            self._graph.replay()
+            self.optimizer.iterations += 1
+            return
+        self._step_device()
+        if self._allreduce is not None:
+            self._allreduce(self.ctx.G[:self.ctx.n_trainable])
+        self._step_update()
+
+    def capture_graph(self, warmup=2):
+        """capture the whole step (incl. the RCCL all-reduce when data-parallel) into one hipGraph"""
+        if self.optimizer is None:
+            raise RuntimeError("compile() the model first")
+        if self.optimizer.decay > 0:
+            raise RuntimeError("graph capture freezes the learning rate; decay>0 is not supported with it")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.train_step_resident()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_device()
+            if self._allreduce is not None:
+                self._allreduce(self.ctx.G[:self.ctx.n_trainable])
+            self._step_update()
+            self.optimizer.iterations -= 1
+        self._graph = g
+
+    def train_on_batch(self, x, y, **kw):
+        self._upload_x(x)
+        self.loss_layer.set_labels(self._labels_internal(y))
+        self.train_step_resident()
+        return self.loss_value()
+
+    def loss_value(self):
+        """loss of the last step (mean over the global batch under data parallelism)"""
+        v = self.loss_layer.loss_sum.clone()
+        if self._allreduce is not None:
+            self._allreduce(v)
+        return float(v.item()) / float(self.loss_layer.count * self.world_size)
+
+    def predict(self, x, batch_size=None, verbose=0):
+        """forward with learning_phase=0: moving BN statistics everywhere, dropout off."""
+        ctx = self.ctx
+        self._upload_x(x)
+        ctx.learning_phase = 0
+        try:
+            ctx.prep_weights()
+            ctx.run_forward()
+        finally:
+            ctx.learning_phase = 1
+        return self._download_logits().cpu().numpy()
+
+    def forward_train_mode(self, x):
+        """logits of the training-phase forward (batch statistics), without touching weights; moving statistics
+        ARE updated exactly as in a training step.  Used by the parity tests."""
+        self._upload_x(x)
+        self.ctx.learning_phase = 1
+        self.ctx.prep_weights()
+        self.ctx.run_forward()
+        return self._download_logits().cpu().numpy()
+
+    def __call__(self, x):
+        return self.predict(x)
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, max_queue_size=10,
+                      workers=1, use_multiprocessing=False, **kw):
+        hist = History()
+        callbacks = callbacks or []
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+        for epoch in range(epochs):
+            losses = []
+            for _ in range(int(steps_per_epoch)):
+                x, y = next(generator)
+                losses.append(self.train_on_batch(x, y))
+            logs = {"loss": float(np.mean(losses))}
+            hist.history["loss"].append(logs["loss"])
+            if verbose:
+                print("Epoch %d/%d - loss: %.4f" % (epoch + 1, epochs, logs["loss"]))
+            for cb in callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        return hist
+
+    # ------------------------------------------------------------------ weights
+    def layer_names(self):
+        return list(self.ctx.by_layer.keys())
+
+    def get_weights_dict(self):
+        return OrderedDict((n, self.ctx.get_layer_weights(n)) for n in self.ctx.by_layer)
+
+    def set_weights_dict(self, d, strict=True):
+        for n, arrs in d.items():
+            if n not in self.ctx.by_layer:
+                if strict:
+                    raise ValueError("no layer named %r in model %s" % (n, self.name))
+                continue
+            self.ctx.set_layer_weights(n, arrs)
+
+    def get_grads_dict(self):
+        return OrderedDict((n, self.ctx.get_layer_grads(n)) for n in self.ctx.by_layer)
+
+    def save_weights(self, filepath, overwrite=True):
+        flat = {}
+        for n, arrs in self.get_weights_dict().items():
+            for i, a in enumerate(arrs):
+                flat["%s/%d" % (n, i)] = a
+        flat["__model_name__"] = np.array(self.name or "")
+        with open(filepath, "wb") as f:
+            np.savez(f, **flat)
+
+    save = save_weights
+
+    def load_weights(self, filepath, by_name=False, by_gpu=False, two_model=False, by_flag=False):
+        """topology.py:2590-2640.  by_name (and the author's by_gpu / two_model loaders, which select an HDF5 group
+        and then match by layer name) skip layers absent from the file; the default requires every layer."""
+        z = np.load(filepath, allow_pickle=False)
+        groups = OrderedDict()
+        for k in z.files:
+            if k == "__model_name__":
+                continue
+            n, i = k.rsplit("/", 1)
+            groups.setdefault(n, {})[int(i)] = z[k]
+        d = OrderedDict((n, [g[i] for i in sorted(g)]) for n, g in groups.items())
+        lenient = by_name or by_gpu or two_model
+        if not lenient:
+            missing = [n for n in self.ctx.by_layer if n not in d]
+            if missing:
+                raise ValueError("weights file lacks layers: %s..." % missing[:5])
+        self.set_weights_dict(d, strict=not lenient)
+
+    def count_params(self):
+        return int(sum(int(np.prod(p.keras_shape)) for p in self.ctx.params))
+
+    def summary(self):
+        print("Model %s (%s, %s)" % (self.name, self.kind, "bf16" if self.dtype == HDU_BF16 else "f32"))
+        for n, ps in self.ctx.by_layer.items():
+            print("  %-28s %s" % (n, [p.keras_shape for p in ps]))
+        print("Total params: %d" % self.count_params())
+
+
+class ModelCheckpoint:
+    """K.callbacks.py:335-432 subset: save every `period` epochs to filepath.format(epoch=, **logs)."""
+
+    def __init__(self, filepath, monitor="loss", verbose=0, save_best_only=False, save_weights_only=False, mode="min",
+                 period=1):
+        self.filepath, self.monitor, self.verbose, self.save_best_only, self.period = filepath, monitor, verbose, save_best_only, period
+        self.best = np.inf
+        self.model = None
+        self.epochs_since = 0
+
+    def set_model(self, model):
+        self.model = model
+
+    def on_epoch_end(self, epoch, logs=None):
+        logs = logs or {}
+        self.epochs_since += 1
+        if self.epochs_since < self.period:
+            return
+        self.epochs_since = 0
+        cur = logs.get(self.monitor, np.inf)
+        if self.save_best_only and not cur < self.best:
+            return
+        self.best = min(self.best, cur)
+        path = self.filepath.format(epoch=epoch + 1, **logs)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        self.model.save(path)
+
+
+def make_parallel(model, gpu_count, mini_batch=None):
+    """K.utils2/multi_gpu.py:7-69 builds in-graph towers in ONE process.  The MI355X design is one process per GPU
+    (launched by torch.distributed.run): inside such a process this binds the model to the RCCL gradient all-reduce
+    and returns it; with gpu_count <= 1 it is the identity (the reference's gpu_count=0 case, train_2ddense.py:180)."""
+    from . import parallel
+    if gpu_count is None or gpu_count <= 1:
+        return model
+    parallel.attach_data_parallel(model, expected_world=gpu_count)
+    return model

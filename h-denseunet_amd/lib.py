@@ -37,6 +37,7 @@ class ConvDesc(ctypes.Structure):
         ("accumulate", c_int),
         ("drop_keep", c_f),
         ("drop_seed", c_u32),
+        ("drop_seed_dev", c_p),
     ]
 
 
@@ -56,7 +57,7 @@ _SIGS = {
     "hdu_bn_bwd_coef": (c_int, [c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                 c_p, c_p]),
     "hdu_bn_bwd_apply": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
-                                 c_p, c_i64, c_int, c_f, c_u32, c_p]),
+                                 c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
     "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),

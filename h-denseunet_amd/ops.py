@@ -87,7 +87,7 @@ class Act:
 
 
 def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
-              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0):
+              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None):
     """x: Act (stored input), y: Act (output), K=(KD,KH,KW)."""
     d = ConvDesc()
     d.dtype = x.dtype
@@ -108,6 +108,8 @@ def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), ski
     d.accumulate = 1 if accumulate else 0
     d.drop_keep = drop_keep
     d.drop_seed = drop_seed
+    if drop_seed_dev is not None:
+        d.drop_seed_dev = ctypes.c_void_p(drop_seed_dev.data_ptr())
     return d
 
 
@@ -170,10 +172,13 @@ def bn_bwd_coef(C, M, batch_stats, s1, s2, gamma, beta, sgamma, rstd, k1, k2, k3
                                    fptr(dsgamma), fptr(dsbeta), stream()), "hdu_bn_bwd_coef")
 
 
-def bn_bwd_apply(dz, x, a, b, relu, mean, k1, k2, k3, dx, accumulate=False, drop_keep=1.0, drop_seed=0):
+def bn_bwd_apply(dz, x, a, b, relu, mean, k1, k2, k3, dx, accumulate=False, drop_keep=1.0, drop_seed=0,
+                 drop_seed_dev=None):
     check(_l.get().hdu_bn_bwd_apply(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
                                     fptr(mean), fptr(k1), fptr(k2), fptr(k3), dx.ptr, dx.ld, 1 if accumulate else 0,
-                                    drop_keep, drop_seed, stream()), "hdu_bn_bwd_apply")
+                                    drop_keep, drop_seed,
+                                    ctypes.c_void_p(drop_seed_dev.data_ptr()) if drop_seed_dev is not None else None,
+                                    stream()), "hdu_bn_bwd_apply")
 
 
 def affine_act(x, a, b, relu, z):

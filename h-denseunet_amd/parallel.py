@@ -1,0 +1,58 @@
+"""Data parallelism: one process per GPU, gradients summed with ONE flat RCCL all-reduce over xGMI.
+
+Replaces K.utils2/multi_gpu.py:7-69 (in-graph towers: batch sliced per tower, outputs concatenated on the CPU,
+gradient summation implicit in tf.gradients, BN statistics per tower).  Semantics kept: every rank runs the same
+weights on its own mini-batch with LOCAL BN statistics; the loss is the mean over the merged batch (loss.py:44),
+so each rank scales its gradient by 1/world_size before the sum.  All trainable parameters live in one flat float32
+buffer (engine.Ctx.G), so the exchange is a single large collective (ring all-reduce is per-link bound on xGMI:
+fewer, larger messages).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend=None):
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def attach_data_parallel(model, expected_world=None):
+    rank, world = init_process_group_from_env()
+    if expected_world is not None and world != expected_world and world != 1:
+        raise RuntimeError("make_parallel asked for %d GPUs but WORLD_SIZE=%d" % (expected_world, world))
+    if world == 1:
+        return model
+
+    def allreduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    model.set_data_parallel(world, allreduce)
+    broadcast_parameters(model)
+    return model
+
+
+def broadcast_parameters(model, src=0):
+    """identical initial weights on every rank (the towers of multi_gpu.py share one set of variables)"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(model.ctx.P, src=src)
+        dist.broadcast(model.ctx.V, src=src)
+
+
+def shard_depth(D, world, rank):
+    """[begin, end) of the depth planes owned by `rank` when one volume is sharded on the depth axis"""
+    per = D // world
+    return rank * per, (rank + 1) * per if rank < world - 1 else D

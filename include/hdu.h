@@ -73,6 +73,8 @@ typedef struct hdu_conv_desc {
   int accumulate;                  /* y += result instead of y = result */
   float drop_keep;                 /* 1.0 = no dropout; else keep-probability */
   uint32_t drop_seed;
+  const uint32_t* drop_seed_dev;   /* optional device word added to drop_seed (lets a captured hipGraph
+                                      draw a fresh mask per replay) */
 } hdu_conv_desc;
 
 /* forward conv; also the data-gradient of every stride-1 conv (caller passes dy as x and the
@@ -127,7 +129,7 @@ int hdu_bn_bwd_coef(int C, int64_t M, int batch_stats, const float* s1, const fl
 int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
                      const float* a, const float* b, int relu, const float* mean, const float* k1,
                      const float* k2, const float* k3, void* dx, int64_t lddx, int accumulate, float drop_keep,
-                     uint32_t drop_seed, void* stream);
+                     uint32_t drop_seed, const uint32_t* drop_seed_dev, void* stream);
 
 /* materialise z = relu?(a*x+b) (needed where the activation is consumed by pooling / as a skip / HFF operand) */
 int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, const float* a, const float* b,

@@ -292,7 +292,9 @@ def dense_unet_2d(P, img, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 
     box.append(x)
 
     skips = variant == "denseunet"
-    dec = [(768, "0"), (384, "1"), (96, "2"), (96, "3"), (64, "4")]
+    # decoder widths equal the skip widths (768, 384, 96 for the real DenseNet-161 blocks, denseunet.py:192-204);
+    # reduced-depth test nets keep that relation
+    dec = [(box[2].shape[-1], "0"), (box[1].shape[-1], "1"), (box[0].shape[-1], "2"), (96, "3"), (64, "4")]
     cur = x
     for i, (f, tag) in enumerate(dec):
         up = upsample_nearest(cur, (2, 2))

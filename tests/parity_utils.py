@@ -1,0 +1,76 @@
+"""Shared helpers of the model-level parity tests: build the oracle + the product with identical (perturbed)
+weights, run one step on both, compare.  TEST INFRASTRUCTURE (imports oracle/)."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import torch_ref as R  # noqa: E402
+
+
+def pkg(mod=None):
+    return importlib.import_module("h-denseunet_amd" + ("." + mod if mod else ""))
+
+
+def make_args(b, size, cols=None):
+    return types.SimpleNamespace(b=b, input_size=size, input_cols=cols)
+
+
+def oracle_forward_fn(kind, variant, nb2d, nb3d):
+    if kind == "2d":
+        return lambda P, x: R.dense_unet_2d(P, x, variant=variant, nb_layers=nb2d)[1]
+    return lambda P, x: R.hybrid_net(P, x, variant=variant, nb_layers2d=nb2d, nb_layers3d=nb3d)
+
+
+def synthetic_batch(kind, b, size, cols, seed=1234):
+    """2D: b slices of one phantom volume, 3 adjacent slices as channels (train_2ddense.py:62-66);
+    hybrid: one (1,H,W,D,1) volume.  Labels int in {0,1,2}."""
+    if kind == "2d":
+        vol, lab = R.synthetic_ct((size, size, b + 2), seed)
+        x = np.stack([vol[:, :, k:k + 3] for k in range(b)], 0).astype(np.float32)
+        y = np.stack([lab[:, :, k + 1] for k in range(b)], 0)[..., None]
+        return x, y
+    vol, lab = R.synthetic_ct((size, size, cols), seed)
+    return vol[None, ..., None].astype(np.float32), lab[None, ..., None]
+
+
+def build_pair(kind, variant, b, size, cols, dtype, nb2d, nb3d, seed=4321, odtype=torch.float64):
+    """returns (product model, oracle ParamStore, oracle forward fn) with identical weights"""
+    P = R.ParamStore(seed=seed, dtype=odtype, perturb=True)
+    fwd = oracle_forward_fn(kind, variant, nb2d, nb3d)
+    x, _ = synthetic_batch(kind, b, size, cols)
+    with torch.no_grad():
+        fwd(P, torch.tensor(x, dtype=odtype))   # creates the parameters
+    P.bn_batch_means = {}
+    if kind == "2d":
+        mod = pkg("denseunet" if variant == "denseunet" else "densenet")
+        m = mod.DenseUNet(reduction=0.5, args=make_args(b, size), dtype=dtype, nb_layers=nb2d)
+    elif variant == "3dpart":
+        m = pkg("denseunet3d").denseunet_3d(make_args(b, size, cols), dtype=dtype, nb_layers2d=nb2d, nb_layers3d=nb3d)
+    else:
+        m = pkg("hybridnet").dense_rnn_net(make_args(b, size, cols), dtype=dtype, nb_layers2d=nb2d, nb_layers3d=nb3d)
+    ow = P.numpy()
+    assert list(ow.keys()) == m.layer_names() or set(ow.keys()) == set(m.layer_names()), \
+        "layer inventories differ: %s" % (set(ow.keys()) ^ set(m.layer_names()))
+    m.set_weights_dict(ow)
+    return m, P, fwd
+
+
+def loss_fn_for(kind):
+    return R.weighted_crossentropy_2ddense if kind == "2d" else R.weighted_crossentropy
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def dice_vs_oracle(logits, ref_logits):
+    return R.dice_per_class(np.argmax(logits, -1), np.argmax(ref_logits, -1))
