@@ -607,27 +607,33 @@ static void launch_igemm(const ConvK& k, hipStream_t s) {
   HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
 }
 
-template <typename T>
-static void dispatch_igemm(const ConvK& k, hipStream_t s) {
-  // pick the N tile that wastes the fewest padded output channels; ties -> widest tile
+// tile choice: the N tile that wastes the fewest padded output channels (ties -> widest); 64-row tiles for small images
+static void choose_igemm(const ConvK& k, int* bm, int* bn) {
   const int cands[4] = {128, 64, 48, 32};
   int best = 64;
   long long best_cost = -1;
   for (int i = 0; i < 4; ++i) {
-    const int bn = cands[i];
-    if (bn == 128 && (k.Cout < 256 || k.M < 4096)) continue;
-    const long long padded = (long long)((k.Cout + bn - 1) / bn) * bn;
-    if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = bn; }
+    const int c = cands[i];
+    if (c == 128 && (k.Cout < 256 || k.M < 4096)) continue;
+    const long long padded = (long long)((k.Cout + c - 1) / c) * c;
+    if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = c; }
   }
-  if (k.M <= 2048 && best != 128) {
-    // small images: 64-row tiles give more workgroups
-    switch (best) {
+  *bn = best;
+  *bm = (k.M <= 2048 && best != 128) ? 64 : 128;
+}
+
+template <typename T>
+static void dispatch_igemm(const ConvK& k, hipStream_t s) {
+  int bm, bn;
+  choose_igemm(k, &bm, &bn);
+  if (bm == 64) {
+    switch (bn) {
       case 64: launch_igemm<T, 64, 64, 2, 2>(k, s); return;
       case 48: launch_igemm<T, 64, 48, 4, 1>(k, s); return;
       default: launch_igemm<T, 64, 32, 2, 2>(k, s); return;
     }
   }
-  switch (best) {
+  switch (bn) {
     case 128: launch_igemm<T, 128, 128, 2, 2>(k, s); return;
     case 64: launch_igemm<T, 128, 64, 4, 1>(k, s); return;
     case 48: launch_igemm<T, 128, 48, 4, 1>(k, s); return;
@@ -660,8 +666,7 @@ static void launch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
   HDU_LAUNCH((conv_wgrad_kernel<T, BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
 }
 
-template <typename T>
-static void dispatch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
+static int choose_wgrad(const ConvK& k) {
   const int cands[3] = {64, 48, 32};
   int best = 64;
   long long best_cost = -1;
@@ -669,6 +674,12 @@ static void dispatch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
     const long long padded = (long long)((k.Cout + cands[i] - 1) / cands[i]) * cands[i];
     if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = cands[i]; }
   }
+  return best;
+}
+
+template <typename T>
+static void dispatch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
+  const int best = choose_wgrad(k);
   if (best == 64) launch_wgrad<T, 64>(k, dw, s);
   else if (best == 48) launch_wgrad<T, 48>(k, dw, s);
   else launch_wgrad<T, 32>(k, dw, s);
@@ -716,4 +727,21 @@ extern "C" int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T
   else
     return hdu_set_error(HDU_ERR_ARG, "weight_prep: bad dtype");
   return hdu_check_launch("weight_prep");
+}
+
+#include <cstdio>
+extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, size_t buflen) {
+  ConvK k;
+  if (int e = fill_convk(d, &k, op == 1)) return e;
+  if (!buf || buflen < 8) return hdu_set_error(HDU_ERR_ARG, "conv_kernel_name: bad buffer");
+  const char* t = d->dtype == HDU_BF16 ? "bf16" : "f32";
+  if (op == 1) {
+    snprintf(buf, buflen, "conv_wgrad_kernel<%s,%d>", t, choose_wgrad(k));
+  } else {
+    int bm, bn;
+    choose_igemm(k, &bm, &bn);
+    const int wm = (bm == 128 && bn == 128) ? 2 : ((bm == 64 && bn != 48) ? 2 : 4);
+    snprintf(buf, buflen, "conv_igemm_kernel<%s,%d,%d,%d,%d>", t, bm, bn, wm, 4 / wm);
+  }
+  return 0;
 }

@@ -48,6 +48,7 @@ _SIGS = {
     "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
+    "hdu_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
     "hdu_weight_prep": (c_int, [c_int, c_p, c_int, c_int, c_int, c_p, c_p, c_p]),
     "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
     "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),

@@ -125,6 +125,12 @@ def conv_dgrad_strided(d):
     check(_l.get().hdu_conv_dgrad_strided(ctypes.byref(d), stream()), "hdu_conv_dgrad_strided")
 
 
+def conv_kernel_name(d, op=0):
+    buf = ctypes.create_string_buffer(96)
+    check(_l.get().hdu_conv_kernel_name(ctypes.byref(d), op, buf, 96), "hdu_conv_kernel_name")
+    return buf.value.decode()
+
+
 def weight_prep(dtype, w_master, Cout, T, Cin, w_f, w_d):
     check(_l.get().hdu_weight_prep(dtype, fptr(w_master), Cout, T, Cin,
                                    ctypes.c_void_p(w_f.data_ptr()) if w_f is not None else None,

@@ -90,6 +90,10 @@ int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream);
  * dx[n,i,c] (+)= sum_{o,k: o*s+k-p=i} dy[n,o,co]*w[co][k][c].  d->x is the output dx, d->y is dy. */
 int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream);
 
+/* name of the kernel template instance the dispatcher launches for this descriptor (op 0 = fprop/dgrad-form,
+ * 1 = wgrad); lets a profiler-side tool group launches exactly like rocprofv3's per-kernel statistics. */
+int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, size_t buflen);
+
 /* master float32 filters [Cout][T][Cin] -> compute-dtype copies: w_f (same layout) and, if w_d != NULL,
  * the data-gradient filter w_d [Cin][T flipped][Cout]. */
 int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, void* w_f, void* w_d, void* stream);

@@ -467,29 +467,6 @@ def predict(P, forward, x):
     return out
 
 
-# --------------------------------------------------------------------------- synthetic CT
-def synthetic_ct(shape_hwd, seed=1234):
-    """Deterministic liver/tumour phantom: float32 volume (H,W,D) after HU clip [-200,250] and mean 48
-    subtraction (preprocessing.py:15-16, train_2ddense.py:32,65), and int labels {0,1,2} of the same geometry."""
-    H, W, D = shape_hwd
-    rng = np.random.default_rng(seed)
-    yy, xx, zz = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), np.linspace(-1, 1, D), indexing="ij")
-    vol = np.full((H, W, D), -200.0)
-    liver = ((yy + 0.1) / 0.62) ** 2 + ((xx - 0.05) / 0.5) ** 2 + (zz / 1.4) ** 2 < 1.0
-    vol[liver] = rng.normal(100.0, 20.0, int(liver.sum()))
-    lab = np.zeros((H, W, D), np.int64)
-    lab[liver] = 1
-    for _ in range(int(rng.integers(1, 4))):
-        cy, cx, cz = rng.uniform(-0.3, 0.2), rng.uniform(-0.2, 0.3), rng.uniform(-0.6, 0.6)
-        r = rng.uniform(0.12, 0.22)
-        tum = ((yy - cy) ** 2 + (xx - cx) ** 2 + ((zz - cz) * 0.6) ** 2 < r * r) & liver
-        vol[tum] = rng.normal(60.0, 15.0, int(tum.sum()))
-        lab[tum] = 2
-    vol += rng.normal(0.0, 10.0, vol.shape)
-    vol = np.clip(vol, -200.0, 250.0) - 48.0
-    return vol.astype(np.float32), lab
-
-
 def dice_per_class(pred_lab, ref_lab, classes=(0, 1, 2)):
     """hard Dice on arg-max labels (evaluation quantity)"""
     out = []

@@ -30,15 +30,7 @@ def oracle_forward_fn(kind, variant, nb2d, nb3d):
 
 
 def synthetic_batch(kind, b, size, cols, seed=1234):
-    """2D: b slices of one phantom volume, 3 adjacent slices as channels (train_2ddense.py:62-66);
-    hybrid: one (1,H,W,D,1) volume.  Labels int in {0,1,2}."""
-    if kind == "2d":
-        vol, lab = R.synthetic_ct((size, size, b + 2), seed)
-        x = np.stack([vol[:, :, k:k + 3] for k in range(b)], 0).astype(np.float32)
-        y = np.stack([lab[:, :, k + 1] for k in range(b)], 0)[..., None]
-        return x, y
-    vol, lab = R.synthetic_ct((size, size, cols), seed)
-    return vol[None, ..., None].astype(np.float32), lab[None, ..., None]
+    return pkg("synth").synthetic_batch(kind, b, size, cols, seed)
 
 
 def build_pair(kind, variant, b, size, cols, dtype, nb2d, nb3d, seed=4321, odtype=torch.float64):

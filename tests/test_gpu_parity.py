@@ -1,0 +1,106 @@
+"""GPU tier: full-size nets through the gfx950 library vs the float32 oracle (reference arithmetic is float32,
+K.backend/common.py:4).  Tolerances are BASELINE.json's: per-voxel logits <= 1e-4 (f32 parity mode), Dice of the
+arg-max labels within 1e-3 of the oracle's (both modes)."""
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as U
+
+pytestmark = pytest.mark.gpu
+
+FULL2D, FULL3D = (6, 12, 36, 24), (3, 4, 12, 8)
+
+
+def _pair(kind, variant, b, size, cols, dtype):
+    m, P, fwd = U.build_pair(kind, variant, b, size, cols, dtype, FULL2D, FULL3D, odtype=torch.float32)
+    m.ctx.dropout_enabled = False
+    return m, P, fwd
+
+
+@pytest.mark.parametrize("kind,variant,b,size,cols", [
+    ("2d", "denseunet", 1, 512, None),          # BASELINE configs[0]: single 512x512 slice
+    ("2d", "densenet", 2, 224, None),
+    ("hybrid", "3dpart", 1, 224, 12),           # configs[2]
+    ("hybrid", "end2end", 1, 224, 12),          # configs[3]
+])
+def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
+    m, P, fwd = _pair(kind, variant, b, size, cols, "f32")
+    x, y = U.synthetic_batch(kind, b, size, cols)
+    xt = torch.tensor(x)
+    ref = U.R.predict(P, fwd, xt).numpy()
+    got = m.predict(x)
+    scale = max(1.0, float(np.abs(ref).max()))
+    e = float(np.abs(got - ref).max())
+    assert e <= 1e-4 * scale, "predict logits: max abs err %.3e (scale %.3g)" % (e, scale)
+    assert min(U.dice_vs_oracle(got, ref)) >= 1 - 1e-3
+    # training-phase forward (batch statistics) + loss
+    ka = U.pkg("keras_api")
+    m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy])
+    ref_loss, ref_grads, ref_logits = U.R.train_step(P, fwd, U.loss_fn_for(kind), xt, torch.tensor(y), {})
+    w_before = m.get_weights_dict()
+    loss = m.train_on_batch(x, y)
+    got_l = m._download_logits().cpu().numpy()
+    rl = ref_logits.numpy()
+    scale = max(1.0, float(np.abs(rl).max()))
+    e = float(np.abs(got_l - rl).max())
+    assert e <= 2e-4 * scale, "train-mode logits: max abs err %.3e (scale %.3g)" % (e, scale)
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
+    assert min(U.dice_vs_oracle(got_l, rl)) >= 1 - 1e-3
+    # gradients: relative L2 error per tensor (max-norm is dominated by single ReLU flips at f32 roundoff)
+    gg = m.get_grads_dict()
+    worst = (0.0, None)
+    for (name, i), g in ref_grads.items():
+        a, r = gg[name][i].astype(np.float64), g.numpy().astype(np.float64)
+        den = np.linalg.norm(r)
+        if den < 1e-12:
+            continue
+        rel = np.linalg.norm(a - r) / den
+        if rel > worst[0]:
+            worst = (rel, (name, i))
+    assert worst[0] < 5e-2, "gradient L2 mismatch: %s" % (worst,)
+    # SGD update direction: updated weights moved by (-lr*g*(1+momentum)) -> compare deltas on the classifier
+    w_after = m.get_weights_dict()
+    last = "dense167classifer" if kind == "2d" else "2d3dclassifer"
+    d_got = w_after[last][0] - w_before[last][0]
+    d_ref = P.numpy()[last][0] - w_before[last][0]
+    assert np.linalg.norm(d_got - d_ref) <= 2e-2 * np.linalg.norm(d_ref) + 1e-9
+
+
+@pytest.mark.parametrize("kind,variant,b,size,cols", [
+    ("2d", "denseunet", 2, 512, None),
+    ("hybrid", "end2end", 1, 224, 12),
+])
+def test_full_dice_parity_bf16(hip_lib, kind, variant, b, size, cols):
+    """bf16 storage / f32 accumulate (the throughput mode): Dice of arg-max labels vs the float32 oracle.
+    Random-init logits are nearly tied between classes, so Dice is evaluated where the oracle's top-2 margin
+    exceeds the bf16 logit resolution; the fraction of such voxels is asserted too."""
+    m, P, fwd = _pair(kind, variant, b, size, cols, "bf16")
+    x, y = U.synthetic_batch(kind, b, size, cols)
+    ref = U.R.predict(P, fwd, torch.tensor(x)).numpy()
+    got = m.predict(x)
+    scale = max(1.0, float(np.abs(ref).max()))
+    e = float(np.abs(got - ref).max())
+    srt = np.sort(ref, -1)
+    margin = srt[..., -1] - srt[..., -2]
+    sure = margin > 0.05 * scale
+    print("bf16 %s: max logit err %.3e (scale %.3g), confident voxels %.1f%%" % (variant, e, scale, 100 * sure.mean()))
+    assert e <= 0.08 * scale
+    gl, rl = np.argmax(got, -1)[sure], np.argmax(ref, -1)[sure]
+    assert min(U.R.dice_per_class(gl, rl)) >= 1 - 1e-3
+    assert (np.argmax(got, -1) == np.argmax(ref, -1)).mean() > 0.97
+
+
+def test_train_loss_decreases_bf16(hip_lib):
+    """a few SGD steps on one synthetic batch reduce the loss (optimizers_test.py:25-40 analogue) -- with dropout on
+    and through a captured hipGraph, i.e. exactly the path bench.py times."""
+    ka = U.pkg("keras_api")
+    m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(2, 128), dtype="bf16", nb_layers=(2, 3, 4, 2))
+    m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy_2ddense])
+    x, y = U.synthetic_batch("2d", 2, 128, None)
+    l0 = m.train_on_batch(x, y)
+    m.capture_graph(warmup=1)
+    for _ in range(30):
+        m.train_step_resident()
+    l1 = m.loss_value()
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < 0.7 * l0, (l0, l1)
