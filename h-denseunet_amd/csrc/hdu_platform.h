@@ -15,8 +15,10 @@
 #define HDU_LAUNCH_OK() 0
 #else
 #include <hip/hip_runtime.h>
+// hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind so that
+// hdu_check_launch() reports THIS launch only
 #define HDU_LAUNCH(kern, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
 #define HDU_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define HDU_LANE() ((int)(threadIdx.x & 63))
 #define HDU_LAUNCH_OK() ((int)hipGetLastError())

@@ -370,8 +370,8 @@ class ConvLayer:
         self.need_dgrad_filter = need_input_grad and not self.strided
         self.wf_off = self.wd_off = None
         ctx.convs.append(self)
-        if bn is not None and bn.needs_stats():
-            ctx.need_ws(xa.M, xa.C)
+        if bn is not None:
+            ctx.need_ws(xa.M, xa.C)      # statistics and / or the backward reductions over the input
         ctx.need_ws(out.act.M, cout_p)
         if need_input_grad:
             if bn is not None or up != (0, 0, 0):
@@ -499,8 +499,7 @@ class MaterializeLayer:
         self.out = ctx.new_var(a.N, a.D, a.H, a.W, a.C)
         if ctx.grad_enabled:
             self.out.require_grad()
-        if bn.needs_stats():
-            ctx.need_ws(a.M, a.C)
+        ctx.need_ws(a.M, a.C)
         ctx.fwd.append(self.forward)
         ctx.bwd.append(self.backward)
 

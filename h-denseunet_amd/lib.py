@@ -97,6 +97,9 @@ def emulator_library_path():
 
 
 def _bind(path):
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be resident BEFORE libhdu.so is loaded so
+    # that both share ONE runtime instance (otherwise our launches hit a second, device-less runtime).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

@@ -50,11 +50,12 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
     # gradients: relative L2 error per tensor (max-norm is dominated by single ReLU flips at f32 roundoff)
     gg = m.get_grads_dict()
     worst = (0.0, None)
+    rms_max = max(float(np.sqrt((g.numpy().astype(np.float64) ** 2).mean())) for g in ref_grads.values())
     for (name, i), g in ref_grads.items():
         a, r = gg[name][i].astype(np.float64), g.numpy().astype(np.float64)
-        den = np.linalg.norm(r)
-        if den < 1e-12:
-            continue
+        # floor: gradients that are mathematically zero (e.g. the bias of a conv feeding a batch-stat BN) are
+        # roundoff noise in both implementations
+        den = max(np.linalg.norm(r), 1e-3 * rms_max * np.sqrt(r.size))
         rel = np.linalg.norm(a - r) / den
         if rel > worst[0]:
             worst = (rel, (name, i))
@@ -95,7 +96,7 @@ def test_train_loss_decreases_bf16(hip_lib):
     """a few SGD steps on one synthetic batch reduce the loss (optimizers_test.py:25-40 analogue) -- with dropout on
     and through a captured hipGraph, i.e. exactly the path bench.py times."""
     ka = U.pkg("keras_api")
-    m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(2, 128), dtype="bf16", nb_layers=(2, 3, 4, 2))
+    m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(2, 128), dtype="bf16", nb_layers=(2, 2, 2, 2))
     m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy_2ddense])
     x, y = U.synthetic_batch("2d", 2, 128, None)
     l0 = m.train_on_batch(x, y)
