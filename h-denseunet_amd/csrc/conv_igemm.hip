@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   const bool has_skip = p.skip != nullptr;
 
   // ---- per-row (output pixel) state, fixed for the whole K loop ----
-  int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT];
+  // rpix = pixel index of the tap-(0,0,0) input position (may be "negative"; only used when in bounds)
+  const bool ups = (p.ud | p.uh | p.uw) != 0;
+  int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const long long m = m0 + r0 + i * 32;
@@ -59,11 +61,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
       rid[i] = od * p.sd - p.pd;
       rih[i] = oh * p.sh - p.ph;
       riw[i] = ow * p.sw - p.pw;
+      rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
     } else {
       rn[i] = 0;
       rid[i] = -(1 << 28);
       rih[i] = -(1 << 28);
       riw[i] = -(1 << 28);
+      rpix[i] = 0;
     }
   }
 
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   auto load_tile = [&]() {
     okmask = 0;
     const bool kvalid = kd < p.KD;
+    const int tapoff = (kd * p.He + kh) * p.We + kw;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
@@ -94,13 +99,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
       u32x4 v = {0u, 0u, 0u, 0u};
       u32x4 s = {0u, 0u, 0u, 0u};
       if (ok) {
-        const long long src =
-            (((long long)rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw);
-        v = *(const u32x4*)(xp + src * p.ldx + c);
-        if (has_skip) {
-          const long long e = (((long long)rn[i] * p.De + id) * p.He + ih) * p.We + iw;
-          s = *(const u32x4*)(sp + e * p.ldskip + c);
-        }
+        const int e = rpix[i] + tapoff;   // effective-resolution pixel index
+        const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw) : e;
+        v = *(const u32x4*)(xp + (long long)src * p.ldx + c);
+        if (has_skip) s = *(const u32x4*)(sp + (long long)e * p.ldskip + c);
         okmask |= 1u << i;
       }
       areg[i] = v;
@@ -473,6 +475,237 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 }
 
 // =====================================================================================
+// bf16 filter gradient, transpose-read form.  Same GEMM view as conv_wgrad_kernel, but the staging pass stores the
+// channel-contiguous 16-byte chunks as they come ([pixel][channel] LDS tiles, one ds_write_b128 per chunk) and the
+// MFMA operands (8 consecutive pixels of one channel per lane) are produced by ds_read_b64_tr_b16.
+// 32-byte segments of each tile row are XOR-swizzled with the pixel index so that the 8 rows a 32-lane pass touches
+// fall on distinct banks.
+template <int ROWB>
+__device__ __forceinline__ int tr_off(int px, int byte_col) {
+  int seg = byte_col >> 5;
+  if (ROWB == 256) seg ^= (px & 3) | ((px >> 1) & 4);
+  else seg ^= ((px >> 1) & 1) | (((px >> 3) & 1) << 1);
+  return px * ROWB + (seg << 5) + (byte_col & 31);
+}
+
+template <int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+  typedef bf16_t T;
+  constexpr int CH = 8;
+  constexpr int PX = 64;              // pixels per step (two MFMA k-groups of 32)
+  constexpr int BKC = 128;            // k columns per workgroup
+  constexpr int XROWB = BKC * 2;      // 256 B per pixel row of the x tile
+  constexpr int DROWB = 128;          // dy tile row: up to 64 output channels
+  constexpr int NDC = BCO / CH;
+  constexpr int D_IT = (PX * NDC + 255) / 256;
+  constexpr int TM = BCO / 16;
+  constexpr int TN = 2;
+  constexpr int STAGE = PX * (XROWB + DROWB);
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ sp = (const T*)p.skip;
+  const T* __restrict__ dyp = (const T*)p.y;
+  const bool has_pro = p.pro_a != nullptr;
+  const bool has_skip = p.skip != nullptr;
+  const bool ups = (p.ud | p.uh | p.uw) != 0;
+
+  const int kcol0 = blockIdx.x * BKC;
+  const int co0 = blockIdx.y * BCO;
+  const long long m_begin = (long long)blockIdx.z * rows_per_split;
+  long long m_end = m_begin + rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  const int kcc = tid & 15;
+  const int pxl = tid >> 4;           // 0..15; pixel slots pxl + 16*i
+  const int kk = kcol0 + kcc * CH;
+  const bool kvalid = kk < p.Ktot;
+  int c = 0, kd = 0, kh = 0, kw = 0;
+  if (kvalid) {
+    const int tap = kk / p.Cin;
+    c = kk - tap * p.Cin;
+    kw = tap % p.KW;
+    const int t = tap / p.KW;
+    kh = t % p.KH;
+    kd = t / p.KH;
+  }
+  float pa[CH], pb[CH];
+  if (has_pro && kvalid) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { pa[j] = p.pro_a[c + j]; pb[j] = p.pro_b[c + j]; }
+  }
+  int sn[4], sod[4], soh[4], sow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m_begin + pxl + i * 16;
+    const int ow = (int)(m % p.Wo);
+    long long t = m / p.Wo;
+    const int oh = (int)(t % p.Ho);
+    t /= p.Ho;
+    sod[i] = (int)(t % p.Do);
+    sn[i] = (int)(t / p.Do);
+    soh[i] = oh;
+    sow[i] = ow;
+  }
+
+  u32x4 xreg[4], sreg[4], dreg[D_IT];
+  unsigned okmask = 0;
+
+  auto load_tile = [&](long long mt) {
+    okmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = mt + pxl + i * 16;
+      const int id = sod[i] * p.sd - p.pd + kd, ih = soh[i] * p.sh - p.ph + kh, iw = sow[i] * p.sw - p.pw + kw;
+      const bool ok = kvalid && m < m_end && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                      (unsigned)iw < (unsigned)p.We;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      u32x4 s = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const int e = ((sn[i] * p.De + id) * p.He + ih) * p.We + iw;
+        const int src = ups ? ((sn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw) : e;
+        v = *(const u32x4*)(xp + (long long)src * p.ldx + c);
+        if (has_skip) s = *(const u32x4*)(sp + (long long)e * p.ldskip + c);
+        okmask |= 1u << i;
+      }
+      xreg[i] = v;
+      sreg[i] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < D_IT; ++j) {
+      const int q = tid + j * 256;
+      const int dcc = q % NDC;
+      const int dpx = q / NDC;
+      const long long m = mt + dpx;
+      const int co = co0 + dcc * CH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (dpx < PX && m < m_end && co < p.Cout) v = *(const u32x4*)(dyp + m * p.ldy + co);
+      dreg[j] = v;
+    }
+  };
+
+  auto advance_pixels = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sow[i] += PX;
+      while (sow[i] >= p.Wo) {
+        sow[i] -= p.Wo;
+        if (++soh[i] == p.Ho) {
+          soh[i] = 0;
+          if (++sod[i] == p.Do) {
+            sod[i] = 0;
+            ++sn[i];
+          }
+        }
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* Xt = smem + buf * STAGE;       // [PX][BKC] x_eff
+    char* Dt = Xt + PX * XROWB;          // [PX][<=64] dy
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4 v = xreg[i];
+      if ((has_pro || has_skip) && ((okmask >> i) & 1u)) {
+        float f[CH];
+        Chunk<T>::unpack(v, f);
+        if (has_pro) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            f[j] = pa[j] * f[j] + pb[j];
+            if (p.pro_relu) f[j] = f[j] > 0.f ? f[j] : 0.f;
+          }
+        }
+        if (has_skip) {
+          float g[CH];
+          Chunk<T>::unpack(sreg[i], g);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) f[j] += g[j];
+        }
+        v = Chunk<T>::pack(f);
+      }
+      const int px = pxl + i * 16;
+      *(u32x4*)(Xt + tr_off<XROWB>(px, kcc * 16)) = v;
+    }
+#pragma unroll
+    for (int jj = 0; jj < D_IT; ++jj) {
+      const int q = tid + jj * 256;
+      const int dcc = q % NDC;
+      const int dpx = q / NDC;
+      if (dpx < PX) *(u32x4*)(Dt + tr_off<DROWB>(dpx, dcc * 16)) = dreg[jj];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (int)((m_end - m_begin + PX - 1) / PX);
+  if (nsteps > 0) {
+    load_tile(m_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int li = lane & 15, lg = lane >> 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    const bool more = st + 1 < nsteps;
+    if (more) {
+      advance_pixels();
+      load_tile(m_begin + (long long)(st + 1) * PX);
+    }
+    {
+      const char* Xt = smem + buf * STAGE;
+      const char* Dt = Xt + PX * XROWB;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int prow = kg * 32 + lg * 8 + (li >> 2);   // pixel row this lane addresses (first half)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int bc = (i * 16 + (li & 3) * 4) * 2;
+          const u32x2 lo = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow, bc));
+          const u32x2 hi = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow + 4, bc));
+          af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int bc = (wave * 32 + j * 16 + (li & 3) * 4) * 2;
+          const u32x2 lo = hdu_lds_tr16_b64(Xt + tr_off<XROWB>(prow, bc));
+          const u32x2 hi = hdu_lds_tr16_b64(Xt + tr_off<XROWB>(prow + 4, bc));
+          bf[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int kcol = kcol0 + wave * 32 + j * 16 + (lane & 15);
+        if (kcol < p.Ktot) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
+      }
+    }
+}
+
+// =====================================================================================
 // strided data gradient (only the stride-2 stems need it; tiny share of the FLOPs): direct gather form,
 // one thread per (input pixel, 16-byte channel chunk).  w is the forward filter [Cout][T][Cin] in dtype T.
 template <typename T>
@@ -587,6 +820,8 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   if (eDo != d->Do || eHo != d->Ho || eWo != d->Wo)
     return hdu_set_error(HDU_ERR_ARG, "conv: output dims inconsistent with input dims / kernel / stride / pad");
   k->M = (long long)d->N * d->Do * d->Ho * d->Wo;
+  if ((long long)d->N * k->De * k->He * k->We >= (1ll << 31) || k->M >= (1ll << 31))
+    return hdu_set_error(HDU_ERR_ARG, "conv: more than 2^31 pixels per tensor (shard the volume)");
   k->Ktot = d->KD * d->KH * d->KW * d->Cin;
   k->pro_relu = d->pro_relu; k->accumulate = d->accumulate;
   if (d->drop_keep > 0.f && d->drop_keep < 1.f) {
@@ -677,9 +912,29 @@ static int choose_wgrad(const ConvK& k) {
   return best;
 }
 
+template <int BCO>
+static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
+  constexpr int PX = 64;
+  const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
+  long long want = 1024 / ((long long)gx * gy);
+  if (want < 1) want = 1;
+  long long steps = (k.M + PX - 1) / PX;
+  if (want > steps) want = steps;
+  long long steps_per = (steps + want - 1) / want;
+  const long long rows_per = steps_per * PX;
+  const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);
+  HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
+}
+
 template <typename T>
 static void dispatch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
   const int best = choose_wgrad(k);
+  if (sizeof(T) == 2) {
+    if (best == 64) launch_wgrad_tr<64>(k, dw, s);
+    else if (best == 48) launch_wgrad_tr<48>(k, dw, s);
+    else launch_wgrad_tr<32>(k, dw, s);
+    return;
+  }
   if (best == 64) launch_wgrad<T, 64>(k, dw, s);
   else if (best == 48) launch_wgrad<T, 48>(k, dw, s);
   else launch_wgrad<T, 32>(k, dw, s);
@@ -736,7 +991,7 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   if (!buf || buflen < 8) return hdu_set_error(HDU_ERR_ARG, "conv_kernel_name: bad buffer");
   const char* t = d->dtype == HDU_BF16 ? "bf16" : "f32";
   if (op == 1) {
-    snprintf(buf, buflen, "conv_wgrad_kernel<%s,%d>", t, choose_wgrad(k));
+    snprintf(buf, buflen, d->dtype == HDU_BF16 ? "conv_wgrad_tr_kernel<%d>" : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
   } else {
     int bm, bn;
     choose_igemm(k, &bm, &bn);

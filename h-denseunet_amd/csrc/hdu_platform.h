@@ -47,12 +47,33 @@ typedef unsigned short bf16_t;
 __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   return __builtin_bit_cast(float, (unsigned)h << 16);
 }
+// two floats -> packed bf16x2 (round-to-nearest-even).  gfx950: one v_cvt_pk_bf16_f32.
+__device__ __forceinline__ unsigned hdu_pack_bf16x2(float lo, float hi);
+
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   unsigned u = hdu_f2u(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+
+#ifdef HDU_EMU
+__device__ __forceinline__ unsigned hdu_pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ bf16_t hdu_f32_to_bf16_dev(float f) { return f32_to_bf16(f); }
+#else
+typedef __bf16 hdu_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hdu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned hdu_pack_bf16x2(float lo, float hi) {
+  const hdu_bf16x2 r = __builtin_convertvector(hdu_f32x2{lo, hi}, hdu_bf16x2);
+  return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ bf16_t hdu_f32_to_bf16_dev(float f) {
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
+}
+#endif
 
 // ---- 16-byte chunk <-> float lanes, per storage type ----
 template <typename T> struct Chunk;  // CH elements per 16 bytes
@@ -80,13 +101,11 @@ template <> struct Chunk<bf16_t> {
     f[6] = hdu_u2f(v.w << 16); f[7] = hdu_u2f(v.w & 0xffff0000u);
   }
   __device__ __forceinline__ static u32x4 pack(const float* f) {
-    return u32x4{(unsigned)f32_to_bf16(f[0]) | ((unsigned)f32_to_bf16(f[1]) << 16),
-                 (unsigned)f32_to_bf16(f[2]) | ((unsigned)f32_to_bf16(f[3]) << 16),
-                 (unsigned)f32_to_bf16(f[4]) | ((unsigned)f32_to_bf16(f[5]) << 16),
-                 (unsigned)f32_to_bf16(f[6]) | ((unsigned)f32_to_bf16(f[7]) << 16)};
+    return u32x4{hdu_pack_bf16x2(f[0], f[1]), hdu_pack_bf16x2(f[2], f[3]), hdu_pack_bf16x2(f[4], f[5]),
+                 hdu_pack_bf16x2(f[6], f[7])};
   }
   __device__ __forceinline__ static float load1(const bf16_t* p) { return bf16_to_f32(*p); }
-  __device__ __forceinline__ static void store1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  __device__ __forceinline__ static void store1(bf16_t* p, float v) { *p = hdu_f32_to_bf16_dev(v); }
 };
 
 // ---- MFMA wrappers: one "k-group" = 16 bytes of k per lane for A and B ----
@@ -121,6 +140,19 @@ template <> struct Mma<float> {
     return c;
   }
 };
+
+// LDS transpose read: lane i of each 16-lane group passes the address of row (i>>2), columns (i&3)*4.. of a 4x16
+// row-major 16-bit tile and receives column i (4 elements, rows 0..3) -- ds_read_b64_tr_b16.
+__device__ __forceinline__ u32x2 hdu_lds_tr16_b64(const void* p) {
+#ifdef HDU_EMU
+  return __builtin_bit_cast(u32x2, hipemu_ds_read_tr16_b64(p));
+#else
+  typedef short hdu_v4i16 __attribute__((ext_vector_type(4)));
+  const hdu_v4i16 r =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hdu_v4i16*)(p));
+  return __builtin_bit_cast(u32x2, r);
+#endif
+}
 
 // counter-based hash RNG for dropout masks (stateless; fwd and bwd regenerate the same mask)
 __host__ __device__ __forceinline__ unsigned hdu_hash32(unsigned long long idx, unsigned seed) {

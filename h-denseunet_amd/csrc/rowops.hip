@@ -88,28 +88,39 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
   }
 }
 
-// sums the per-block partials in double and post-processes per mode
+// sums the per-block partials (double accumulation) and post-processes per mode.
+// 256 threads = 32 channels x 8 partial lanes: lane p strides over the row blocks, then an LDS tree over the lanes.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                               long long M, const void* x, float* __restrict__ o1,
                                                               float* __restrict__ o2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[2][8][32];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double a1 = 0.0, a2 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    a1 += (double)partial[((long long)b * 2 + 0) * C + c];
-    a2 += (double)partial[((long long)b * 2 + 1) * C + c];
+  if (c < C) {
+    for (int b = pl; b < nblk; b += 8) {
+      a1 += (double)partial[((long long)b * 2 + 0) * C + c];
+      if (MODE != RED_COLSUM) a2 += (double)partial[((long long)b * 2 + 1) * C + c];
+    }
   }
-  if (MODE == RED_STATS) {
-    const double shift = (double)Chunk<T>::load1((const T*)x + c);
-    const double m1 = a1 / (double)M;
-    double var = a2 / (double)M - m1 * m1;
-    if (var < 0.0) var = 0.0;
-    o1[c] = (float)(shift + m1);
-    o2[c] = (float)var;
-  } else {
-    o1[c] = (float)a1;
-    if (o2) o2[c] = (float)a2;
+  red[0][pl][cl] = a1;
+  red[1][pl][cl] = a2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+#pragma unroll
+    for (int p = 1; p < 8; ++p) { a1 += red[0][p][cl]; a2 += red[1][p][cl]; }
+    if (MODE == RED_STATS) {
+      const double shift = (double)Chunk<T>::load1((const T*)x + c);
+      const double m1 = a1 / (double)M;
+      double var = a2 / (double)M - m1 * m1;
+      if (var < 0.0) var = 0.0;
+      o1[c] = (float)(shift + m1);
+      o2[c] = (float)var;
+    } else {
+      o1[c] = (float)a1;
+      if (o2) o2[c] = (float)a2;
+    }
   }
 }
 
@@ -124,7 +135,7 @@ static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   *cols = red_cols_for(nchunks);
   *gy = (unsigned)((nchunks + *cols - 1) / *cols);
   const int rows = 256 / *cols;
-  long long want = 2048 / *gy;
+  long long want = 1024 / *gy;
   if (want < 1) want = 1;
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);  // >= 4 rows per thread
   if (maxb < 1) maxb = 1;
@@ -172,7 +183,7 @@ static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_
     return hdu_set_error(HDU_ERR_WORKSPACE, "reduce: workspace too small (see hdu_reduce_ws_bytes)");
   k.rows_per_block = rpb;
   k.partial = (float*)ws;
-  const unsigned fb = (unsigned)((k.C + 255) / 256);
+  const unsigned fb = (unsigned)((k.C + 31) / 32);
   if (dtype == HDU_BF16) {
     run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
     HDU_LAUNCH((reduce_finalize_kernel<bf16_t, MODE>), dim3(fb), dim3(256), 0, s, (const float*)ws, (int)gx, k.C,
@@ -282,7 +293,7 @@ struct RowK {
   const void* x;
   const void* dz;
   void* out;
-  long long ldx, lddz, ldo, M;
+  long long ldx, lddz, ldo, M, rows_per_block;
   int C;
   int relu, accumulate;
   const float* a;
@@ -296,22 +307,29 @@ struct RowK {
   const unsigned* drop_seed_dev;
 };
 
-template <typename T>
+// Row kernels: thread (cc, rl) owns 16-byte channel chunk cc of its column group for the whole launch (coefficients
+// live in registers) and strides over the rows of its row block.
+template <typename T, int COLS>
 __global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
   constexpr int CH = Chunk<T>::CH;
-  const int ncc = p.C / CH;
-  const long long total = p.M * ncc;
+  constexpr int ROWS = 256 / COLS;
+  const int cc = threadIdx.x % COLS, rl = threadIdx.x / COLS;
+  const int c0 = (blockIdx.y * COLS + cc) * CH;
+  if (c0 >= p.C) return;
   const T* __restrict__ xp = (const T*)p.x;
   T* __restrict__ op = (T*)p.out;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(q % ncc) * CH;
-    const long long m = q / ncc;
+  float a[CH], b[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
+  const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long r_end = r_begin + p.rows_per_block;
+  if (r_end > p.M) r_end = p.M;
+  for (long long m = r_begin + rl; m < r_end; m += ROWS) {
     float f[CH];
     Chunk<T>::unpack(*(const u32x4*)(xp + m * p.ldx + c0), f);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      float s = p.a ? p.a[c0 + j] * f[j] + p.b[c0 + j] : f[j];
+      float s = a[j] * f[j] + b[j];
       if (p.relu) s = s > 0.f ? s : 0.f;
       f[j] = s;
     }
@@ -319,31 +337,39 @@ __global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
   }
 }
 
-template <typename T>
+template <typename T, int COLS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   constexpr int CH = Chunk<T>::CH;
-  const int ncc = p.C / CH;
-  const long long total = p.M * ncc;
+  constexpr int ROWS = 256 / COLS;
+  const int cc = threadIdx.x % COLS, rl = threadIdx.x / COLS;
+  const int c0 = (blockIdx.y * COLS + cc) * CH;
+  if (c0 >= p.C) return;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ dzp = (const T*)p.dz;
   T* __restrict__ op = (T*)p.out;
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(q % ncc) * CH;
-    const long long m = q / ncc;
-    float f[CH], g[CH];
+  // dx = k1*g - k2 - k3*(x-mean) = k1*g - k3*x + k4,  k4 = k3*mean - k2
+  float a[CH], b[CH], k1[CH], k3[CH], k4[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const int c = c0 + j;
+    a[j] = p.a[c]; b[j] = p.b[c]; k1[j] = p.k1[c]; k3[j] = p.k3[c];
+    k4[j] = p.k3[c] * p.mean[c] - p.k2[c];
+  }
+  const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long r_end = r_begin + p.rows_per_block;
+  if (r_end > p.M) r_end = p.M;
+  for (long long m = r_begin + rl; m < r_end; m += ROWS) {
+    float f[CH], g[CH], o[CH];
     Chunk<T>::unpack(*(const u32x4*)(xp + m * p.ldx + c0), f);
     Chunk<T>::unpack(*(const u32x4*)(dzp + m * p.lddz + c0), g);
-    float o[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int c = c0 + j;
-      const float s = p.a[c] * f[j] + p.b[c];
+      const float s = a[j] * f[j] + b[j];
       const float gg = (!p.relu || s > 0.f) ? g[j] : 0.f;
-      float d = p.k1[c] * gg - p.k2[c] - p.k3[c] * (f[j] - p.mean[c]);
+      float d = k1[j] * gg - k3[j] * f[j] + k4[j];
       if (p.drop_scale != 0.f) {
-        const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.C + (unsigned)c, dseed);
+        const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.C + (unsigned)(c0 + j), dseed);
         d = h < p.drop_thresh ? d * p.drop_scale : 0.f;
       }
       o[j] = d;
@@ -358,6 +384,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
     *(u32x4*)dst = Chunk<T>::pack(o);
   }
 }
+
+// geometry shared by the row kernels: column groups of COLS chunks, row blocks sized to ~2048 workgroups
+static void row_geometry(int dtype, long long M, int C, int* cols, unsigned* gx, unsigned* gy, long long* rpb) {
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  const int nchunks = C / ch;
+  int c = 4;
+  while (c < nchunks && c < 32) c <<= 1;
+  *cols = c;
+  *gy = (unsigned)((nchunks + c - 1) / c);
+  const int rows = 256 / c;
+  long long want = 2048 / *gy;
+  if (want < 1) want = 1;
+  long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);
+  if (maxb < 1) maxb = 1;
+  if (want > maxb) want = maxb;
+  *rpb = (M + want - 1) / want;
+  *gx = (unsigned)((M + *rpb - 1) / *rpb);
+}
+
+#define HDU_ROW_LAUNCH(kern, T, cols, gx, gy, stream, k)                                                  \
+  switch (cols) {                                                                                         \
+    case 4: HDU_LAUNCH((kern<T, 4>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;         \
+    case 8: HDU_LAUNCH((kern<T, 8>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;         \
+    case 16: HDU_LAUNCH((kern<T, 16>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
+    default: HDU_LAUNCH((kern<T, 32>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
+  }
 
 static int rowk_check(int dtype, const RowK& k, const char* what) {
   if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, what);
@@ -374,10 +426,10 @@ extern "C" int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, 
   if (!x || !z || ((a == nullptr) != (b == nullptr))) return hdu_set_error(HDU_ERR_ARG, "affine_act: bad pointers");
   if (int e = rowk_check(dtype, k, "affine_act: C / strides must be multiples of the 16-byte chunk")) return e;
   if (M == 0) return 0;
-  const int ch = dtype == HDU_BF16 ? 8 : 4;
-  const unsigned g = hdu_grid_1d(M * (C / ch), 256, 4096);
-  if (dtype == HDU_BF16) HDU_LAUNCH((affine_act_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
-  else HDU_LAUNCH((affine_act_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
+  int cols; unsigned gx, gy;
+  row_geometry(dtype, M, C, &cols, &gx, &gy, &k.rows_per_block);
+  if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(affine_act_kernel, bf16_t, cols, gx, gy, stream, k); }
+  else { HDU_ROW_LAUNCH(affine_act_kernel, float, cols, gx, gy, stream, k); }
   return hdu_check_launch("affine_act");
 }
 
@@ -397,10 +449,10 @@ extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const v
   if (!x || !dz || !dx || !a || !b || !mean || !k1 || !k2 || !k3) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_apply: null pointer");
   if (int e = rowk_check(dtype, k, "bn_bwd_apply: C / strides must be multiples of the 16-byte chunk")) return e;
   if (M == 0) return 0;
-  const int ch = dtype == HDU_BF16 ? 8 : 4;
-  const unsigned g = hdu_grid_1d(M * (C / ch), 256, 4096);
-  if (dtype == HDU_BF16) HDU_LAUNCH((bn_bwd_apply_kernel<bf16_t>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
-  else HDU_LAUNCH((bn_bwd_apply_kernel<float>), dim3(g), dim3(256), 0, (hipStream_t)stream, k);
+  int cols; unsigned gx, gy;
+  row_geometry(dtype, M, C, &cols, &gx, &gy, &k.rows_per_block);
+  if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(bn_bwd_apply_kernel, bf16_t, cols, gx, gy, stream, k); }
+  else { HDU_ROW_LAUNCH(bn_bwd_apply_kernel, float, cols, gx, gy, stream, k); }
   return hdu_check_launch("bn_bwd_apply");
 }
 

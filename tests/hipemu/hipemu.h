@@ -157,3 +157,22 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x
   hipemu::wave_release();
   return d;
 }
+
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read), lane map measured on MI355X with tools/probe_tr.hip:
+// within each 16-lane group the lanes' 8-byte pieces form a 4x16 row-major bf16 tile (lane i supplies row i>>2,
+// columns (i&3)*4..+3); lane i receives column i, rows 0..3.
+typedef unsigned short hipemu_u16x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_u16x4 hipemu_ds_read_tr16_b64(const void* lds_addr) {
+  unsigned short mine[4];
+  std::memcpy(mine, lds_addr, 8);
+  size_t stride;
+  const char* all = hipemu::wave_exchange(mine, 8, &stride);
+  const int lane = hipemu::g_cur->lane, i = lane & 15, g = lane >> 4;
+  hipemu_u16x4 r;
+  for (int j = 0; j < 4; ++j) {
+    const unsigned short* src = (const unsigned short*)(all + (size_t)(16 * g + 4 * j + (i >> 2)) * stride);
+    r[j] = src[i & 3];
+  }
+  hipemu::wave_release();
+  return r;
+}
