@@ -706,6 +706,350 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
 }
 
 // =====================================================================================
+// DMA form of the implicit GEMM: used whenever the operand gather needs no arithmetic (no BN/ReLU prologue, no
+// skip add) -- i.e. for materialised inputs, for every data gradient and for all filter tiles.  Each lane issues
+// global_load_lds_dwordx4 straight into the swizzled LDS tile (no VGPR staging, no ds_write, no VALU on data);
+// padding / tails read a 16-byte page of zeros.  The LDS image is lane-linear per wave instruction, so the XOR
+// swizzle is applied by permuting which logical k-chunk each lane fetches.
+__device__ __attribute__((aligned(16))) unsigned hdu_zero_page[16];
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int BK = 8 * CH;
+  constexpr int A_IT = BM / 32;
+  constexpr int B_IT = (BN + 31) / 32;
+  constexpr int WM = BM / WAVES_M;
+  constexpr int WN = BN / WAVES_N;
+  constexpr int TM = WM / 16;
+  constexpr int TN = WN / 16;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int r0 = tid >> 3;
+  const int kcl = (tid & 7) ^ (r0 & 7);   // logical chunk this lane fetches (it lands at physical chunk tid&7)
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ wp = (const T*)p.w;
+  const char* zero = (const char*)hdu_zero_page;
+  const bool ups = (p.ud | p.uh | p.uw) != 0;
+
+  int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const long long m = m0 + r0 + i * 32;
+    if (m < p.M) {
+      const int ow = (int)(m % p.Wo);
+      long long t = m / p.Wo;
+      const int oh = (int)(t % p.Ho);
+      t /= p.Ho;
+      const int od = (int)(t % p.Do);
+      rn[i] = (int)(t / p.Do);
+      rid[i] = od * p.sd - p.pd;
+      rih[i] = oh * p.sh - p.ph;
+      riw[i] = ow * p.sw - p.pw;
+      rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
+    } else {
+      rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
+    }
+  }
+  int k = kcl * CH;
+  int c, kd, kh, kw;
+  {
+    const int tap = k / p.Cin;
+    c = k - tap * p.Cin;
+    kw = tap % p.KW;
+    const int t = tap / p.KW;
+    kh = t % p.KH;
+    kd = t / p.KH;
+  }
+  // filter rows of this lane
+  const T* wrow[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int col = n0 + r0 + j * 32;
+    wrow[j] = (r0 + j * 32 < BN && col < p.Cout) ? wp + (long long)col * p.Ktot : nullptr;
+  }
+
+  auto issue_tile = [&](int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + BM * 128;
+    const bool kvalid = kd < p.KD;
+    const int tapoff = (kd * p.He + kh) * p.We + kw;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
+      const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                      (unsigned)iw < (unsigned)p.We;
+      const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
+                          : rpix[i] + tapoff;
+      const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+      hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      if (j * 32 + wave * 8 < BN) {   // wave-uniform
+        const char* g = (wrow[j] != nullptr && k < p.Ktot) ? (const char*)(wrow[j] + k) : zero;
+        hdu_glds16(g, Bs + (j * 32 + wave * 8) * 128);
+      }
+    }
+  };
+
+  auto advance = [&]() {
+    k += BK;
+    c += BK;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      if (++kw == p.KW) {
+        kw = 0;
+        if (++kh == p.KH) {
+          kh = 0;
+          ++kd;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.Ktot + BK - 1) / BK;
+  issue_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) {
+      advance();
+      issue_tile(buf ^ 1);
+    }
+    {
+      const char* As = smem + buf * STAGE;
+      const char* Bs = As + BM * 128;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int chunk = kg * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(As + lds_chunk_off(wm * WM + i * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(Bs + lds_chunk_off(wn * WN + j * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  T* __restrict__ yp = (T*)p.y;
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[n];
+        if (p.drop_scale != 0.f) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
+          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
+        }
+        T* q = yp + m * p.ldy + n;
+        if (p.accumulate) v += Chunk<T>::load1(q);
+        Chunk<T>::store1(q, v);
+      }
+    }
+  }
+}
+
+// bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
+template <int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+  typedef bf16_t T;
+  constexpr int CH = 8;
+  constexpr int PX = 64;
+  constexpr int BKC = 128;
+  constexpr int XROWB = 256;
+  constexpr int DROWB = 128;
+  constexpr int TM = BCO / 16;
+  constexpr int TN = 2;
+  constexpr int STAGE = PX * (XROWB + DROWB);
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dyp = (const T*)p.y;
+  const char* zero = (const char*)hdu_zero_page;
+  const bool ups = (p.ud | p.uh | p.uw) != 0;
+
+  const int kcol0 = blockIdx.x * BKC;
+  const int co0 = blockIdx.y * BCO;
+  const long long m_begin = (long long)blockIdx.z * rows_per_split;
+  long long m_end = m_begin + rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+
+  // x tile: lane owns physical 16-byte chunk (tid&15) of pixel rows (tid>>4)+16*i; logical chunk via the swizzle
+  const int pxl = tid >> 4;
+  const int fx = (pxl & 3) | ((pxl >> 1) & 4);
+  const int xp16 = tid & 15;
+  const int kcc = ((((xp16 >> 1) ^ fx) << 1) | (xp16 & 1));
+  const int kk = kcol0 + kcc * CH;
+  const bool kvalid = kk < p.Ktot;
+  int c = 0, kd = 0, kh = 0, kw = 0;
+  if (kvalid) {
+    const int tap = kk / p.Cin;
+    c = kk - tap * p.Cin;
+    kw = tap % p.KW;
+    const int t = tap / p.KW;
+    kh = t % p.KH;
+    kd = t / p.KH;
+  }
+  int sn[4], sod[4], soh[4], sow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m_begin + pxl + i * 16;
+    const int ow = (int)(m % p.Wo);
+    long long t = m / p.Wo;
+    const int oh = (int)(t % p.Ho);
+    t /= p.Ho;
+    sod[i] = (int)(t % p.Do);
+    sn[i] = (int)(t / p.Do);
+    soh[i] = oh;
+    sow[i] = ow;
+  }
+  // dy tile: lane owns physical chunk (tid&7) of pixel rows (tid>>3)+32*j
+  const int dpx0 = tid >> 3;
+  const int gd = ((dpx0 >> 1) & 1) | (((dpx0 >> 3) & 1) << 1);
+  const int dp16 = tid & 7;
+  const int dcl = ((((dp16 >> 1) ^ gd) << 1) | (dp16 & 1));
+  const bool dvalid = dcl * CH < BCO && co0 + dcl * CH < p.Cout;
+
+  auto issue_tile = [&](int buf, long long mt) {
+    char* Xt = smem + buf * STAGE;
+    char* Dt = Xt + PX * XROWB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long m = mt + pxl + i * 16;
+      const int id = sod[i] * p.sd - p.pd + kd, ih = soh[i] * p.sh - p.ph + kh, iw = sow[i] * p.sw - p.pw + kw;
+      const bool ok = kvalid && m < m_end && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                      (unsigned)iw < (unsigned)p.We;
+      const int src = ups ? ((sn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
+                          : ((sn[i] * p.De + id) * p.He + ih) * p.We + iw;
+      const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+      hdu_glds16(g, Xt + (i * 16 + wave * 4) * XROWB);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long long m = mt + dpx0 + j * 32;
+      const char* g = (dvalid && m < m_end) ? (const char*)(dyp + m * p.ldy + co0 + dcl * CH) : zero;
+      hdu_glds16(g, Dt + (j * 32 + wave * 8) * DROWB);
+    }
+  };
+
+  auto advance_pixels = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sow[i] += PX;
+      while (sow[i] >= p.Wo) {
+        sow[i] -= p.Wo;
+        if (++soh[i] == p.Ho) {
+          soh[i] = 0;
+          if (++sod[i] == p.Do) {
+            sod[i] = 0;
+            ++sn[i];
+          }
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (int)((m_end - m_begin + PX - 1) / PX);
+  if (nsteps > 0) issue_tile(0, m_begin);
+  __syncthreads();
+  const int li = lane & 15, lg = lane >> 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) {
+      advance_pixels();
+      issue_tile(buf ^ 1, m_begin + (long long)(st + 1) * PX);
+    }
+    {
+      const char* Xt = smem + buf * STAGE;
+      const char* Dt = Xt + PX * XROWB;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int prow = kg * 32 + lg * 8 + (li >> 2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int bc = (i * 16 + (li & 3) * 4) * 2;
+          const u32x2 lo = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow, bc));
+          const u32x2 hi = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow + 4, bc));
+          af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int bc = (wave * 32 + j * 16 + (li & 3) * 4) * 2;
+          const u32x2 lo = hdu_lds_tr16_b64(Xt + tr_off<XROWB>(prow, bc));
+          const u32x2 hi = hdu_lds_tr16_b64(Xt + tr_off<XROWB>(prow + 4, bc));
+          bf[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int kcol = kcol0 + wave * 32 + j * 16 + (lane & 15);
+        if (kcol < p.Ktot) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
+      }
+    }
+}
+
+// =====================================================================================
 // strided data gradient (only the stride-2 stems need it; tiny share of the FLOPs): direct gather form,
 // one thread per (input pixel, 16-byte channel chunk).  w is the forward filter [Cout][T][Cin] in dtype T.
 template <typename T>
@@ -839,7 +1183,10 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
 template <typename T, int BM, int BN, int WMv, int WNv>
 static void launch_igemm(const ConvK& k, hipStream_t s) {
   dim3 grid((unsigned)((k.M + BM - 1) / BM), (unsigned)((k.Cout + BN - 1) / BN), 1);
-  HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+  if (k.pro_a == nullptr && k.skip == nullptr)
+    HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+  else
+    HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
 }
 
 // tile choice: the N tile that wastes the fewest padded output channels (ties -> widest); 64-row tiles for small images
@@ -913,6 +1260,9 @@ static int choose_wgrad(const ConvK& k) {
 }
 
 template <int BCO>
+static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s);
+
+template <int BCO>
 static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
   constexpr int PX = 64;
   const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
@@ -923,7 +1273,10 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
   long long steps_per = (steps + want - 1) / want;
   const long long rows_per = steps_per * PX;
   const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);
-  HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
+  if (k.pro_a == nullptr && k.skip == nullptr)
+    HDU_LAUNCH((conv_wgrad_dma_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
+  else
+    HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
 }
 
 template <typename T>
@@ -991,12 +1344,14 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   if (!buf || buflen < 8) return hdu_set_error(HDU_ERR_ARG, "conv_kernel_name: bad buffer");
   const char* t = d->dtype == HDU_BF16 ? "bf16" : "f32";
   if (op == 1) {
-    snprintf(buf, buflen, d->dtype == HDU_BF16 ? "conv_wgrad_tr_kernel<%d>" : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
+    const bool dma = k.pro_a == nullptr && k.skip == nullptr;
+    snprintf(buf, buflen, d->dtype == HDU_BF16 ? (dma ? "conv_wgrad_dma_kernel<%d>" : "conv_wgrad_tr_kernel<%d>") : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
   } else {
     int bm, bn;
     choose_igemm(k, &bm, &bn);
     const int wm = (bm == 128 && bn == 128) ? 2 : ((bm == 64 && bn != 48) ? 2 : 4);
-    snprintf(buf, buflen, "conv_igemm_kernel<%s,%d,%d,%d,%d>", t, bm, bn, wm, 4 / wm);
+    const bool dma = k.pro_a == nullptr && k.skip == nullptr;
+    snprintf(buf, buflen, "conv_igemm%s_kernel<%s,%d,%d,%d,%d>", dma ? "_dma" : "", t, bm, bn, wm, 4 / wm);
   }
   return 0;
 }

@@ -154,11 +154,23 @@ __device__ __forceinline__ u32x2 hdu_lds_tr16_b64(const void* p) {
 #endif
 }
 
+// async global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is the wave-uniform
+// `lds_wave_base` + lane*16 (lane-linear, 1 KiB per wave instruction); the global source is per lane.
+__device__ __forceinline__ void hdu_glds16(const void* gsrc, char* lds_wave_base) {
+#ifdef HDU_EMU
+  __builtin_memcpy(lds_wave_base + HDU_LANE() * 16, gsrc, 16);
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
 // counter-based hash RNG for dropout masks (stateless; fwd and bwd regenerate the same mask)
 __host__ __device__ __forceinline__ unsigned hdu_hash32(unsigned long long idx, unsigned seed) {
-  unsigned long long z = idx + 0x9E3779B97F4A7C15ull * (unsigned long long)(seed + 1u);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (unsigned)(z >> 32);
+  unsigned h = (unsigned)idx * 0x9E3779B1u;
+  h ^= (unsigned)(idx >> 32) * 0xC2B2AE3Du + (seed + 1u) * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
 }

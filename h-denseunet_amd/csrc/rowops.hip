@@ -411,6 +411,78 @@ static void row_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
     default: HDU_LAUNCH((kern<T, 32>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
   }
 
+struct MatK {
+  const void* x;
+  const void* skip;
+  void* out;
+  const float* a;
+  const float* b;
+  long long ldx, ldskip, ldo, Mo, rows_per_block;
+  int N, D, H, W, C;
+  int ud, uh, uw, relu;
+};
+
+template <typename T, int COLS>
+__global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int ROWS = 256 / COLS;
+  const int cc = threadIdx.x % COLS, rl = threadIdx.x / COLS;
+  const int c0 = (blockIdx.y * COLS + cc) * CH;
+  if (c0 >= p.C) return;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ sp = (const T*)p.skip;
+  T* __restrict__ op = (T*)p.out;
+  float a[CH], b[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
+  const int We = p.W << p.uw, He = p.H << p.uh, De = p.D << p.ud;
+  const bool ups = (p.ud | p.uh | p.uw) != 0;
+  const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long r_end = r_begin + p.rows_per_block;
+  if (r_end > p.Mo) r_end = p.Mo;
+  long long m = r_begin + rl;
+  int w = 0, h = 0, d = 0, n = 0;
+  if (ups && m < r_end) {
+    w = (int)(m % We);
+    long long t = m / We;
+    h = (int)(t % He);
+    t /= He;
+    d = (int)(t % De);
+    n = (int)(t / De);
+  }
+  for (; m < r_end; m += ROWS) {
+    const long long src = ups ? ((((long long)n * p.D + (d >> p.ud)) * p.H + (h >> p.uh)) * p.W + (w >> p.uw)) : m;
+    float f[CH];
+    Chunk<T>::unpack(*(const u32x4*)(xp + src * p.ldx + c0), f);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float s = a[j] * f[j] + b[j];
+      if (p.relu) s = s > 0.f ? s : 0.f;
+      f[j] = s;
+    }
+    if (sp) {
+      float g[CH];
+      Chunk<T>::unpack(*(const u32x4*)(sp + m * p.ldskip + c0), g);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) f[j] += g[j];
+    }
+    *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(f);
+    if (ups) {
+      w += ROWS;
+      while (w >= We) {
+        w -= We;
+        if (++h == He) {
+          h = 0;
+          if (++d == De) {
+            d = 0;
+            ++n;
+          }
+        }
+      }
+    }
+  }
+}
+
 static int rowk_check(int dtype, const RowK& k, const char* what) {
   if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, what);
   const int ch = dtype == HDU_BF16 ? 8 : 4;
@@ -431,6 +503,26 @@ extern "C" int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, 
   if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(affine_act_kernel, bf16_t, cols, gx, gy, stream, k); }
   else { HDU_ROW_LAUNCH(affine_act_kernel, float, cols, gx, gy, stream, k); }
   return hdu_check_launch("affine_act");
+}
+
+extern "C" int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
+                               const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
+                               void* out, int64_t ldout, void* stream) {
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "materialize: bad dtype");
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if (!x || !out || ((a == nullptr) != (b == nullptr)) || ((ud | uh | uw) & ~1))
+    return hdu_set_error(HDU_ERR_ARG, "materialize: bad pointers / upsample shifts");
+  if (C <= 0 || C % ch || ldx % ch || ldout % ch || (skip && ldskip % ch) || N <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return hdu_set_error(HDU_ERR_ARG, "materialize: C / strides must be multiples of the 16-byte chunk");
+  MatK k{};
+  k.x = x; k.skip = skip; k.out = out; k.a = a; k.b = b; k.ldx = ldx; k.ldskip = ldskip; k.ldo = ldout;
+  k.N = N; k.D = D; k.H = H; k.W = W; k.C = C; k.ud = ud; k.uh = uh; k.uw = uw; k.relu = relu;
+  k.Mo = (long long)N * (D << ud) * (H << uh) * (W << uw);
+  int cols; unsigned gx, gy;
+  row_geometry(dtype, k.Mo, C, &cols, &gx, &gy, &k.rows_per_block);
+  if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(materialize_kernel, bf16_t, cols, gx, gy, stream, k); }
+  else { HDU_ROW_LAUNCH(materialize_kernel, float, cols, gx, gy, stream, k); }
+  return hdu_check_launch("materialize");
 }
 
 extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,

@@ -13,6 +13,7 @@ all-reduce are single flat operations.  Conv filters are stored [Cout][KD][KH][K
 """
 import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -119,6 +120,7 @@ class Ctx:
         self.drop_layers = 0
         self.dropout_enabled = True
         self.grad_enabled = True
+        self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
         self.finalized = False
 
     # ---------------- parameters
@@ -365,6 +367,18 @@ class ConvLayer:
         need_input_grad = x.root.needs_grad
         if ctx.grad_enabled:
             out.require_grad()
+        # Operand preparation.  Fused mode: the BN/ReLU/upsample/skip prologue runs inside the conv's operand gather
+        # (nothing materialised).  Default: one streaming hdu_materialize pass writes the conv input so that the conv
+        # is a pure async-DMA implicit GEMM -- at the narrow output widths of this net (Cout 32..192) the fused
+        # prologue costs more VALU cycles than the MFMAs it feeds (profiles/).
+        self.xin = None
+        self.conv_up = up
+        if (bn is not None or skip is not None) and not ctx.fuse_prologue:
+            if skip is not None:
+                self.xin = ctx.new_var(xa.N, De, He, We, cin_p)
+                self.conv_up = (0, 0, 0)
+            else:
+                self.xin = ctx.new_var(xa.N, xa.D, xa.H, xa.W, cin_p)
         self.need_input_grad = need_input_grad
         self.strided = stride != (1, 1, 1)
         self.need_dgrad_filter = need_input_grad and not self.strided
@@ -393,15 +407,16 @@ class ConvLayer:
         x, out = self.x.act, self.out.act
         pro = (self.bn.a, self.bn.b) if self.bn is not None else None
         relu = self.bn.relu if self.bn is not None else False
-        self.d_f = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, self.up,
-                                 self.skip.act if self.skip is not None else None, pro, relu,
-                                 self.bias.data if self.bias is not None else None)
+        skip = self.skip.act if self.skip is not None else None
+        up = self.up
+        if self.xin is not None:            # materialised operand: plain conv
+            x, pro, relu, skip, up = self.xin.act, None, False, None, self.conv_up
+        bias = self.bias.data if self.bias is not None else None
+        self.d_f = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu, bias)
         self.d_f_drop = None
         if self.dropout > 0:
-            self.d_f_drop = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, self.up,
-                                          self.skip.act if self.skip is not None else None, pro, relu,
-                                          self.bias.data if self.bias is not None else None, False,
-                                          1.0 - self.dropout, self.drop_seed, ctx.seed_dev)
+            self.d_f_drop = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu,
+                                          bias, False, 1.0 - self.dropout, self.drop_seed, ctx.seed_dev)
 
     def prep(self):
         ctx = self.ctx
@@ -415,6 +430,11 @@ class ConvLayer:
         ctx = self.ctx
         if self.bn is not None:
             self.bn.fold(self.x)
+        if self.xin is not None:
+            bn = self.bn
+            ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False,
+                            self.up if self.skip is not None else (0, 0, 0),
+                            self.skip.act if self.skip is not None else None, self.xin.act)
         if self.d_f_drop is not None and ctx.learning_phase == 1 and ctx.dropout_enabled:
             ops.conv_fprop(self.d_f_drop)
         else:
@@ -428,10 +448,13 @@ class ConvLayer:
         dy = out.grad
         x = self.x.act
         if self.trainable:
-            d = ops.conv_desc(x, self.wf_ptr, dy, self.K, self.stride, self.pad, self.up,
-                              self.skip.act if self.skip is not None else None,
-                              (self.bn.a, self.bn.b) if self.bn is not None else None,
-                              self.bn.relu if self.bn is not None else False)
+            if self.xin is not None:
+                d = ops.conv_desc(self.xin.act, self.wf_ptr, dy, self.K, self.stride, self.pad, self.conv_up)
+            else:
+                d = ops.conv_desc(x, self.wf_ptr, dy, self.K, self.stride, self.pad, self.up,
+                                  self.skip.act if self.skip is not None else None,
+                                  (self.bn.a, self.bn.b) if self.bn is not None else None,
+                                  self.bn.relu if self.bn is not None else False)
             ops.conv_wgrad(d, self.kernel.grad)
             if self.bias is not None:
                 ops.colsum(dy, self.bias.grad, ctx.ws)

@@ -60,6 +60,8 @@ _SIGS = {
     "hdu_bn_bwd_apply": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
                                  c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
     "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
+    "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
+                                c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),
     "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64,

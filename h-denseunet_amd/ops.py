@@ -192,6 +192,12 @@ def affine_act(x, a, b, relu, z):
                                   stream()), "hdu_affine_act")
 
 
+def materialize(x, a, b, relu, up, skip, out):
+    check(_l.get().hdu_materialize(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, fptr(a), fptr(b), 1 if relu else 0,
+                                   up[0], up[1], up[2], skip.ptr if skip is not None else None,
+                                   skip.ld if skip is not None else 0, out.ptr, out.ld, stream()), "hdu_materialize")
+
+
 def colsum(x, out, ws):
     check(_l.get().hdu_colsum(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(out), ws.ptr, ws.nbytes, stream()), "hdu_colsum")
 

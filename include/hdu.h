@@ -139,6 +139,14 @@ int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int
 int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, const float* a, const float* b,
                    int relu, void* z, int64_t ldz, void* stream);
 
+/* materialise the input of a conv:  out[n,d,h,w,c] = relu?(a[c]*x[n,d>>ud,h>>uh,w>>uw,c]+b[c]) + skip[n,d,h,w,c]
+ * (BN(+Scale)+ReLU, nearest up-sampling and the skip add in ONE streaming pass; a/b and skip optional).
+ * N,D,H,W are the stored (low-res) dims of x; out and skip have dims (D<<ud, H<<uh, W<<uw).  With the input
+ * materialised, the conv itself runs as a pure async-DMA implicit GEMM (no VALU work on the operands). */
+int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
+                    const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip, void* out,
+                    int64_t ldout, void* stream);
+
 /* per-channel column sum: out[c] = sum_m x[m][c]   (bias gradients) */
 int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws, size_t ws_bytes,
                void* stream);

@@ -421,6 +421,32 @@ def test_wce_loss(hdu, dtype):
     assert float((got[:, :3] - zr.grad).abs().max()) < at * float(zr.grad.abs().max()) + 1e-9
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("up,use_skip,use_pro", [((0, 0, 0), False, True), ((0, 1, 1), True, True), ((1, 1, 1), False, True),
+                                                  ((0, 0, 0), True, False), ((0, 1, 1), True, True)])
+def test_materialize(hdu, dtype, up, use_skip, use_pro):
+    """relu(a*x+b) -> nearest up-sampling (== np.repeat, convolutional_test.py:673-681,726-736) -> + skip"""
+    ops = ops_mod()
+    N, D, H, W, C = 2, 2, 5, 7, 24
+    x = rnd((N, D, H, W, C), 1, 1.0, dtype)
+    De, He, We = D << up[0], H << up[1], W << up[2]
+    skip = rnd((N, De, He, We, C), 2, 1.0, dtype) if use_skip else None
+    a = (rnd((C,), 3, 0.5) + 1.0).float().double(); b = rnd((C,), 4, 0.3).float().double()
+    xa = mkact(ops, x, dtype, 40, 8)
+    out = ops.Act.alloc(N, De, He, We, C, dtype)
+    ops.materialize(xa, dev(ops, a) if use_pro else None, dev(ops, b) if use_pro else None, use_pro, up,
+                    mkact(ops, skip, dtype) if use_skip else None, out)
+    ref = x
+    if use_pro:
+        ref = (ref * a + b).clamp_min(0)
+    for ax, u in zip((1, 2, 3), up):
+        if u:
+            ref = ref.repeat_interleave(2, dim=ax)
+    if use_skip:
+        ref = ref + skip
+    assert_close(out.to_torch().cpu(), ref, dtype, what="materialize")
+
+
 def test_sgd_nesterov(hdu):
     ops = ops_mod()
     n = 10007

@@ -14,6 +14,7 @@ ops = importlib.import_module("h-denseunet_amd.ops")
 
 which = sys.argv[1] if len(sys.argv) > 1 else "2d"
 dtype = 0 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else 1
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 
 # (name, N, D, H, W, Cin, Cout, K, up, pro)
 S2D = [
@@ -58,6 +59,8 @@ def timeit(fn, n=5):
 
 tot = {"fprop": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 for (name, N, D, H, W, Cin, Cout, K, up, pro, st, pad) in (S2D if which == "2d" else S3D):
+    if only and name not in only:
+        continue
     x = ops.Act.alloc(N, D, H, W, Cin, dtype); x.buf.normal_()
     De, He, We = D << up[0], H << up[1], W << up[2]
     Do, Ho, Wo = [(n + 2 * p - k) // s + 1 for n, p, k, s in zip((De, He, We), pad, K, st)]
