@@ -12,6 +12,7 @@
 // the BN(+Scale)+ReLU affine of the producing layer, nearest up-sampling, the skip add and zero padding,
 // so none of those tensors is ever materialised in HBM.
 #include "conv_common.h"
+#include "../../include/hdu.h"
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
@@ -882,6 +883,184 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   }
 }
 
+// 3-stage ring variant: tiles t+1 and t+2 stay in flight while tile t is multiplied.  Per iteration: counted
+// vmcnt (this wave's DMAs of tile t have landed) -> ONE raw barrier (everyone's have; everyone finished reading the
+// slot about to be refilled) -> issue tile t+2 -> MFMAs on tile t.  Every wave issues exactly A_IT + B_IT DMAs per
+// tile (invalid rows fetch the zero page) so the vmcnt immediate is uniform.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_dma3_kernel(ConvK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int BK = 8 * CH;
+  constexpr int A_IT = BM / 32;
+  constexpr int B_IT = (BN + 31) / 32;
+  constexpr int BNP = B_IT * 32;
+  constexpr int WM = BM / WAVES_M;
+  constexpr int WN = BN / WAVES_N;
+  constexpr int TM = WM / 16;
+  constexpr int TN = WN / 16;
+  constexpr int STAGE = (BM + BNP) * 128;
+  constexpr int L = A_IT + B_IT;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int r0 = tid >> 3;
+  const int kcl = (tid & 7) ^ (r0 & 7);
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ wp = (const T*)p.w;
+  const char* zero = (const char*)hdu_zero_page;
+  const bool ups = (p.ud | p.uh | p.uw) != 0;
+
+  int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const long long m = m0 + r0 + i * 32;
+    if (m < p.M) {
+      const int ow = (int)(m % p.Wo);
+      long long t = m / p.Wo;
+      const int oh = (int)(t % p.Ho);
+      t /= p.Ho;
+      const int od = (int)(t % p.Do);
+      rn[i] = (int)(t / p.Do);
+      rid[i] = od * p.sd - p.pd;
+      rih[i] = oh * p.sh - p.ph;
+      riw[i] = ow * p.sw - p.pw;
+      rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
+    } else {
+      rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
+    }
+  }
+  int k = kcl * CH;
+  int c, kd, kh, kw;
+  {
+    const int tap = k / p.Cin;
+    c = k - tap * p.Cin;
+    kw = tap % p.KW;
+    const int t = tap / p.KW;
+    kh = t % p.KH;
+    kd = t / p.KH;
+  }
+  const T* wrow[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int col = n0 + r0 + j * 32;
+    wrow[j] = (r0 + j * 32 < BN && col < p.Cout) ? wp + (long long)col * p.Ktot : nullptr;
+  }
+
+  auto issue_tile = [&](int slot) {
+    char* As = smem + slot * STAGE;
+    char* Bs = As + BM * 128;
+    const bool kvalid = kd < p.KD;
+    const int tapoff = (kd * p.He + kh) * p.We + kw;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
+      const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                      (unsigned)iw < (unsigned)p.We;
+      const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
+                          : rpix[i] + tapoff;
+      const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+      hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const char* g = (wrow[j] != nullptr && k < p.Ktot) ? (const char*)(wrow[j] + k) : zero;
+      hdu_glds16(g, Bs + (j * 32 + wave * 8) * 128);
+    }
+    // advance this lane's k state to the next tile
+    k += BK;
+    c += BK;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      if (++kw == p.KW) {
+        kw = 0;
+        if (++kh == p.KH) {
+          kh = 0;
+          ++kd;
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.Ktot + BK - 1) / BK;
+  issue_tile(0);
+  if (nk > 1) issue_tile(1);
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if constexpr (L == 2) { HDU_WAIT_VMCNT(2); }
+      else if constexpr (L == 3) { HDU_WAIT_VMCNT(3); }
+      else if constexpr (L == 4) { HDU_WAIT_VMCNT(4); }
+      else if constexpr (L == 5) { HDU_WAIT_VMCNT(5); }
+      else if constexpr (L == 6) { HDU_WAIT_VMCNT(6); }
+      else { HDU_WAIT_VMCNT(8); }
+    } else {
+      HDU_WAIT_VMCNT(0);
+    }
+    HDU_RAW_BARRIER();
+    if (kt + 2 < nk) issue_tile(slot >= 1 ? slot - 1 : 2);   // slot (kt+2)%3
+    {
+      const char* As = smem + slot * STAGE;
+      const char* Bs = As + BM * 128;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int chunk = kg * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(As + lds_chunk_off(wm * WM + i * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(Bs + lds_chunk_off(wn * WN + j * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+  T* __restrict__ yp = (T*)p.y;
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + (lane & 15);
+        if (n >= p.Cout) continue;
+        float v = acc[i][j][r];
+        if (p.bias) v += p.bias[n];
+        if (p.drop_scale != 0.f) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
+          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
+        }
+        T* q = yp + m * p.ldy + n;
+        if (p.accumulate) v += Chunk<T>::load1(q);
+        Chunk<T>::store1(q, v);
+      }
+    }
+  }
+}
+
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
 template <int BCO>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
@@ -1132,8 +1311,36 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep_entry* __restrict__ table,
+                                                                 const float* __restrict__ master, T* __restrict__ wc) {
+  const hdu_prep_entry e = table[blockIdx.y];
+  const long long total = (long long)e.Cout * e.T * e.Cin;
+  const float* wm = master + e.master_off;
+  T* wf = e.w_f_off >= 0 ? wc + e.w_f_off : nullptr;
+  T* wd = e.w_d_off >= 0 ? wc + e.w_d_off : nullptr;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(q % e.Cin);
+    const long long t2 = q / e.Cin;
+    const int t = (int)(t2 % e.T);
+    const int co = (int)(t2 / e.T);
+    const float v = wm[q];
+    if (wf) Chunk<T>::store1(wf + q, v);
+    if (wd) Chunk<T>::store1(wd + ((long long)ci * e.T + (e.T - 1 - t)) * e.Cout + co, v);
+  }
+}
+
 // ------------------------------------------------------------------ host-side dispatch
 #include "hdu_host.h"
+
+int g_tuning[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+
+extern "C" int hdu_set_tuning(int key, int value) {
+  if (key < 0 || key >= 8) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
+  g_tuning[key] = value;
+  return 0;
+}
 
 static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   if (!d) return hdu_set_error(HDU_ERR_ARG, "conv: null descriptor");
@@ -1183,9 +1390,12 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
 template <typename T, int BM, int BN, int WMv, int WNv>
 static void launch_igemm(const ConvK& k, hipStream_t s) {
   dim3 grid((unsigned)((k.M + BM - 1) / BM), (unsigned)((k.Cout + BN - 1) / BN), 1);
-  if (k.pro_a == nullptr && k.skip == nullptr)
-    HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
-  else
+  if (k.pro_a == nullptr && k.skip == nullptr) {
+    if (g_tuning[HDU_TUNE_DMA_STAGES] == 3)
+      HDU_LAUNCH((conv_igemm_dma3_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+    else
+      HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+  } else
     HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
 }
 
@@ -1351,7 +1561,22 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     choose_igemm(k, &bm, &bn);
     const int wm = (bm == 128 && bn == 128) ? 2 : ((bm == 64 && bn != 48) ? 2 : 4);
     const bool dma = k.pro_a == nullptr && k.skip == nullptr;
-    snprintf(buf, buflen, "conv_igemm%s_kernel<%s,%d,%d,%d,%d>", dma ? "_dma" : "", t, bm, bn, wm, 4 / wm);
+    snprintf(buf, buflen, "conv_igemm%s_kernel<%s,%d,%d,%d,%d>",
+             dma ? (g_tuning[HDU_TUNE_DMA_STAGES] == 3 ? "_dma3" : "_dma") : "", t, bm, bn, wm, 4 / wm);
   }
   return 0;
+}
+
+extern "C" int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, const float* master_base,
+                                       void* wc_base, void* stream) {
+  if (!table || n <= 0 || !master_base || !wc_base) return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad args");
+  if (dtype == HDU_BF16)
+    HDU_LAUNCH((weight_prep_batched_kernel<bf16_t>), dim3(48, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table,
+               master_base, (bf16_t*)wc_base);
+  else if (dtype == HDU_F32)
+    HDU_LAUNCH((weight_prep_batched_kernel<float>), dim3(48, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table,
+               master_base, (float*)wc_base);
+  else
+    return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad dtype");
+  return hdu_check_launch("weight_prep_batched");
 }

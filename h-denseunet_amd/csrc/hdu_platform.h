@@ -165,6 +165,16 @@ __device__ __forceinline__ void hdu_glds16(const void* gsrc, char* lds_wave_base
 #endif
 }
 
+// raw workgroup barrier / counted vector-memory wait (lets async LDS-DMA tiles stay in flight across a barrier;
+// __syncthreads() would drain them with vmcnt(0)).  LDS traffic is still fenced with lgkmcnt(0).
+#ifdef HDU_EMU
+#define HDU_WAIT_VMCNT(n) do { } while (0)
+#define HDU_RAW_BARRIER() __syncthreads()
+#else
+#define HDU_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define HDU_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#endif
+
 // counter-based hash RNG for dropout masks (stateless; fwd and bwd regenerate the same mask)
 __host__ __device__ __forceinline__ unsigned hdu_hash32(unsigned long long idx, unsigned seed) {
   unsigned h = (unsigned)idx * 0x9E3779B1u;

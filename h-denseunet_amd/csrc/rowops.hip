@@ -89,17 +89,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
 }
 
 // sums the per-block partials (double accumulation) and post-processes per mode.
-// 256 threads = 32 channels x 8 partial lanes: lane p strides over the row blocks, then an LDS tree over the lanes.
+// 256 threads = 8 channels x 32 partial lanes: lane p strides over the row blocks, then an LDS tree over the lanes.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                               long long M, const void* x, float* __restrict__ o1,
                                                               float* __restrict__ o2) {
-  __shared__ double red[2][8][32];
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ double red[2][32][8];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int b = pl; b < nblk; b += 8) {
+    for (int b = pl; b < nblk; b += 32) {
       a1 += (double)partial[((long long)b * 2 + 0) * C + c];
       if (MODE != RED_COLSUM) a2 += (double)partial[((long long)b * 2 + 1) * C + c];
     }
@@ -107,9 +107,16 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   red[0][pl][cl] = a1;
   red[1][pl][cl] = a2;
   __syncthreads();
+  for (int s = 16; s > 0; s >>= 1) {
+    if (pl < s) {
+      red[0][pl][cl] += red[0][pl + s][cl];
+      red[1][pl][cl] += red[1][pl + s][cl];
+    }
+    __syncthreads();
+  }
   if (pl == 0 && c < C) {
-#pragma unroll
-    for (int p = 1; p < 8; ++p) { a1 += red[0][p][cl]; a2 += red[1][p][cl]; }
+    a1 = red[0][0][cl];
+    a2 = red[1][0][cl];
     if (MODE == RED_STATS) {
       const double shift = (double)Chunk<T>::load1((const T*)x + c);
       const double m1 = a1 / (double)M;
@@ -183,7 +190,7 @@ static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_
     return hdu_set_error(HDU_ERR_WORKSPACE, "reduce: workspace too small (see hdu_reduce_ws_bytes)");
   k.rows_per_block = rpb;
   k.partial = (float*)ws;
-  const unsigned fb = (unsigned)((k.C + 31) / 32);
+  const unsigned fb = (unsigned)((k.C + 7) / 8);
   if (dtype == HDU_BF16) {
     run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
     HDU_LAUNCH((reduce_finalize_kernel<bf16_t, MODE>), dim3(fb), dim3(256), 0, s, (const float*)ws, (int)gx, k.C,
@@ -553,6 +560,7 @@ struct PoolK {
   const void* x;
   const void* dy;
   void* out;
+  unsigned char* idx;
   long long ldx, lddy, ldo;
   int N, D, H, W, C;      // input dims
   int Do, Ho, Wo;
@@ -560,6 +568,8 @@ struct PoolK {
   int ud, uh, uw;
 };
 
+// forward: also records, per output element, which window tap won (255 = the zero padding): the backward pass
+// then needs one byte + the output gradient per covering window instead of re-reading the whole window.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolK p) {
   constexpr int CH = Chunk<T>::CH;
@@ -578,9 +588,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolK p) {
     const int od = (int)(t % p.Do);
     const int n = (int)(t / p.Do);
     float best[CH];
+    int bi[CH];
     bool any_pad = false;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) best[j] = -3.0e38f;
+    for (int j = 0; j < CH; ++j) { best[j] = -3.0e38f; bi[j] = 255; }
     for (int kd = 0; kd < kdn; ++kd) {
       const int id = od * sdd - pdd + kd;
       for (int kh = 0; kh < 3; ++kh) {
@@ -590,8 +601,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolK p) {
           if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
             float f[CH];
             Chunk<T>::unpack(*(const u32x4*)(xp + ((((long long)n * p.D + id) * p.H + ih) * p.W + iw) * p.ldx + c0), f);
+            const int tap = (kd * 3 + kh) * 3 + kw;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) best[j] = f[j] > best[j] ? f[j] : best[j];
+            for (int j = 0; j < CH; ++j) {
+              if (f[j] > best[j]) { best[j] = f[j]; bi[j] = tap; }
+            }
           } else {
             any_pad = true;
           }
@@ -600,23 +614,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolK p) {
     }
     if (any_pad) {
 #pragma unroll
-      for (int j = 0; j < CH; ++j) best[j] = best[j] > 0.f ? best[j] : 0.f;  // the explicit zero padding competes
+      for (int j = 0; j < CH; ++j) {
+        if (!(best[j] > 0.f)) { best[j] = 0.f; bi[j] = 255; }   // the explicit zero padding competes (and wins ties)
+      }
     }
     *(u32x4*)(op + opix * p.ldo + c0) = Chunk<T>::pack(best);
+    if (p.idx) {
+      unsigned char* ip = p.idx + opix * p.C + c0;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) ip[j] = (unsigned char)bi[j];
+    }
   }
 }
 
-// gather form of the max-pool gradient: each input pixel visits the <=2 (x2 x2) windows covering it and takes
-// the window's gradient iff it is the first maximal element of that window in scan order.
+// backward from the recorded argmax: each input pixel visits the <=2 (x2 x2) windows covering it.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolK p) {
   constexpr int CH = Chunk<T>::CH;
   const int ncc = p.C / CH;
   const long long total = (long long)p.N * p.D * p.H * p.W * ncc;
-  const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ dyp = (const T*)p.dy;
   T* __restrict__ op = (T*)p.out;
-  const int kdn = p.D == 1 ? 1 : 3, pdd = p.D == 1 ? 0 : 1, sdd = p.D == 1 ? 1 : 2;
+  const int pdd = p.D == 1 ? 0 : 1, sdd = p.D == 1 ? 1 : 2;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(q % ncc) * CH;
@@ -626,47 +645,22 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolK p) {
     const int ih = (int)(t % p.H); t /= p.H;
     const int id = (int)(t % p.D);
     const int n = (int)(t / p.D);
-    float me[CH], acc[CH];
-    Chunk<T>::unpack(*(const u32x4*)(xp + ipix * p.ldx + c0), me);
+    float acc[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[j] = 0.f;
-    const int od_lo = p.D == 1 ? 0 : (id > 0 ? (id - 1 + 1) / 2 : 0), od_hi = p.D == 1 ? 0 : (id + 1) / 2;
+    const int od_lo = p.D == 1 ? 0 : id / 2, od_hi = p.D == 1 ? 0 : (id + 1) / 2;
     const int oh_lo = ih / 2, oh_hi = (ih + 1) / 2;
     const int ow_lo = iw / 2, ow_hi = (iw + 1) / 2;
     for (int od = od_lo; od <= od_hi && od < p.Do; ++od)
       for (int oh = oh_lo; oh <= oh_hi && oh < p.Ho; ++oh)
         for (int ow = ow_lo; ow <= ow_hi && ow < p.Wo; ++ow) {
-          // recompute the window: is `me` its first maximum?
-          bool win[CH];
-#pragma unroll
-          for (int j = 0; j < CH; ++j) win[j] = true;
-          bool before = true;
-          for (int kd = 0; kd < kdn; ++kd) {
-            const int jd = od * sdd - pdd + kd;
-            for (int kh = 0; kh < 3; ++kh) {
-              const int jh = oh * 2 - 1 + kh;
-              for (int kw = 0; kw < 3; ++kw) {
-                const int jw = ow * 2 - 1 + kw;
-                const bool inb = (unsigned)jd < (unsigned)p.D && (unsigned)jh < (unsigned)p.H && (unsigned)jw < (unsigned)p.W;
-                if (inb && jd == id && jh == ih && jw == iw) { before = false; continue; }
-                float f[CH];
-                if (inb) {
-                  Chunk<T>::unpack(*(const u32x4*)(xp + ((((long long)n * p.D + jd) * p.H + jh) * p.W + jw) * p.ldx + c0), f);
-                } else {
-#pragma unroll
-                  for (int j = 0; j < CH; ++j) f[j] = 0.f;  // padding element
-                }
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                  if (before ? (f[j] >= me[j]) : (f[j] > me[j])) win[j] = false;
-                }
-              }
-            }
-          }
+          const int tap = ((id - (od * sdd - pdd)) * 3 + (ih - (oh * 2 - 1))) * 3 + (iw - (ow * 2 - 1));
+          const long long opix = (((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow;
+          const unsigned char* ip = p.idx + opix * p.C + c0;
           float g[CH];
-          Chunk<T>::unpack(*(const u32x4*)(dyp + ((((long long)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.lddy + c0), g);
+          Chunk<T>::unpack(*(const u32x4*)(dyp + opix * p.lddy + c0), g);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[j] += win[j] ? g[j] : 0.f;
+          for (int j = 0; j < CH; ++j) acc[j] += (ip[j] == tap) ? g[j] : 0.f;
         }
     T* dst = op + ipix * p.ldo + c0;
     if (p.accumulate) {
@@ -801,8 +795,9 @@ static int poolk_check(int dtype, const PoolK& k, const char* what) {
   } while (0)
 
 extern "C" int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
-                                  int64_t ldy, void* stream) {
+                                  int64_t ldy, uint8_t* argmax, void* stream) {
   PoolK k{};
+  k.idx = argmax;
   k.x = x; k.ldx = ldx; k.out = y; k.ldo = ldy; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
   k.Do = D == 1 ? 1 : (D - 1) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1;
   if (!x || !y) return hdu_set_error(HDU_ERR_ARG, "maxpool_fwd: null pointer");
@@ -811,12 +806,15 @@ extern "C" int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, 
   return hdu_check_launch("maxpool_fwd");
 }
 
-extern "C" int hdu_maxpool3s2_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, int N, int D,
+extern "C" int hdu_maxpool3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, int64_t lddy, int N, int D,
                                   int H, int W, int C, void* dx, int64_t lddx, int accumulate, void* stream) {
   PoolK k{};
-  k.x = x; k.ldx = ldx; k.dy = dy; k.lddy = lddy; k.out = dx; k.ldo = lddx; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
+  const void* x = argmax;
+  const int64_t ldx = 16;
+  k.idx = const_cast<uint8_t*>(argmax);
+  k.ldx = ldx; k.dy = dy; k.lddy = lddy; k.out = dx; k.ldo = lddx; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
   k.Do = D == 1 ? 1 : (D - 1) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1; k.accumulate = accumulate;
-  if (!x || !dy || !dx) return hdu_set_error(HDU_ERR_ARG, "maxpool_bwd: null pointer");
+  if (!x || !dy || !dx) return hdu_set_error(HDU_ERR_ARG, "maxpool_bwd: null pointer (argmax / dy / dx)");
   if (int e = poolk_check(dtype, k, "maxpool_bwd: bad dims / strides")) return e;
   HDU_POOL_LAUNCH(maxpool_bwd_kernel, (long long)N * D * H * W);
   return hdu_check_launch("maxpool_bwd");

@@ -176,6 +176,7 @@ class Ctx:
         self.init_weights(seed)
         for cv in self.convs:
             cv.bind()
+        self._build_prep_table()
         self.finalized = True
 
     def init_weights(self, seed):
@@ -251,8 +252,24 @@ class Ctx:
 
     # ---------------- step pieces
     def prep_weights(self):
+        """float32 master filters -> compute-dtype forward / data-gradient copies, all layers in one launch"""
+        if self._prep_n:
+            ops.weight_prep_batched(self.dtype, self._prep_table, self._prep_n, self.P, self.Wc)
+
+    def _build_prep_table(self):
+        from .lib import PrepEntry
+        ents = []
         for cv in self.convs:
-            cv.prep()
+            wf = -1 if self.dtype == HDU_F32 else cv.wf_off
+            wd = cv.wd_off if cv.need_dgrad_filter else -1
+            if wf < 0 and wd < 0:
+                continue
+            ents.append(PrepEntry(cv.kernel.offset, wf, wd, cv.cout_p, cv.T, cv.cin_p, 0))
+        self._prep_n = len(ents)
+        if ents:
+            arr = (PrepEntry * len(ents))(*ents)
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self._prep_table = torch.from_numpy(raw).to(self.dev)
 
     def run_forward(self):
         for f in self.fwd:
@@ -547,12 +564,14 @@ class MaxPoolLayer:
         assert (self.out.act.N, self.out.act.D, self.out.act.H, self.out.act.W) == dims
         if ctx.grad_enabled:
             self.out.require_grad()
-        ctx.fwd.append(lambda: ops.maxpool_fwd(self.x.act, self.out.act))
+        oa = self.out.act
+        self.argmax = torch.zeros(oa.M * a.C, dtype=torch.uint8, device=ctx.dev) if self.x.root.needs_grad else None
+        ctx.fwd.append(lambda: ops.maxpool_fwd(self.x.act, self.out.act, self.argmax))
         ctx.bwd.append(self.backward)
 
     def backward(self):
         if self.out.root.needs_grad and self.x.root.needs_grad:
-            ops.maxpool_bwd(self.x.act, self.out.grad, self.x.grad, self.x.grad_mode())
+            ops.maxpool_bwd(self.argmax, self.out.grad, self.x.grad, self.x.grad_mode())
 
 
 class AvgPoolLayer:

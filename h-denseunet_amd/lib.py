@@ -41,15 +41,22 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class PrepEntry(ctypes.Structure):
+    _fields_ = [("master_off", c_i64), ("w_f_off", c_i64), ("w_d_off", c_i64),
+                ("Cout", ctypes.c_int32), ("T", ctypes.c_int32), ("Cin", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
 _SIGS = {
     "hdu_last_error": (ctypes.c_char_p, []),
     "hdu_backend": (ctypes.c_char_p, []),
     "hdu_abi_version": (c_int, []),
+    "hdu_set_tuning": (c_int, [c_int, c_int]),
     "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
     "hdu_weight_prep": (c_int, [c_int, c_p, c_int, c_int, c_int, c_p, c_p, c_p]),
+    "hdu_weight_prep_batched": (c_int, [c_int, c_p, c_int, c_p, c_p, c_p]),
     "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
     "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),
     "hdu_bn_fold": (c_int, [c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
@@ -63,9 +70,8 @@ _SIGS = {
     "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
                                 c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
-    "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),
-    "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64,
-                                   c_int, c_p]),
+    "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_p]),
+    "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_p]),
     "hdu_avgpool2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),
     "hdu_avgpool2_bwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_p]),
     "hdu_upsample_bwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p,
@@ -120,6 +126,8 @@ def load(path=None):
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
     _lib = _bind(path)
     _backend = _lib.hdu_backend().decode()
+    if "HDU_DMA_STAGES" in os.environ:      # developer knob (A/B of the LDS ring depth)
+        _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
     return _lib
 
 

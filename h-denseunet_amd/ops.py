@@ -138,6 +138,11 @@ def weight_prep(dtype, w_master, Cout, T, Cin, w_f, w_d):
           "hdu_weight_prep")
 
 
+def weight_prep_batched(dtype, table_dev, n, master, wc):
+    check(_l.get().hdu_weight_prep_batched(dtype, ctypes.c_void_p(table_dev.data_ptr()), n, fptr(master),
+                                           ctypes.c_void_p(wc.data_ptr()), stream()), "hdu_weight_prep_batched")
+
+
 class Workspace:
     """Reduction scratch shared by all stats / loss calls of one model (stream-ordered reuse)."""
 
@@ -202,14 +207,16 @@ def colsum(x, out, ws):
     check(_l.get().hdu_colsum(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(out), ws.ptr, ws.nbytes, stream()), "hdu_colsum")
 
 
-def maxpool_fwd(x, y):
-    check(_l.get().hdu_maxpool3s2_fwd(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, y.ptr, y.ld, stream()),
+def maxpool_fwd(x, y, argmax=None):
+    check(_l.get().hdu_maxpool3s2_fwd(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, y.ptr, y.ld,
+                                      ctypes.c_void_p(argmax.data_ptr()) if argmax is not None else None, stream()),
           "hdu_maxpool3s2_fwd")
 
 
-def maxpool_bwd(x, dy, dx, accumulate=False):
-    check(_l.get().hdu_maxpool3s2_bwd(x.dtype, x.ptr, x.ld, dy.ptr, dy.ld, x.N, x.D, x.H, x.W, x.C, dx.ptr, dx.ld,
-                                      1 if accumulate else 0, stream()), "hdu_maxpool3s2_bwd")
+def maxpool_bwd(argmax, dy, dx, accumulate=False):
+    check(_l.get().hdu_maxpool3s2_bwd(dx.dtype, ctypes.c_void_p(argmax.data_ptr()), dy.ptr, dy.ld, dx.N, dx.D, dx.H,
+                                      dx.W, dx.C, dx.ptr, dx.ld, 1 if accumulate else 0, stream()),
+          "hdu_maxpool3s2_bwd")
 
 
 def avgpool_fwd(x, y):

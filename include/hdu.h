@@ -41,6 +41,9 @@ const char* hdu_last_error(void);
 /* "hip-gfx950" for the product library; "emu-x86" for the CPU test build of the same sources. */
 const char* hdu_backend(void);
 int hdu_abi_version(void);
+/* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES = LDS ring depth of the DMA implicit GEMM (2 or 3) */
+#define HDU_TUNE_DMA_STAGES 0
+int hdu_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------ convolution
  * Replaces K.layers/convolutional.py:148-182 (_Conv.call) -> TFB:3128-3165 (conv2d) /
@@ -97,6 +100,15 @@ int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, size_t bufle
 /* master float32 filters [Cout][T][Cin] -> compute-dtype copies: w_f (same layout) and, if w_d != NULL,
  * the data-gradient filter w_d [Cin][T flipped][Cout]. */
 int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, void* w_f, void* w_d, void* stream);
+
+/* all layers of a model in ONE launch: `table` is a device array of n hdu_prep_entry (element offsets into the flat
+ * float32 master buffer and into the flat compute-dtype filter buffer; w_f_off / w_d_off < 0 = not wanted). */
+typedef struct hdu_prep_entry {
+  int64_t master_off, w_f_off, w_d_off;
+  int32_t Cout, T, Cin, pad_;
+} hdu_prep_entry;
+int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, const float* master_base, void* wc_base,
+                            void* stream);
 
 /* ------------------------------------------------------------------ batch normalisation
  * K.layers/normalization.py:126-190 -> TFB:1620-1664 (normalize_batch_in_training = tf.nn.moments +
@@ -156,9 +168,10 @@ int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* o
  * padding takes part in the max (denseunet.py:169-170, denseunet3d.py:135-136).  D==1 selects the 2D window.
  * Avg pool: 2x2 stride 2 over (H,W); depth is not pooled (denseunet3d.py:102). */
 int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
-                       int64_t ldy, void* stream);
-int hdu_maxpool3s2_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, int N, int D, int H,
-                       int W, int C, void* dx, int64_t lddx, int accumulate, void* stream);
+                       int64_t ldy, uint8_t* argmax /* optional [N*Do*Ho*Wo][C]: winning tap, 255 = padding */,
+                       void* stream);
+int hdu_maxpool3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, int64_t lddy, int N, int D, int H, int W,
+                       int C, void* dx, int64_t lddx, int accumulate, void* stream);
 int hdu_avgpool2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
                      int64_t ldy, void* stream);
 int hdu_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, int N, int D, int H, int W, int C, void* dx,

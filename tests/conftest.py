@@ -58,3 +58,10 @@ def hdu(request):
     if request.param == "emu":
         return request.getfixturevalue("emu_lib")
     return request.getfixturevalue("hip_lib")
+
+
+@pytest.fixture(params=[2, 3], ids=["dma2", "dma3"])
+def dma_stages(request):
+    """run a test under both LDS ring depths of the DMA implicit GEMM"""
+    lib = hdu_pkg().lib
+    yield request.param

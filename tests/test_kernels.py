@@ -173,9 +173,10 @@ def test_conv_wgrad(hdu, cs, dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES if c["s"] == (1, 1, 1)])
-def test_conv_dgrad_via_fprop(hdu, cs, dtype):
+def test_conv_dgrad_via_fprop(hdu, cs, dtype, dma_stages):
     """data gradient of a stride-1 conv = fprop with the flipped/transposed filter from hdu_weight_prep"""
     ops = ops_mod()
+    hdu.lib.get().hdu_set_tuning(0, dma_stages)
     import ctypes
     K, p, up = cs["K"], cs["p"], cs["up"]
     N, D, H, W, Cin, Cout = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cin"], cs["Cout"]
@@ -197,6 +198,7 @@ def test_conv_dgrad_via_fprop(hdu, cs, dtype):
     xe = torch.zeros((N, De, He, We, Cin), dtype=torch.float64, requires_grad=True)
     y = ref_conv(xe, q(w, dtype), (1, 1, 1), p, None)
     (y * dy).sum().backward()
+    hdu.lib.get().hdu_set_tuning(0, 2)
     assert_close(dxe.to_torch().cpu(), xe.grad, dtype, what="dgrad")
 
 
@@ -344,7 +346,8 @@ def test_maxpool(hdu, dtype, dims):
     Do = 1 if D == 1 else (D - 1) // 2 + 1
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = ops.Act.alloc(N, Do, Ho, Wo, C, dtype)
-    ops.maxpool_fwd(xa, y)
+    amax = torch.zeros(N * Do * Ho * Wo * C, dtype=torch.uint8, device=ops.device())
+    ops.maxpool_fwd(xa, y, amax)
     xr = x.clone().requires_grad_(True)
     xp = xr.permute(0, 4, 1, 2, 3)
     if D == 1:
@@ -357,7 +360,7 @@ def test_maxpool(hdu, dtype, dims):
     dy = rnd((N, Do, Ho, Wo, C), 5, 1.0, dtype)
     (yr * dy).sum().backward()
     dx = ops.Act.alloc(N, D, H, W, C, dtype)
-    ops.maxpool_bwd(xa, mkact(ops, dy, dtype), dx)
+    ops.maxpool_bwd(amax, mkact(ops, dy, dtype), dx)
     got = dx.to_torch().cpu().double()
     # ties only happen at exactly 0 (post-ReLU) where the upstream ReLU kills the gradient: compare where x>0
     nz = x > 0
