@@ -1311,23 +1311,47 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   }
 }
 
+// One workgroup per 32x32 (Cout x Cin) tile of one tap of one layer: coalesced read of the float32 master along
+// Cin, coalesced write of the forward copy, LDS transpose, coalesced write of the data-gradient copy along Cout.
+// tile_begin[] (in the table) maps blockIdx.x to its layer by binary search.
 template <typename T>
-__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep_entry* __restrict__ table,
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep_entry* __restrict__ table, int n,
                                                                  const float* __restrict__ master, T* __restrict__ wc) {
-  const hdu_prep_entry e = table[blockIdx.y];
-  const long long total = (long long)e.Cout * e.T * e.Cin;
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hdu_prep_entry e = table[lo];
+  const int t_local = (int)(blockIdx.x - e.tile_begin);
+  const int nci = (e.Cin + 31) / 32, nco = (e.Cout + 31) / 32;
+  const int cib = t_local % nci;
+  const int cob = (t_local / nci) % nco;
+  const int tap = t_local / (nci * nco);
   const float* wm = master + e.master_off;
   T* wf = e.w_f_off >= 0 ? wc + e.w_f_off : nullptr;
   T* wd = e.w_d_off >= 0 ? wc + e.w_d_off : nullptr;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (long long)gridDim.x * blockDim.x) {
-    const int ci = (int)(q % e.Cin);
-    const long long t2 = q / e.Cin;
-    const int t = (int)(t2 % e.T);
-    const int co = (int)(t2 / e.T);
-    const float v = wm[q];
-    if (wf) Chunk<T>::store1(wf + q, v);
-    if (wd) Chunk<T>::store1(wd + ((long long)ci * e.T + (e.T - 1 - t)) * e.Cout + co, v);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = cob * 32 + r, ci = cib * 32 + tx;
+    float v = 0.f;
+    if (co < e.Cout && ci < e.Cin) {
+      const long long q = ((long long)co * e.T + tap) * e.Cin + ci;
+      v = wm[q];
+      if (wf) Chunk<T>::store1(wf + q, v);
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wd) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = cib * 32 + r, co = cob * 32 + tx;
+      if (co < e.Cout && ci < e.Cin)
+        Chunk<T>::store1(wd + ((long long)ci * e.T + (e.T - 1 - tap)) * e.Cout + co, tile[tx][r]);
+    }
   }
 }
 
@@ -1567,15 +1591,16 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   return 0;
 }
 
-extern "C" int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, const float* master_base,
-                                       void* wc_base, void* stream) {
-  if (!table || n <= 0 || !master_base || !wc_base) return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad args");
+extern "C" int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, int64_t total_tiles,
+                                       const float* master_base, void* wc_base, void* stream) {
+  if (!table || n <= 0 || total_tiles <= 0 || !master_base || !wc_base)
+    return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad args");
   if (dtype == HDU_BF16)
-    HDU_LAUNCH((weight_prep_batched_kernel<bf16_t>), dim3(48, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table,
-               master_base, (bf16_t*)wc_base);
+    HDU_LAUNCH((weight_prep_batched_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+               table, n, master_base, (bf16_t*)wc_base);
   else if (dtype == HDU_F32)
-    HDU_LAUNCH((weight_prep_batched_kernel<float>), dim3(48, (unsigned)n), dim3(256), 0, (hipStream_t)stream, table,
-               master_base, (float*)wc_base);
+    HDU_LAUNCH((weight_prep_batched_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+               table, n, master_base, (float*)wc_base);
   else
     return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad dtype");
   return hdu_check_launch("weight_prep_batched");

@@ -121,6 +121,10 @@ class Ctx:
         self.dropout_enabled = True
         self.grad_enabled = True
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
+        # 0 = off, 1 = every layer, 2 = only layers with <= 16384 output pixels (latency-bound on their own)
+        self.overlap_wgrad = int(os.environ.get("HDU_OVERLAP_WGRAD", "0"))
+        self._side = None
+        self.wgrad_open = False
         self.finalized = False
 
     # ---------------- parameters
@@ -254,18 +258,21 @@ class Ctx:
     def prep_weights(self):
         """float32 master filters -> compute-dtype forward / data-gradient copies, all layers in one launch"""
         if self._prep_n:
-            ops.weight_prep_batched(self.dtype, self._prep_table, self._prep_n, self.P, self.Wc)
+            ops.weight_prep_batched(self.dtype, self._prep_table, self._prep_n, self._prep_tiles, self.P, self.Wc)
 
     def _build_prep_table(self):
         from .lib import PrepEntry
         ents = []
+        tiles = 0
         for cv in self.convs:
             wf = -1 if self.dtype == HDU_F32 else cv.wf_off
             wd = cv.wd_off if cv.need_dgrad_filter else -1
             if wf < 0 and wd < 0:
                 continue
-            ents.append(PrepEntry(cv.kernel.offset, wf, wd, cv.cout_p, cv.T, cv.cin_p, 0))
+            ents.append(PrepEntry(cv.kernel.offset, wf, wd, tiles, cv.cout_p, cv.T, cv.cin_p, 0))
+            tiles += cv.T * ((cv.cout_p + 31) // 32) * ((cv.cin_p + 31) // 32)
         self._prep_n = len(ents)
+        self._prep_tiles = tiles
         if ents:
             arr = (PrepEntry * len(ents))(*ents)
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
@@ -278,8 +285,27 @@ class Ctx:
     def run_backward(self):
         for v in self.vars:
             v.written = False
+        self.wgrad_open = False
         for f in reversed(self.bwd):
             f()
+        self.join_wgrad()
+
+    # Filter gradients only feed the optimiser: they run on a side stream, concurrently with the data-gradient /
+    # BN-backward chain (forked after each dy is complete, joined once before the SGD update).  The many small
+    # late-stage layers are latency-bound on their own, so the two chains overlap almost for free.
+    def wgrad_stream(self, M=0):
+        if self.dev.type != "cuda" or not self.overlap_wgrad:
+            return None
+        if self.overlap_wgrad == 2 and M > 16384:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def join_wgrad(self):
+        if self.wgrad_open:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self.wgrad_open = False
 
 
 # ======================================================================================= layers
@@ -472,7 +498,14 @@ class ConvLayer:
                                   self.skip.act if self.skip is not None else None,
                                   (self.bn.a, self.bn.b) if self.bn is not None else None,
                                   self.bn.relu if self.bn is not None else False)
-            ops.conv_wgrad(d, self.kernel.grad)
+            side = ctx.wgrad_stream(out.act.M)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())    # dy is complete on the main stream
+                with torch.cuda.stream(side):
+                    ops.conv_wgrad(d, self.kernel.grad)
+                ctx.wgrad_open = True
+            else:
+                ops.conv_wgrad(d, self.kernel.grad)
             if self.bias is not None:
                 ops.colsum(dy, self.bias.grad, ctx.ws)
         if not self.need_input_grad:

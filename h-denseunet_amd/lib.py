@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
 
 
 class PrepEntry(ctypes.Structure):
-    _fields_ = [("master_off", c_i64), ("w_f_off", c_i64), ("w_d_off", c_i64),
+    _fields_ = [("master_off", c_i64), ("w_f_off", c_i64), ("w_d_off", c_i64), ("tile_begin", c_i64),
                 ("Cout", ctypes.c_int32), ("T", ctypes.c_int32), ("Cin", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
@@ -56,7 +56,7 @@ _SIGS = {
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
     "hdu_weight_prep": (c_int, [c_int, c_p, c_int, c_int, c_int, c_p, c_p, c_p]),
-    "hdu_weight_prep_batched": (c_int, [c_int, c_p, c_int, c_p, c_p, c_p]),
+    "hdu_weight_prep_batched": (c_int, [c_int, c_p, c_int, c_i64, c_p, c_p, c_p]),
     "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
     "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),
     "hdu_bn_fold": (c_int, [c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),

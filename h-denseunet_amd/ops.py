@@ -138,8 +138,8 @@ def weight_prep(dtype, w_master, Cout, T, Cin, w_f, w_d):
           "hdu_weight_prep")
 
 
-def weight_prep_batched(dtype, table_dev, n, master, wc):
-    check(_l.get().hdu_weight_prep_batched(dtype, ctypes.c_void_p(table_dev.data_ptr()), n, fptr(master),
+def weight_prep_batched(dtype, table_dev, n, total_tiles, master, wc):
+    check(_l.get().hdu_weight_prep_batched(dtype, ctypes.c_void_p(table_dev.data_ptr()), n, total_tiles, fptr(master),
                                            ctypes.c_void_p(wc.data_ptr()), stream()), "hdu_weight_prep_batched")
 
 

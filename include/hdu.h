@@ -102,13 +102,15 @@ int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, size_t bufle
 int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, void* w_f, void* w_d, void* stream);
 
 /* all layers of a model in ONE launch: `table` is a device array of n hdu_prep_entry (element offsets into the flat
- * float32 master buffer and into the flat compute-dtype filter buffer; w_f_off / w_d_off < 0 = not wanted). */
+ * float32 master buffer and into the flat compute-dtype filter buffer; w_f_off / w_d_off < 0 = not wanted).  Work
+ * is split in 32x32 (Cout x Cin) tiles per tap; tile_begin is the running tile count (exclusive prefix sum of
+ * T*ceil(Cout/32)*ceil(Cin/32)), total_tiles the grand total. */
 typedef struct hdu_prep_entry {
-  int64_t master_off, w_f_off, w_d_off;
+  int64_t master_off, w_f_off, w_d_off, tile_begin;
   int32_t Cout, T, Cin, pad_;
 } hdu_prep_entry;
-int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, const float* master_base, void* wc_base,
-                            void* stream);
+int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, int64_t total_tiles,
+                            const float* master_base, void* wc_base, void* stream);
 
 /* ------------------------------------------------------------------ batch normalisation
  * K.layers/normalization.py:126-190 -> TFB:1620-1664 (normalize_batch_in_training = tf.nn.moments +
