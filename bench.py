@@ -69,7 +69,7 @@ def instrumented_step(m):
             e0.record()
             fn(d, *a)
             e1.record()
-            recs.append((ops.conv_kernel_name(d, op), flops(d, op), e0, e1))
+            recs.append((ops.conv_kernel_name(d, op), flops(d, op), e0, e1, d.N * d.Do * d.Ho * d.Wo))
         return f
 
     ops.conv_fprop, ops.conv_wgrad = wrap(orig_f, 0), wrap(orig_w, 1)
@@ -82,11 +82,20 @@ def instrumented_step(m):
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w
     agg = {}
-    for name, fl, e0, e1 in recs:
+    bym = {}
+    for name, fl, e0, e1, mm in recs:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += fl
+        b = bym.setdefault(mm, [0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += e0.elapsed_time(e1)
+        b[2] += fl
+    if os.environ.get("HDU_BENCH_VERBOSE"):
+        for mm in sorted(bym):
+            b = bym[mm]
+            print("M=%8d launches=%4d ms=%7.3f TF=%6.1f" % (mm, b[0], b[1], b[2] / (b[1] * 1e-3) / 1e12), file=sys.stderr)
     return agg
 
 

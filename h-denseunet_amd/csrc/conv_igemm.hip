@@ -883,12 +883,32 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   }
 }
 
-// 3-stage ring variant: tiles t+1 and t+2 stay in flight while tile t is multiplied.  Per iteration: counted
+// NS-stage ring variant: tiles t+1 .. t+NS-1 stay in flight while tile t is multiplied.  Per iteration: counted
 // vmcnt (this wave's DMAs of tile t have landed) -> ONE raw barrier (everyone's have; everyone finished reading the
-// slot about to be refilled) -> issue tile t+2 -> MFMAs on tile t.  Every wave issues exactly A_IT + B_IT DMAs per
-// tile (invalid rows fetch the zero page) so the vmcnt immediate is uniform.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_dma3_kernel(ConvK p) {
+// slot about to be refilled) -> issue tile t+NS-1 -> MFMAs on tile t.  Every wave issues exactly A_IT + B_IT DMAs
+// per tile (invalid rows fetch the zero page) so the vmcnt immediate is uniform.  Used for small grids (< 1
+// workgroup per CU), where latency rather than occupancy limits the K loop and one workgroup may take the LDS.
+template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_n() {
+  if constexpr (N == 0) { HDU_WAIT_VMCNT(0); }
+  else if constexpr (N == 2) { HDU_WAIT_VMCNT(2); }
+  else if constexpr (N == 3) { HDU_WAIT_VMCNT(3); }
+  else if constexpr (N == 4) { HDU_WAIT_VMCNT(4); }
+  else if constexpr (N == 5) { HDU_WAIT_VMCNT(5); }
+  else if constexpr (N == 6) { HDU_WAIT_VMCNT(6); }
+  else if constexpr (N == 8) { HDU_WAIT_VMCNT(8); }
+  else if constexpr (N == 9) { HDU_WAIT_VMCNT(9); }
+  else if constexpr (N == 10) { HDU_WAIT_VMCNT(10); }
+  else if constexpr (N == 12) { HDU_WAIT_VMCNT(12); }
+  else if constexpr (N == 15) { HDU_WAIT_VMCNT(15); }
+  else if constexpr (N == 16) { HDU_WAIT_VMCNT(16); }
+  else if constexpr (N == 18) { HDU_WAIT_VMCNT(18); }
+  else if constexpr (N == 20) { HDU_WAIT_VMCNT(20); }
+  else if constexpr (N == 24) { HDU_WAIT_VMCNT(24); }
+  else { static_assert(N == 0, "add the vmcnt immediate"); }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+__global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
   constexpr int A_IT = BM / 32;
@@ -901,7 +921,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma3_kernel(ConvK p) {
   constexpr int STAGE = (BM + BNP) * 128;
   constexpr int L = A_IT + B_IT;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -999,22 +1019,20 @@ __global__ __launch_bounds__(256) void conv_igemm_dma3_kernel(ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.Ktot + BK - 1) / BK;
-  issue_tile(0);
-  if (nk > 1) issue_tile(1);
+#pragma unroll
+  for (int pre = 0; pre < NS - 1; ++pre)
+    if (pre < nk) issue_tile(pre);
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      if constexpr (L == 2) { HDU_WAIT_VMCNT(2); }
-      else if constexpr (L == 3) { HDU_WAIT_VMCNT(3); }
-      else if constexpr (L == 4) { HDU_WAIT_VMCNT(4); }
-      else if constexpr (L == 5) { HDU_WAIT_VMCNT(5); }
-      else if constexpr (L == 6) { HDU_WAIT_VMCNT(6); }
-      else { HDU_WAIT_VMCNT(8); }
-    } else {
-      HDU_WAIT_VMCNT(0);
-    }
+    // tiles issued beyond kt: min(NS-2, nk-1-kt) may stay in flight
+    const int ahead = nk - 1 - kt;
+    if (ahead >= NS - 2) hdu_wait_vmcnt_n<(NS - 2) * L>();
+    else if (NS > 3 && ahead == 1) hdu_wait_vmcnt_n<L>();
+    else if (NS > 4 && ahead == 2) hdu_wait_vmcnt_n<2 * L>();
+    else if (NS > 5 && ahead == 3) hdu_wait_vmcnt_n<3 * L>();
+    else hdu_wait_vmcnt_n<0>();
     HDU_RAW_BARRIER();
-    if (kt + 2 < nk) issue_tile(slot >= 1 ? slot - 1 : 2);   // slot (kt+2)%3
+    if (kt + NS - 1 < nk) issue_tile(slot == 0 ? NS - 1 : slot - 1);   // slot (kt+NS-1) % NS
     {
       const char* As = smem + slot * STAGE;
       const char* Bs = As + BM * 128;
@@ -1032,7 +1050,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma3_kernel(ConvK p) {
           for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
       }
     }
-    slot = slot == 2 ? 0 : slot + 1;
+    slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
   T* __restrict__ yp = (T*)p.y;
@@ -1415,8 +1433,15 @@ template <typename T, int BM, int BN, int WMv, int WNv>
 static void launch_igemm(const ConvK& k, hipStream_t s) {
   dim3 grid((unsigned)((k.M + BM - 1) / BM), (unsigned)((k.Cout + BN - 1) / BN), 1);
   if (k.pro_a == nullptr && k.skip == nullptr) {
-    if (g_tuning[HDU_TUNE_DMA_STAGES] == 3)
-      HDU_LAUNCH((conv_igemm_dma3_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+    // deep ring when the grid cannot fill the chip (latency-bound K loop, LDS is free); else 2 stages x 3 blocks/CU
+    constexpr int STAGE = (BM + ((BN + 31) / 32) * 32) * 128;
+    constexpr int NSD = STAGE * 6 <= 160 * 1024 ? 6 : 4;
+    const long long nblk = (long long)grid.x * grid.y;
+    const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
+    if (STAGE * NSD <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128)))
+      HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD>), grid, dim3(256), 0, s, k);
+    else if (mode == 3)
+      HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3>), grid, dim3(256), 0, s, k);
     else
       HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
   } else
@@ -1435,7 +1460,7 @@ static void choose_igemm(const ConvK& k, int* bm, int* bn) {
     if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = c; }
   }
   *bn = best;
-  *bm = (k.M <= 2048 && best != 128) ? 64 : 128;
+  *bm = (k.M <= 16384 && best != 128) ? 64 : 128;
 }
 
 template <typename T>
@@ -1585,8 +1610,14 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     choose_igemm(k, &bm, &bn);
     const int wm = (bm == 128 && bn == 128) ? 2 : ((bm == 64 && bn != 48) ? 2 : 4);
     const bool dma = k.pro_a == nullptr && k.skip == nullptr;
-    snprintf(buf, buflen, "conv_igemm%s_kernel<%s,%d,%d,%d,%d>",
-             dma ? (g_tuning[HDU_TUNE_DMA_STAGES] == 3 ? "_dma3" : "_dma") : "", t, bm, bn, wm, 4 / wm);
+    const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
+    const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
+    const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
+    const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;
+    const bool ring = dma && stage * nsd <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128));
+    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s,%d,%d,%d,%d,%d>", t, bm, bn, wm, 4 / wm, nsd);
+    else if (dma && mode == 3) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s,%d,%d,%d,%d,3>", t, bm, bn, wm, 4 / wm);
+    else snprintf(buf, buflen, "conv_igemm%s_kernel<%s,%d,%d,%d,%d>", dma ? "_dma" : "", t, bm, bn, wm, 4 / wm);
   }
   return 0;
 }
