@@ -1525,10 +1525,15 @@ template <int BCO>
 static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
   constexpr int PX = 64;
   const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
-  long long want = 1024 / ((long long)gx * gy);
+  // pixel splits: fill the chip (~768 workgroups) but keep >= g_tuning[1] steps per workgroup so that the
+  // pipeline fill and the float atomics of the partial tile are amortised
+  const int target = g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768;
+  long long want = target / ((long long)gx * gy);
   if (want < 1) want = 1;
   long long steps = (k.M + PX - 1) / PX;
-  if (want > steps) want = steps;
+  const int min_steps = g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] : 4;
+  if (want > (steps + min_steps - 1) / min_steps) want = (steps + min_steps - 1) / min_steps;
+  if (want < 1) want = 1;
   long long steps_per = (steps + want - 1) / want;
   const long long rows_per = steps_per * PX;
   const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);

@@ -126,8 +126,12 @@ def load(path=None):
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
     _lib = _bind(path)
     _backend = _lib.hdu_backend().decode()
-    if "HDU_DMA_STAGES" in os.environ:      # developer knob (A/B of the LDS ring depth)
+    if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
         _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_WGRAD_TARGET" in os.environ:
+        _lib.hdu_set_tuning(2, int(os.environ["HDU_WGRAD_TARGET"]))
+    if "HDU_WGRAD_MIN_STEPS" in os.environ:
+        _lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
     return _lib
 
 
