@@ -88,12 +88,59 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
   }
 }
 
+// optional per-channel epilogue of the finalize kernel (saves the separate bn_fold / bn_bwd_coef launches)
+struct FinK {
+  int kind;                 // 0 none, 1 BN fold (after RED_STATS), 2 BN backward coefficients (after RED_BNBWD)
+  const float* gamma; const float* beta; const float* sgamma; const float* sbeta;
+  float eps, momentum, invM;
+  int batch_stats;
+  float* a; float* b; float* rstd; float* mov_mean; float* mov_var;          // kind 1 outputs
+  const float* rstd_in;                                                        // kind 2 input
+  float* k1; float* k2; float* k3; float* dgamma; float* dbeta; float* dsgamma; float* dsbeta;  // kind 2 outputs
+};
+
+__device__ __forceinline__ void bn_fold_channel(int c, float mu, float v, const float* gamma, const float* beta,
+                                                float eps, const float* sgamma, const float* sbeta, float* a, float* b,
+                                                float* rstd, float* mov_mean, float* mov_var, float momentum) {
+  const float r = 1.0f / sqrtf(v + eps);
+  const float g = gamma ? gamma[c] : 1.f;
+  const float be = beta ? beta[c] : 0.f;
+  const float sg = sgamma ? sgamma[c] : 1.f;
+  const float sb = sbeta ? sbeta[c] : 0.f;
+  // tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
+  const float inv = g * r;
+  a[c] = sg * inv;
+  b[c] = sg * (be - mu * inv) + sb;
+  if (rstd) rstd[c] = r;
+  if (mov_mean) mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
+  if (mov_var) mov_var[c] -= (mov_var[c] - v) * (1.f - momentum);
+}
+
+__device__ __forceinline__ void bn_coef_channel(int c, float invM, int batch_stats, float S1, float S2,
+                                                const float* gamma, const float* beta, const float* sgamma,
+                                                const float* rstd, float* k1, float* k2, float* k3, float* dgamma,
+                                                float* dbeta, float* dsgamma, float* dsbeta) {
+  const float g = gamma ? gamma[c] : 1.f;
+  const float be = beta ? beta[c] : 0.f;
+  const float sg = sgamma ? sgamma[c] : 1.f;
+  const float r = rstd[c];
+  const float kk = sg * g * r;
+  k1[c] = kk;
+  k2[c] = batch_stats ? kk * S1 * invM : 0.f;
+  k3[c] = batch_stats ? kk * r * S2 * invM : 0.f;
+  // y = g*xhat + beta ; z = sg*y + sb :  d sg = sum g_s*y = g*S2 + beta*S1 ; d sb = S1 ; d g = sg*S2 ; d beta = sg*S1
+  if (dgamma) dgamma[c] = sg * S2;
+  if (dbeta) dbeta[c] = sg * S1;
+  if (dsgamma) dsgamma[c] = g * S2 + be * S1;
+  if (dsbeta) dsbeta[c] = S1;
+}
+
 // sums the per-block partials (double accumulation) and post-processes per mode.
 // 256 threads = 8 channels x 32 partial lanes: lane p strides over the row blocks, then an LDS tree over the lanes.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                               long long M, const void* x, float* __restrict__ o1,
-                                                              float* __restrict__ o2) {
+                                                              float* __restrict__ o2, FinK fin) {
   __shared__ double red[2][32][8];
   const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
@@ -124,9 +171,15 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
       if (var < 0.0) var = 0.0;
       o1[c] = (float)(shift + m1);
       o2[c] = (float)var;
+      if (fin.kind == 1)
+        bn_fold_channel(c, (float)(shift + m1), (float)var, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a,
+                        fin.b, fin.rstd, fin.mov_mean, fin.mov_var, fin.momentum);
     } else {
       o1[c] = (float)a1;
       if (o2) o2[c] = (float)a2;
+      if (MODE == RED_BNBWD && fin.kind == 2)
+        bn_coef_channel(c, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma, fin.beta, fin.sgamma, fin.rstd_in,
+                        fin.k1, fin.k2, fin.k3, fin.dgamma, fin.dbeta, fin.dsgamma, fin.dsbeta);
     }
   }
 }
@@ -178,7 +231,7 @@ static int run_reduce(RedK k, int cols, unsigned gx, unsigned gy, hipStream_t s)
 
 template <int MODE>
 static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_t ws_bytes, hipStream_t s,
-                        const char* what) {
+                        const char* what, FinK fin = FinK{}) {
   if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "reduce: bad dtype");
   const int ch = dtype == HDU_BF16 ? 8 : 4;
   if (k.C <= 0 || k.C % ch || k.ldx % ch || (k.dz && k.lddz % ch))
@@ -194,11 +247,11 @@ static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_
   if (dtype == HDU_BF16) {
     run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
     HDU_LAUNCH((reduce_finalize_kernel<bf16_t, MODE>), dim3(fb), dim3(256), 0, s, (const float*)ws, (int)gx, k.C,
-               k.M, k.x, o1, o2);
+               k.M, k.x, o1, o2, fin);
   } else {
     run_reduce<float, MODE>(k, cols, gx, gy, s);
     HDU_LAUNCH((reduce_finalize_kernel<float, MODE>), dim3(fb), dim3(256), 0, s, (const float*)ws, (int)gx, k.C, k.M,
-               k.x, o1, o2);
+               k.x, o1, o2, fin);
   }
   return hdu_check_launch(what);
 }
@@ -209,6 +262,37 @@ extern "C" int hdu_bn_stats(int dtype, const void* x, int64_t ldx, int64_t M, in
   RedK k{};
   k.x = x; k.ldx = ldx; k.M = M; k.C = C;
   return reduce_entry<RED_STATS>(dtype, k, mean, var, ws, ws_bytes, (hipStream_t)stream, "bn_stats");
+}
+
+extern "C" int hdu_bn_stats_fold(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* mean, float* var,
+                                 const float* gamma, const float* beta, float eps, const float* sgamma,
+                                 const float* sbeta, float* a, float* b, float* rstd, float* mov_mean, float* mov_var,
+                                 float momentum, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !mean || !var || !a || !b) return hdu_set_error(HDU_ERR_ARG, "bn_stats_fold: null pointer");
+  RedK k{};
+  k.x = x; k.ldx = ldx; k.M = M; k.C = C;
+  FinK f{};
+  f.kind = 1; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.sbeta = sbeta; f.eps = eps; f.momentum = momentum;
+  f.a = a; f.b = b; f.rstd = rstd; f.mov_mean = mov_mean; f.mov_var = mov_var;
+  return reduce_entry<RED_STATS>(dtype, k, mean, var, ws, ws_bytes, (hipStream_t)stream, "bn_stats_fold", f);
+}
+
+extern "C" int hdu_bn_bwd_reduce_coef(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
+                                      int C, const float* a, const float* b, int relu, const float* mean,
+                                      const float* rstd, int batch_stats, const float* gamma, const float* beta,
+                                      const float* sgamma, float* s1, float* s2, float* k1, float* k2, float* k3,
+                                      float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  if (!dz || !x || !a || !b || !mean || !rstd || !s1 || !s2 || !k1 || !k2 || !k3)
+    return hdu_set_error(HDU_ERR_ARG, "bn_bwd_reduce_coef: null pointer");
+  RedK k{};
+  k.x = x; k.ldx = ldx; k.dz = dz; k.lddz = lddz; k.M = M; k.C = C;
+  k.a = a; k.b = b; k.mean = mean; k.rstd = rstd; k.relu = relu;
+  FinK f{};
+  f.kind = 2; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.rstd_in = rstd; f.invM = 1.0f / (float)M;
+  f.batch_stats = batch_stats; f.k1 = k1; f.k2 = k2; f.k3 = k3;
+  f.dgamma = dgamma; f.dbeta = dbeta; f.dsgamma = dsgamma; f.dsbeta = dsbeta;
+  return reduce_entry<RED_BNBWD>(dtype, k, s1, s2, ws, ws_bytes, (hipStream_t)stream, "bn_bwd_reduce_coef", f);
 }
 
 extern "C" int hdu_bn_bwd_reduce(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
@@ -236,19 +320,7 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(int C, const float* mean, 
                                                       float* mov_mean, float* mov_var, float momentum) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float mu = mean[c], v = var[c];
-  const float r = 1.0f / sqrtf(v + eps);
-  const float g = gamma ? gamma[c] : 1.f;
-  const float be = beta ? beta[c] : 0.f;
-  const float sg = sgamma ? sgamma[c] : 1.f;
-  const float sb = sbeta ? sbeta[c] : 0.f;
-  // tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
-  const float inv = g * r;
-  a[c] = sg * inv;
-  b[c] = sg * (be - mu * inv) + sb;
-  if (rstd) rstd[c] = r;
-  if (mov_mean) mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
-  if (mov_var) mov_var[c] -= (mov_var[c] - v) * (1.f - momentum);
+  bn_fold_channel(c, mean[c], var[c], gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum);
 }
 
 extern "C" int hdu_bn_fold(int C, const float* mean, const float* var, const float* gamma, const float* beta,
@@ -267,20 +339,8 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(int C, float invM, int
                                                           float* dsgamma, float* dsbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float g = gamma ? gamma[c] : 1.f;
-  const float be = beta ? beta[c] : 0.f;
-  const float sg = sgamma ? sgamma[c] : 1.f;
-  const float r = rstd[c];
-  const float S1 = s1 ? s1[c] : 0.f, S2 = s2 ? s2[c] : 0.f;
-  const float kk = sg * g * r;
-  k1[c] = kk;
-  k2[c] = batch_stats ? kk * S1 * invM : 0.f;
-  k3[c] = batch_stats ? kk * r * S2 * invM : 0.f;
-  // y = g*xhat + beta ; z = sg*y + sb :  d sg = sum g_s*y = g*S2 + beta*S1 ; d sb = S1 ; d g = sg*S2 ; d beta = sg*S1
-  if (dgamma) dgamma[c] = sg * S2;
-  if (dbeta) dbeta[c] = sg * S1;
-  if (dsgamma) dsgamma[c] = g * S2 + be * S1;
-  if (dsbeta) dsbeta[c] = S1;
+  bn_coef_channel(c, invM, batch_stats, s1 ? s1[c] : 0.f, s2 ? s2[c] : 0.f, gamma, beta, sgamma, rstd, k1, k2, k3,
+                  dgamma, dbeta, dsgamma, dsbeta);
 }
 
 extern "C" int hdu_bn_bwd_coef(int C, int64_t M, int batch_stats, const float* s1, const float* s2,

@@ -109,6 +109,7 @@ class Ctx:
         self.bwd = []          # appended in forward order, executed reversed
         self.vars = []
         self.learning_phase = 1
+        self.pass_id = 0
         self.P = self.G = self.V = None
         self.n_trainable = 0
         self.convs = []
@@ -279,6 +280,7 @@ class Ctx:
             self._prep_table = torch.from_numpy(raw).to(self.dev)
 
     def run_forward(self):
+        self.pass_id += 1
         for f in self.fwd:
             f()
 
@@ -331,6 +333,7 @@ class BNLayer:
         self.s1, self.s2, self.k1, self.k2, self.k3 = v(C), v(C), v(C), v(C), v(C)
         self.mean_used = None
         self.batch_now = False
+        self.folded_pass = -1
 
     def any_trainable(self):
         return self.trainable or (self.sg is not None and self.scale_trainable)
@@ -343,6 +346,8 @@ class BNLayer:
         sg = self.sg.data if self.sg else None
         sb = self.sb.data if self.sb else None
         self.batch_now = self.mode == "batch" and ctx.learning_phase == 1
+        if self.batch_now and self.folded_pass == ctx.pass_id:
+            return   # the statistics reduction of this pass already folded this BN (StatsOp.fused)
         if self.batch_now:
             mean, var = xvar.stats()
             ops.bn_fold(self.C, mean, var, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a, self.b,
@@ -358,14 +363,17 @@ class BNLayer:
         ctx = self.ctx
         x = xvar.act
         need_sums = self.batch_now or self.any_trainable()
-        if need_sums:
-            ops.bn_bwd_reduce(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.s1, self.s2, ctx.ws)
         tr_bn = self.trainable
         tr_sc = self.sg is not None and self.scale_trainable
-        ops.bn_bwd_coef(self.C, x.M, self.batch_now, self.s1 if need_sums else None, self.s2 if need_sums else None,
-                        self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.rstd, self.k1,
-                        self.k2, self.k3, self.gamma.grad if tr_bn else None, self.beta.grad if tr_bn else None,
-                        self.sg.grad if tr_sc else None, self.sb.grad if tr_sc else None)
+        if need_sums:   # reduction + coefficients + parameter gradients: two launches
+            ops.bn_bwd_reduce_coef(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.batch_now,
+                                   self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.s1,
+                                   self.s2, self.k1, self.k2, self.k3, self.gamma.grad if tr_bn else None,
+                                   self.beta.grad if tr_bn else None, self.sg.grad if tr_sc else None,
+                                   self.sb.grad if tr_sc else None, ctx.ws)
+        else:
+            ops.bn_bwd_coef(self.C, x.M, False, None, None, self.gamma.data, self.beta.data,
+                            self.sg.data if self.sg else None, self.rstd, self.k1, self.k2, self.k3)
         if xvar.root.needs_grad:
             acc = xvar.grad_mode()
             drop = xvar.root.drop if (ctx.dropout_enabled and ctx.learning_phase == 1) else None
@@ -549,18 +557,35 @@ class ConvLayer:
 
 
 class StatsOp:
-    """tf.nn.moments of a freshly written tensor / slab, once, shared by every consumer BN."""
+    """tf.nn.moments of a freshly written tensor / slab, once, shared by every consumer BN.  When the tensor has a
+    single batch-stat consumer BN over exactly these channels, `fuse(bn)` folds it in the same two launches."""
 
     def __init__(self, ctx, var):
         self.ctx, self.var = ctx, var
+        self.fused = None
         ctx.need_ws(var.act.M, var.C)
         var.stats()
         ctx.fwd.append(self.forward)
 
+    def fuse(self, bn):
+        assert bn.C == self.var.C and bn.mode == "batch"
+        self.fused = bn
+        return self
+
     def forward(self):
-        if self.ctx.learning_phase == 1:
-            mean, var = self.var.stats()
-            ops.bn_stats(self.var.act, mean, var, self.ctx.ws)
+        ctx = self.ctx
+        if ctx.learning_phase != 1:
+            return
+        mean, var = self.var.stats()
+        bn = self.fused
+        if bn is None:
+            ops.bn_stats(self.var.act, mean, var, ctx.ws)
+            return
+        ops.bn_stats_fold(self.var.act, mean, var, bn.gamma.data, bn.beta.data, bn.eps,
+                          bn.sg.data if bn.sg else None, bn.sb.data if bn.sb else None, bn.a, bn.b, bn.rstd,
+                          bn.mm.data, bn.mv.data, bn.momentum, ctx.ws)
+        bn.mean_used = mean
+        bn.folded_pass = ctx.pass_id
 
 
 class MaterializeLayer:

@@ -60,6 +60,10 @@ _SIGS = {
     "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
     "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),
     "hdu_bn_fold": (c_int, [c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "hdu_bn_stats_fold": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p,
+                                  c_p, c_f, c_p, c_sz, c_p]),
+    "hdu_bn_bwd_reduce_coef": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_int,
+                                       c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
     "hdu_bn_bwd_reduce": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
                                   c_p, c_sz, c_p]),
     "hdu_bn_bwd_coef": (c_int, [c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,

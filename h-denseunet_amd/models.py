@@ -15,8 +15,15 @@ EPS_DENSE = 1.1e-5
 
 
 def _stats(ctx, var, mode):
+    """returns the StatsOp (or None) so that a unique consumer BN can be fused into it"""
     if mode == "batch":
-        StatsOp(ctx, var)
+        return StatsOp(ctx, var)
+    return None
+
+
+def _fuse(st, bn):
+    if st is not None and bn.mode == "batch":
+        st.fuse(bn)
 
 
 def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 36, 24), growth=48,
@@ -41,8 +48,9 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
     nb_filter = 96
     conv1 = ConvLayer(ctx, "conv1", x_in, nb_filter, (1, 7, 7), (1, 2, 2), (0, 3, 3), use_bias=False,
                       trainable=tr_conv, cin_logical=3)
-    _stats(ctx, conv1.out, mode)
+    st = _stats(ctx, conv1.out, mode)
     bn1 = bn_dense("conv1", nb_filter)
+    _fuse(st, bn1)
     z0 = MaterializeLayer(ctx, conv1.out, bn1).out          # relu1 = box[0]
     box = [z0]
 
@@ -53,8 +61,9 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
             bn_a = bn_dense(base + "_x1", c)
             c1 = ConvLayer(ctx, base + "_x1", buf.slab(0, c), growth * 4, (1, 1, 1), bn=bn_a, use_bias=False,
                            trainable=tr_conv)
-            _stats(ctx, c1.out, mode)
+            st = _stats(ctx, c1.out, mode)
             bn_b = bn_dense(base + "_x2", growth * 4)
+            _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (1, 3, 3), pad=(0, 1, 1), bn=bn_b, use_bias=False,
                       out=buf.slab(c, growth), trainable=tr_conv)
             _stats(ctx, buf.slab(c, growth), mode)
@@ -97,8 +106,9 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
         drop = 0.3 if (i == 4 and standalone) else 0.0
         cu = ConvLayer(ctx, "conv_up" + tag, cur, f, (1, 3, 3), pad=(0, 1, 1), bn=cur_bn, up=(0, 1, 1), skip=skip,
                        init=dec_init, trainable=tr_conv, dropout=drop)
-        _stats(ctx, cu.out, mode)
+        st = _stats(ctx, cu.out, mode)
         cur_bn = BNLayer(ctx, "bn_up" + tag, cu.out.C, 1e-3, 0.99, mode, tr_bn)
+        _fuse(st, cur_bn)
         cur = cu.out
     res = dict(feat_raw=cur, feat_bn=cur_bn)
     if materialize_feature:
@@ -123,8 +133,9 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     nb_filter = 96
     conv1 = ConvLayer(ctx, "3dconv1", x_in, nb_filter, (7, 7, 7), (2, 2, 2), (3, 3, 3), use_bias=False, keras_nd=3,
                       cin_logical=4)
-    StatsOp(ctx, conv1.out)
+    st = StatsOp(ctx, conv1.out)
     bn1 = BNLayer(ctx, "3dconv1_bn", nb_filter, EPS_DENSE, 0.99, "batch", True, "3dconv1_scale", True)
+    st.fuse(bn1)
     z0 = MaterializeLayer(ctx, conv1.out, bn1).out
     d0 = z0.act.D
     d, h, w = (d0 - 1) // 2 + 1, H // 4, W // 4
@@ -138,8 +149,9 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
             base = "3dconv%d_%d" % (stage, i + 1)
             bn_a = BNLayer(ctx, base + "_x1_bn", c, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x1_scale", True)
             c1 = ConvLayer(ctx, base + "_x1", buf.slab(0, c), growth * 4, (1, 1, 1), bn=bn_a, use_bias=False, keras_nd=3)
-            _stats(ctx, c1.out, blk_mode)
+            st = _stats(ctx, c1.out, blk_mode)
             bn_b = BNLayer(ctx, base + "_x2_bn", growth * 4, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x2_scale", True)
+            _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (3, 3, 3), pad=(1, 1, 1), bn=bn_b, use_bias=False,
                       out=buf.slab(c, growth), keras_nd=3)
             _stats(ctx, buf.slab(c, growth), blk_mode)
@@ -174,8 +186,9 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     cur, cur_bn = buf, bn5
     for i in range(5):
         cu = ConvLayer(ctx, "3dconv_up%d" % i, cur, filt[i], (3, 3, 3), pad=(1, 1, 1), bn=cur_bn, up=ups[i], keras_nd=3)
-        StatsOp(ctx, cu.out)
+        st = StatsOp(ctx, cu.out)
         cur_bn = BNLayer(ctx, "3dbn_up%d" % i, cu.out.C, 1e-3, 0.99, "batch", True)
+        st.fuse(cur_bn)
         cur = cu.out
     return cur, cur_bn
 
@@ -230,7 +243,8 @@ def build_hybrid(ctx, vol, D, H, W, variant="3dpart", nb_layers2d=(6, 12, 36, 24
     fea2d = as3d(ctx, r2d["feat"])
     fc = ConvLayer(ctx, "fianl_conv", feat3d, 64, (3, 3, 3), pad=(1, 1, 1), bn=bn3d, skip=fea2d, keras_nd=3,
                    dropout=0.1 if variant == "3dpart" else 0.3)
-    StatsOp(ctx, fc.out)
+    st = StatsOp(ctx, fc.out)
     fbn = BNLayer(ctx, "final_bn", fc.out.C, 1e-3, 0.99, "batch", True)
+    st.fuse(fbn)
     cls = ConvLayer(ctx, "2d3dclassifer", fc.out, 3, (1, 1, 1), bn=fbn, keras_nd=3)
     return cls.out

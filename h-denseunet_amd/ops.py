@@ -170,6 +170,21 @@ def bn_fold(C, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean=
           "hdu_bn_fold")
 
 
+def bn_stats_fold(x, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum, ws):
+    check(_l.get().hdu_bn_stats_fold(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(mean), fptr(var), fptr(gamma), fptr(beta), eps,
+                                     fptr(sgamma), fptr(sbeta), fptr(a), fptr(b), fptr(rstd), fptr(mov_mean),
+                                     fptr(mov_var), momentum, ws.ptr, ws.nbytes, stream()), "hdu_bn_stats_fold")
+
+
+def bn_bwd_reduce_coef(dz, x, a, b, relu, mean, rstd, batch_stats, gamma, beta, sgamma, s1, s2, k1, k2, k3, dgamma,
+                       dbeta, dsgamma, dsbeta, ws):
+    check(_l.get().hdu_bn_bwd_reduce_coef(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b),
+                                          1 if relu else 0, fptr(mean), fptr(rstd), 1 if batch_stats else 0,
+                                          fptr(gamma), fptr(beta), fptr(sgamma), fptr(s1), fptr(s2), fptr(k1), fptr(k2),
+                                          fptr(k3), fptr(dgamma), fptr(dbeta), fptr(dsgamma), fptr(dsbeta), ws.ptr,
+                                          ws.nbytes, stream()), "hdu_bn_bwd_reduce_coef")
+
+
 def bn_bwd_reduce(dz, x, a, b, relu, mean, rstd, s1, s2, ws):
     check(_l.get().hdu_bn_bwd_reduce(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
                                      fptr(mean), fptr(rstd), fptr(s1), fptr(s2), ws.ptr, ws.nbytes, stream()),

@@ -132,6 +132,19 @@ int hdu_bn_fold(int C, const float* mean, const float* var, const float* gamma, 
                 const float* sgamma, const float* sbeta, float* a, float* b, float* rstd, float* mov_mean,
                 float* mov_var, float momentum, void* stream);
 
+/* hdu_bn_stats + hdu_bn_fold in two launches instead of three (the fold runs in the finalize pass of the reduction) */
+int hdu_bn_stats_fold(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* mean, float* var,
+                      const float* gamma, const float* beta, float eps, const float* sgamma, const float* sbeta,
+                      float* a, float* b, float* rstd, float* mov_mean, float* mov_var, float momentum, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* hdu_bn_bwd_reduce + hdu_bn_bwd_coef fused the same way */
+int hdu_bn_bwd_reduce_coef(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                           const float* a, const float* b, int relu, const float* mean, const float* rstd,
+                           int batch_stats, const float* gamma, const float* beta, const float* sgamma, float* s1,
+                           float* s2, float* k1, float* k2, float* k3, float* dgamma, float* dbeta, float* dsgamma,
+                           float* dsbeta, void* ws, size_t ws_bytes, void* stream);
+
 /* backward of  z = relu?(a*x+b)  where a,b came from hdu_bn_fold: per-channel sums
  *   s1 = sum g, s2 = sum g*(x-mean)*rstd,  g = dz * [a*x+b > 0]  */
 int hdu_bn_bwd_reduce(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
