@@ -23,6 +23,8 @@ struct ConvK {
   unsigned drop_thresh;       // keep iff hash < thresh
   unsigned drop_seed;
   const unsigned* drop_seed_dev;
+  int xcd_swizzle;
+  int vec_out;                // output rows are 16-byte addressable (DMA kernels' vector epilogue)
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][128 B] LDS tile.
@@ -30,4 +32,14 @@ struct ConvK {
 // distinct 16-B slots of the 256-B bank row.
 __device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
   return row * 128 + ((chunk ^ (row & 7)) << 4);
+}
+
+// XCD-aware tile order (MI355X: 8 XCDs, private 4 MiB L2 each; workgroup b is observed to run on XCD b % 8 -- used
+// for speed only, never correctness).  Maps the hardware block index to a tile index such that each XCD walks a
+// contiguous range of tiles: neighbouring output tiles share 3x3 halo rows and land in the same L2.  Bijective for
+// any grid size.
+__device__ __forceinline__ unsigned xcd_tile_index(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned xcd = bid & 7u, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   const int wn = wave % WAVES_N;
   const int kc = tid & 7;
   const int r0 = tid >> 3;
-  const long long m0 = (long long)blockIdx.x * BM;
+  const long long m0 = (long long)(p.xcd_swizzle ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ sp = (const T*)p.skip;
@@ -215,30 +215,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   }
 
   // ---- epilogue: bias, dropout, optional accumulate, store ----
-  T* __restrict__ yp = (T*)p.y;
-  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + (lane & 15);
-        if (n >= p.Cout) continue;
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[n];
-        if (p.drop_scale != 0.f) {
-          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
-          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
-        }
-        T* q = yp + m * p.ldy + n;
-        if (p.accumulate) v += Chunk<T>::load1(q);
-        Chunk<T>::store1(q, v);
-      }
-    }
-  }
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // =====================================================================================
@@ -706,6 +683,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
     }
 }
 
+// ---- epilogue shared by the DMA kernels: bias / dropout in registers, then the tile goes through LDS so that every
+// lane writes (and, in accumulate mode, reads) one full 16-byte chunk of a row: 8 lanes cover a 128-byte line.
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][TN], char* smem, long long m0, int n0,
+                                               int wm, int wn, int lane, int tid) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int ROWB = BN * (int)sizeof(T) + 16;     // +16 B: consecutive rows start on different banks
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+  __syncthreads();                                   // all MFMA operand reads of the last K tile are done
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wm * WM + i * 16 + (lane >> 4) * 4 + r;
+      const long long m = m0 + row;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * WN + j * 16 + (lane & 15);
+        const int n = n0 + col;
+        float v = acc[i][j][r];
+        if (p.bias && n < p.Cout) v += p.bias[n];
+        if (p.drop_scale != 0.f) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
+          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
+        }
+        Chunk<T>::store1((T*)(smem + row * ROWB) + col, v);
+      }
+    }
+  }
+  __syncthreads();
+  T* __restrict__ yp = (T*)p.y;
+  constexpr int NCC = BN / CH;                       // 16-byte chunks per tile row
+  for (int q = tid; q < BM * NCC; q += 256) {
+    const int row = q / NCC, cc = q % NCC;
+    const long long m = m0 + row;
+    const int n = n0 + cc * CH;
+    if (m >= p.M || n >= p.Cout) continue;           // Cout is a multiple of CH: chunks are all-or-nothing
+    u32x4 v = *(const u32x4*)(smem + row * ROWB + cc * 16);
+    T* dst = yp + m * p.ldy + n;
+    if (p.accumulate) {
+      float f[CH], g[CH];
+      Chunk<T>::unpack(v, f);
+      Chunk<T>::unpack(*(const u32x4*)dst, g);
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj) f[jj] += g[jj];
+      v = Chunk<T>::pack(f);
+    }
+    *(u32x4*)dst = v;
+  }
+}
+
 // =====================================================================================
 // DMA form of the implicit GEMM: used whenever the operand gather needs no arithmetic (no BN/ReLU prologue, no
 // skip add) -- i.e. for materialised inputs, for every data gradient and for all filter tiles.  Each lane issues
@@ -739,7 +767,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   const int wn = wave % WAVES_N;
   const int r0 = tid >> 3;
   const int kcl = (tid & 7) ^ (r0 & 7);   // logical chunk this lane fetches (it lands at physical chunk tid&7)
-  const long long m0 = (long long)blockIdx.x * BM;
+  const long long m0 = (long long)(p.xcd_swizzle ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ wp = (const T*)p.w;
@@ -857,30 +885,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     __syncthreads();
   }
 
-  T* __restrict__ yp = (T*)p.y;
-  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + (lane & 15);
-        if (n >= p.Cout) continue;
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[n];
-        if (p.drop_scale != 0.f) {
-          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
-          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
-        }
-        T* q = yp + m * p.ldy + n;
-        if (p.accumulate) v += Chunk<T>::load1(q);
-        Chunk<T>::store1(q, v);
-      }
-    }
-  }
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // NS-stage ring variant: tiles t+1 .. t+NS-1 stay in flight while tile t is multiplied.  Per iteration: counted
@@ -934,7 +939,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   const int wn = wave % WAVES_N;
   const int r0 = tid >> 3;
   const int kcl = (tid & 7) ^ (r0 & 7);
-  const long long m0 = (long long)blockIdx.x * BM;
+  const long long m0 = (long long)(p.xcd_swizzle ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ wp = (const T*)p.w;
@@ -1053,30 +1058,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
-  T* __restrict__ yp = (T*)p.y;
-  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long m = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 16 + (lane & 15);
-        if (n >= p.Cout) continue;
-        float v = acc[i][j][r];
-        if (p.bias) v += p.bias[n];
-        if (p.drop_scale != 0.f) {
-          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
-          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
-        }
-        T* q = yp + m * p.ldy + n;
-        if (p.accumulate) v += Chunk<T>::load1(q);
-        Chunk<T>::store1(q, v);
-      }
-    }
-  }
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
@@ -1376,7 +1358,7 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep
 // ------------------------------------------------------------------ host-side dispatch
 #include "hdu_host.h"
 
-int g_tuning[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+int g_tuning[8] = {2, 0, 0, 1, 0, 0, 0, 0};
 
 extern "C" int hdu_set_tuning(int key, int value) {
   if (key < 0 || key >= 8) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
@@ -1426,13 +1408,17 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   }
   k->drop_seed = d->drop_seed;
   k->drop_seed_dev = d->drop_seed_dev;
+  k->xcd_swizzle = g_tuning[HDU_TUNE_XCD_SWIZZLE];
+  k->vec_out = 1;
+  if (!wgrad && d->y && (d->Cout % ch || d->ldy % ch || (uintptr_t)d->y % 16))
+    return hdu_set_error(HDU_ERR_ARG, "conv: Cout / output pixel stride must be multiples of the 16-byte chunk and y 16-byte aligned");
   return 0;
 }
 
 template <typename T, int BM, int BN, int WMv, int WNv>
 static void launch_igemm(const ConvK& k, hipStream_t s) {
   dim3 grid((unsigned)((k.M + BM - 1) / BM), (unsigned)((k.Cout + BN - 1) / BN), 1);
-  if (k.pro_a == nullptr && k.skip == nullptr) {
+  if (k.pro_a == nullptr && k.skip == nullptr && k.vec_out) {
     // deep ring when the grid cannot fill the chip (latency-bound K loop, LDS is free); else 2 stages x 3 blocks/CU
     constexpr int STAGE = (BM + ((BN + 31) / 32) * 32) * 128;
     constexpr int NSD = STAGE * 6 <= 160 * 1024 ? 6 : 4;
@@ -1614,7 +1600,7 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     int bm, bn;
     choose_igemm(k, &bm, &bn);
     const int wm = (bm == 128 && bn == 128) ? 2 : ((bm == 64 && bn != 48) ? 2 : 4);
-    const bool dma = k.pro_a == nullptr && k.skip == nullptr;
+    const bool dma = k.pro_a == nullptr && k.skip == nullptr && k.vec_out;
     const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
     const int stage = (bm + ((bn + 31) / 32) * 32) * 128;

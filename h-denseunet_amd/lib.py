@@ -132,6 +132,8 @@ def load(path=None):
     _backend = _lib.hdu_backend().decode()
     if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
         _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_XCD_SWIZZLE" in os.environ:
+        _lib.hdu_set_tuning(3, int(os.environ["HDU_XCD_SWIZZLE"]))
     if "HDU_WGRAD_TARGET" in os.environ:
         _lib.hdu_set_tuning(2, int(os.environ["HDU_WGRAD_TARGET"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
