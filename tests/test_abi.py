@@ -1,0 +1,60 @@
+"""The C-ABI shared library loads and exports every symbol include/hdu.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "hdu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(hdu_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_declares_what_python_binds():
+    import importlib
+    lib = importlib.import_module("h-denseunet_amd.lib")
+    assert set(lib.EXPORTS) == set(declared_symbols())
+
+
+@pytest.mark.parametrize("which", ["hip", "emu"])
+def test_library_exports_every_declared_symbol(which):
+    import importlib
+    lib = importlib.import_module("h-denseunet_amd.lib")
+    path = lib.product_library_path() if which == "hip" else lib.emulator_library_path()
+    if not os.path.exists(path):
+        subprocess.check_call([os.path.join(ROOT, "build.sh"), which])
+    import torch  # noqa: F401  (one shared HIP runtime, see lib._bind)
+    so = ctypes.CDLL(path)
+    for name in declared_symbols():
+        assert hasattr(so, name), name
+    so.hdu_backend.restype = ctypes.c_char_p
+    assert so.hdu_backend().decode() == ("hip-gfx950" if which == "hip" else "emu-x86")
+
+
+def test_product_path_fails_loudly_without_library(tmp_path):
+    import importlib
+    lib = importlib.import_module("h-denseunet_amd.lib")
+    with pytest.raises(lib.HduError, match="no CPU fallback"):
+        lib.load(str(tmp_path / "missing_libhdu.so"))
+
+
+def test_product_library_refuses_cpu_storage():
+    """with the gfx950 library bound and no GPU visible the ops refuse to run (no silent CPU path)"""
+    import importlib
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = importlib.import_module("h-denseunet_amd.lib")
+    ops = importlib.import_module("h-denseunet_amd.ops")
+    lib.load()
+    try:
+        with pytest.raises(lib.HduError, match="no CPU fallback"):
+            ops.device()
+    finally:
+        lib.use_emulator_for_tests()
