@@ -1,13 +1,38 @@
 // hipemu.cpp -- TEST INFRASTRUCTURE ONLY (see hipemu.h).
 #include "hipemu.h"
 
-#include <ucontext.h>
 
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
 #include <vector>
+
+// minimal x86-64 System V context switch (callee-saved registers + stack pointer); ucontext's swapcontext costs two
+// sigprocmask syscalls per switch, which dominated the emulator's run time.
+extern "C" void hipemu_ctx_switch(void** from_sp, void* to_sp);
+asm(R"(
+.text
+.globl hipemu_ctx_switch
+.type hipemu_ctx_switch,@function
+hipemu_ctx_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_ctx_switch, .-hipemu_ctx_switch
+)");
 
 namespace hipemu {
 
@@ -19,7 +44,7 @@ constexpr size_t kStack = 256 * 1024;
 constexpr size_t kSlot = 64;  // bytes per lane in a wave exchange buffer
 
 struct Fiber {
-  ucontext_t uc;
+  void* sp = nullptr;
   ThreadCtx ctx;
   bool done = false;
   char* stack = nullptr;
@@ -33,7 +58,7 @@ struct WaveState {
 };
 
 struct BlockRun {
-  ucontext_t sched;
+  void* sched_sp = nullptr;
   std::vector<Fiber> fibers;
   std::vector<WaveState> waves;
   int bar_arrived = 0;
@@ -49,7 +74,7 @@ thread_local BlockRun* t_run = nullptr;
 void yield_to_sched() {
   BlockRun* r = t_run;
   Fiber* f = r->running;
-  swapcontext(&f->uc, &r->sched);
+  hipemu_ctx_switch(&f->sp, r->sched_sp);
   g_cur = &f->ctx;
 }
 
@@ -62,7 +87,8 @@ void fiber_main() {
   r->alive--;
   r->waves[f->ctx.wave].alive--;
   r->progress++;
-  swapcontext(&f->uc, &r->sched);
+  hipemu_ctx_switch(&f->sp, r->sched_sp);
+  __builtin_trap();   // a finished fiber is never resumed
 }
 
 }  // namespace
@@ -133,11 +159,13 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
     f.ctx.dyn_smem = smem_aligned;
     f.ctx.lane = (int)(t & 63);
     f.ctx.wave = (int)(t >> 6);
-    getcontext(&f.uc);
-    f.uc.uc_stack.ss_sp = f.stack;
-    f.uc.uc_stack.ss_size = kStack;
-    f.uc.uc_link = nullptr;
-    makecontext(&f.uc, (void (*)())fiber_main, 0);
+    // initial frame: six zeroed callee-saved registers, then the entry address consumed by `ret`
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 64);
+    for (int q = 0; q < 6; ++q) sp[q] = nullptr;
+    sp[6] = (void*)fiber_main;
+    sp[7] = nullptr;
+    f.sp = (void*)sp;
   }
   for (unsigned w = 0; w < run.waves.size(); ++w) {
     unsigned lo = w * 64, hi = lo + 64 > nthreads ? nthreads : lo + 64;
@@ -149,7 +177,7 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
       Fiber& f = run.fibers[t];
       if (f.done) continue;
       run.running = &f;
-      swapcontext(&run.sched, &f.uc);
+      hipemu_ctx_switch(&run.sched_sp, f.sp);
     }
     if (run.progress == before && run.alive > 0) {
       fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): %d threads alive, barrier %d arrived\n", bx, by, bz,
