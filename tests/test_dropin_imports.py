@@ -1,0 +1,50 @@
+"""the reference scripts' own import lines (train_2ddense.py:13-19, train_hybrid.py:13-21) resolve against compat/
+and drive a (tiny) model through compile / train_on_batch / predict / checkpoint with the reference's call pattern."""
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_import_lines_and_call_pattern(emu_lib, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    try:
+        from keras.optimizers import SGD
+        from keras.callbacks import ModelCheckpoint
+        from keras.utils2.multi_gpu import make_parallel
+        import keras.backend as K
+        from denseunet import DenseUNet
+        from denseunet3d import denseunet_3d  # noqa: F401
+        from hybridnet import dense_rnn_net  # noqa: F401
+        from loss import weighted_crossentropy_2ddense, weighted_crossentropy  # noqa: F401
+        from lib.custom_layers import Scale
+        K.set_image_dim_ordering('tf')
+        args = types.SimpleNamespace(b=1, input_size=32, input_cols=8)
+        model = DenseUNet(reduction=0.5, args=args, dtype="f32", nb_layers=(2, 2, 2, 2))
+        model = make_parallel(model, args.b // 10, mini_batch=10)      # gpu_count 0 -> identity (train_2ddense.py:180)
+        sgd = SGD(lr=1e-3, momentum=0.9, nesterov=True)
+        model.compile(optimizer=sgd, loss=[weighted_crossentropy_2ddense])
+        x = np.random.default_rng(0).normal(0, 50, (1, 32, 32, 3)).astype(np.float32)
+        y = np.random.default_rng(1).integers(0, 3, (1, 32, 32, 1))
+
+        def gen():
+            while True:
+                yield x, y
+
+        ck = ModelCheckpoint(str(tmp_path / "weights.{epoch:02d}-{loss:.2f}.npz"), monitor="loss", period=1)
+        hist = model.fit_generator(gen(), steps_per_epoch=2, epochs=2, verbose=0, callbacks=[ck], workers=3,
+                                   use_multiprocessing=True, max_queue_size=10)
+        assert len(hist.history["loss"]) == 2 and hist.history["loss"][1] < hist.history["loss"][0] * 1.5
+        assert len(list(tmp_path.iterdir())) == 2
+        p = model.predict(x, batch_size=1, verbose=1)
+        assert p.shape == (1, 32, 32, 3) and np.isfinite(p).all()
+        s = Scale(axis=3, name="conv1_scale")
+        s.build((None, 4, 4, 6))
+        assert s.call(np.ones((1, 4, 4, 6), np.float32)).shape == (1, 4, 4, 6)
+    finally:
+        sys.path.remove(os.path.join(ROOT, "compat"))
+        for m in [k for k in sys.modules if k.split(".")[0] in ("keras", "denseunet", "densenet", "denseunet3d", "hybridnet", "loss", "lib", "_hdu")]:
+            del sys.modules[m]
