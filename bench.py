@@ -76,8 +76,10 @@ def instrumented_step(m):
     try:
         g = m._graph
         m._graph = None
-        m.train_step_resident()
-        m._graph = g
+        try:
+            m.train_step_resident()
+        finally:
+            m._graph = g
         torch.cuda.synchronize()
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w

@@ -159,7 +159,12 @@ class Model:
         if self.optimizer is None:
             raise RuntimeError("compile() the model first")
         if self._graph is not None:
-            self._graph.replay()
+            g_fb, g_upd = self._graph
+            g_fb.replay()
+            if self._allreduce is not None:
+                self._allreduce(self.ctx.G[:self.ctx.n_trainable])
+            if g_upd is not None:
+                g_upd.replay()
             self.optimizer.iterations += 1
             return
         self._step_device()
@@ -168,7 +173,8 @@ class Model:
         self._step_update()
 
     def capture_graph(self, warmup=2):
-        """capture the whole step (incl. the RCCL all-reduce when data-parallel) into one hipGraph"""
+        """capture the step into hipGraphs.  Single GPU: ONE graph (fwd + bwd + SGD).  Data parallel: the gradient
+        all-reduce stays an eager RCCL call between two graphs (fwd+bwd | SGD update) -- no collective is captured."""
         if self.optimizer is None:
             raise RuntimeError("compile() the model first")
         if self.optimizer.decay > 0:
@@ -180,14 +186,21 @@ class Model:
                 self.train_step_resident()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_device()
-            if self._allreduce is not None:
-                self._allreduce(self.ctx.G[:self.ctx.n_trainable])
-            self._step_update()
-            self.optimizer.iterations -= 1
-        self._graph = g
+        it0 = self.optimizer.iterations
+        g_fb = torch.cuda.CUDAGraph()
+        g_upd = None
+        if self._allreduce is None:
+            with torch.cuda.graph(g_fb):
+                self._step_device()
+                self._step_update()
+        else:
+            with torch.cuda.graph(g_fb):
+                self._step_device()
+            g_upd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_upd):
+                self._step_update()
+        self.optimizer.iterations = it0
+        self._graph = (g_fb, g_upd)
 
     def train_on_batch(self, x, y, **kw):
         self._upload_x(x)
