@@ -626,6 +626,7 @@ struct PoolK {
   int Do, Ho, Wo;
   int accumulate;
   int ud, uh, uw;
+  int pad_d;               // max pool: zero padding on the depth axis (0 when neighbour planes are supplied as halo)
 };
 
 // forward: also records, per output element, which window tap won (255 = the zero padding): the backward pass
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(PoolK p) {
   const long long total = (long long)p.N * p.Do * p.Ho * p.Wo * ncc;
   const T* __restrict__ xp = (const T*)p.x;
   T* __restrict__ op = (T*)p.out;
-  const int kdn = p.D == 1 ? 1 : 3, pdd = p.D == 1 ? 0 : 1, sdd = p.D == 1 ? 1 : 2;
+  const int kdn = p.D == 1 ? 1 : 3, pdd = p.D == 1 ? 0 : p.pad_d, sdd = p.D == 1 ? 1 : 2;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(q % ncc) * CH;
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolK p) {
   const long long total = (long long)p.N * p.D * p.H * p.W * ncc;
   const T* __restrict__ dyp = (const T*)p.dy;
   T* __restrict__ op = (T*)p.out;
-  const int pdd = p.D == 1 ? 0 : 1, sdd = p.D == 1 ? 1 : 2;
+  const int pdd = p.D == 1 ? 0 : p.pad_d, sdd = p.D == 1 ? 1 : 2;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
        q += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(q % ncc) * CH;
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolK p) {
     float acc[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[j] = 0.f;
-    const int od_lo = p.D == 1 ? 0 : id / 2, od_hi = p.D == 1 ? 0 : (id + 1) / 2;
+    const int od_lo = p.D == 1 ? 0 : (id + pdd - 2 > 0 ? (id + pdd - 1) / 2 : 0), od_hi = p.D == 1 ? 0 : (id + pdd) / 2;
     const int oh_lo = ih / 2, oh_hi = (ih + 1) / 2;
     const int ow_lo = iw / 2, ow_hi = (iw + 1) / 2;
     for (int od = od_lo; od <= od_hi && od < p.Do; ++od)
@@ -855,25 +856,28 @@ static int poolk_check(int dtype, const PoolK& k, const char* what) {
   } while (0)
 
 extern "C" int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
-                                  int64_t ldy, uint8_t* argmax, void* stream) {
+                                  int64_t ldy, uint8_t* argmax, int pad_d, void* stream) {
   PoolK k{};
   k.idx = argmax;
+  k.pad_d = pad_d;
   k.x = x; k.ldx = ldx; k.out = y; k.ldo = ldy; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
-  k.Do = D == 1 ? 1 : (D - 1) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1;
-  if (!x || !y) return hdu_set_error(HDU_ERR_ARG, "maxpool_fwd: null pointer");
+  k.Do = D == 1 ? 1 : (D + 2 * pad_d - 3) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1;
+  if (!x || !y || (pad_d & ~1)) return hdu_set_error(HDU_ERR_ARG, "maxpool_fwd: null pointer / bad pad_d");
   if (int e = poolk_check(dtype, k, "maxpool_fwd: bad dims / strides")) return e;
   HDU_POOL_LAUNCH(maxpool_fwd_kernel, (long long)N * k.Do * k.Ho * k.Wo);
   return hdu_check_launch("maxpool_fwd");
 }
 
 extern "C" int hdu_maxpool3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, int64_t lddy, int N, int D,
-                                  int H, int W, int C, void* dx, int64_t lddx, int accumulate, void* stream) {
+                                  int H, int W, int C, void* dx, int64_t lddx, int accumulate, int pad_d,
+                                  void* stream) {
   PoolK k{};
+  k.pad_d = pad_d;
   const void* x = argmax;
   const int64_t ldx = 16;
   k.idx = const_cast<uint8_t*>(argmax);
   k.ldx = ldx; k.dy = dy; k.lddy = lddy; k.out = dx; k.ldo = lddx; k.N = N; k.D = D; k.H = H; k.W = W; k.C = C;
-  k.Do = D == 1 ? 1 : (D - 1) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1; k.accumulate = accumulate;
+  k.Do = D == 1 ? 1 : (D + 2 * pad_d - 3) / 2 + 1; k.Ho = (H - 1) / 2 + 1; k.Wo = (W - 1) / 2 + 1; k.accumulate = accumulate;
   if (!x || !dy || !dx) return hdu_set_error(HDU_ERR_ARG, "maxpool_bwd: null pointer (argmax / dy / dx)");
   if (int e = poolk_check(dtype, k, "maxpool_bwd: bad dims / strides")) return e;
   HDU_POOL_LAUNCH(maxpool_bwd_kernel, (long long)N * D * H * W);

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import shard as _sh
 from .lib import HDU_BF16, HDU_F32
 
 
@@ -121,6 +122,7 @@ class Ctx:
         self.drop_layers = 0
         self.dropout_enabled = True
         self.grad_enabled = True
+        self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
         # 0 = off, 1 = every layer, 2 = only layers with <= 16384 output pixels (latency-bound on their own)
         self.overlap_wgrad = int(os.environ.get("HDU_OVERLAP_WGRAD", "0"))
@@ -334,6 +336,7 @@ class BNLayer:
         self.mean_used = None
         self.batch_now = False
         self.folded_pass = -1
+        self.s12 = v(2 * C)
 
     def any_trainable(self):
         return self.trainable or (self.sg is not None and self.scale_trainable)
@@ -365,7 +368,22 @@ class BNLayer:
         need_sums = self.batch_now or self.any_trainable()
         tr_bn = self.trainable
         tr_sc = self.sg is not None and self.scale_trainable
-        if need_sums:   # reduction + coefficients + parameter gradients: two launches
+        if ctx.shard is not None and ctx.shard.world > 1 and need_sums:
+            # depth-sharded: parameter gradients from the LOCAL sums (the flat gradient all-reduce adds the ranks),
+            # dx coefficients from the GLOBAL sums over all shards
+            ops.bn_bwd_reduce(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.s1, self.s2, ctx.ws)
+            ops.bn_bwd_coef(self.C, x.M, False, self.s1, self.s2, self.gamma.data, self.beta.data,
+                            self.sg.data if self.sg else None, self.rstd, self.k1, self.k2, self.k3,
+                            self.gamma.grad if tr_bn else None, self.beta.grad if tr_bn else None,
+                            self.sg.grad if tr_sc else None, self.sb.grad if tr_sc else None)
+            if self.batch_now:
+                self.s12[:self.C].copy_(self.s1)
+                self.s12[self.C:].copy_(self.s2)
+                _sh.allreduce_sum(ctx.shard, self.s12)
+                ops.bn_bwd_coef(self.C, x.M * ctx.shard.world, True, self.s12[:self.C], self.s12[self.C:],
+                                self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.rstd, self.k1,
+                                self.k2, self.k3)
+        elif need_sums:   # reduction + coefficients + parameter gradients: two launches
             ops.bn_bwd_reduce_coef(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.batch_now,
                                    self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.s1,
                                    self.s2, self.k1, self.k2, self.k3, self.gamma.grad if tr_bn else None,
@@ -386,16 +404,24 @@ class ConvLayer:
     """[BN(+Scale)+ReLU] -> [UpSampling] -> [+skip] -> [ZeroPadding] -> Conv(+bias)(+Dropout) as ONE launch."""
 
     def __init__(self, ctx, name, x, filters, K, stride=(1, 1, 1), pad=(0, 0, 0), bn=None, up=(0, 0, 0), skip=None,
-                 use_bias=True, out=None, init="glorot", trainable=True, dropout=0.0, keras_nd=2, cin_logical=None):
+                 use_bias=True, out=None, init="glorot", trainable=True, dropout=0.0, keras_nd=2, cin_logical=None,
+                 halo=0):
+        """halo > 0 (depth sharding): the conv input buffer carries `halo` extra depth planes on both sides, filled
+        from the depth neighbours before the launch; the padding on the depth axis shrinks accordingly."""
         self.ctx, self.name, self.x, self.bn, self.up, self.skip = ctx, name, x, bn, up, skip
-        self.K, self.stride, self.pad = K, stride, pad
+        self.K, self.stride = K, stride
+        self.halo = halo
+        if halo:
+            assert skip is None and not ctx.fuse_prologue, "halo mode materialises the conv input"
+            pad = (pad[0] - (halo << up[0]), pad[1], pad[2])
+        self.pad = pad
         self.trainable = trainable
         dt = ctx.dtype
         xa = x.act
         cin_p = xa.C
         cin = cin_logical or cin_p
         cout_p = ops.cpad(filters, dt)
-        De, He, We = xa.D << up[0], xa.H << up[1], xa.W << up[2]
+        De, He, We = (xa.D + 2 * halo) << up[0], xa.H << up[1], xa.W << up[2]
         Do = (De + 2 * pad[0] - K[0]) // stride[0] + 1
         Ho = (He + 2 * pad[1] - K[1]) // stride[1] + 1
         Wo = (We + 2 * pad[2] - K[2]) // stride[2] + 1
@@ -424,7 +450,12 @@ class ConvLayer:
         # prologue costs more VALU cycles than the MFMAs it feeds (profiles/).
         self.xin = None
         self.conv_up = up
-        if (bn is not None or skip is not None) and not ctx.fuse_prologue:
+        if halo:
+            self.xin = ctx.new_var(xa.N, xa.D + 2 * halo, xa.H, xa.W, cin_p)
+            plane = xa.H * xa.W * cin_p
+            self.xin_interior = ops.Act(self.xin.act.buf, halo * plane, xa.N, xa.D, xa.H, xa.W, cin_p, cin_p, dt)
+            self._halo_tmp = ctx.scratch("halo_tmp", 1, 2 * halo, xa.H, xa.W, cin_p)
+        elif (bn is not None or skip is not None) and not ctx.fuse_prologue:
             if skip is not None:
                 self.xin = ctx.new_var(xa.N, De, He, We, cin_p)
                 self.conv_up = (0, 0, 0)
@@ -439,10 +470,10 @@ class ConvLayer:
             ctx.need_ws(xa.M, xa.C)      # statistics and / or the backward reductions over the input
         ctx.need_ws(out.act.M, cout_p)
         if need_input_grad:
-            if bn is not None or up != (0, 0, 0):
+            if bn is not None or up != (0, 0, 0) or halo:
                 self._dxe = ctx.scratch("dxe", xa.N, De, He, We, cin_p)
-            if bn is not None and up != (0, 0, 0):
-                self._dz = ctx.scratch("dz", xa.N, xa.D, xa.H, xa.W, cin_p)
+            if (bn is not None or halo) and up != (0, 0, 0):
+                self._dz = ctx.scratch("dz", xa.N, xa.D + 2 * halo, xa.H, xa.W, cin_p)
         ctx.fwd.append(self.forward)
         ctx.bwd.append(self.backward)
 
@@ -485,7 +516,10 @@ class ConvLayer:
             bn = self.bn
             ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False,
                             self.up if self.skip is not None else (0, 0, 0),
-                            self.skip.act if self.skip is not None else None, self.xin.act)
+                            self.skip.act if self.skip is not None else None,
+                            self.xin_interior if self.halo else self.xin.act)
+            if self.halo:
+                _sh.halo_exchange(ctx.shard, self.xin.act, self.halo)
         if self.d_f_drop is not None and ctx.learning_phase == 1 and ctx.dropout_enabled:
             ops.conv_fprop(self.d_f_drop)
         else:
@@ -519,6 +553,8 @@ class ConvLayer:
         if not self.need_input_grad:
             return
         K, pad = self.K, self.pad
+        if self.halo:
+            return self._backward_halo(dy)
         De, He, We = x.D << self.up[0], x.H << self.up[1], x.W << self.up[2]
         direct = self.bn is None and self.up == (0, 0, 0)
         skip_first = self.skip is not None and self.skip.root.needs_grad and not self.skip.root.written \
@@ -556,6 +592,34 @@ class ConvLayer:
             ops.upsample_bwd(dz, self.x.grad, (0, 0, 0), accumulate=self.x.grad_mode())
 
 
+def _conv_backward_halo(self, dy):
+    """data gradient of a depth-sharded conv: d(input incl. halo planes) -> [upsample gradient] -> halo gradients
+    go back to the owning neighbours -> BN backward on the local planes"""
+    ctx = self.ctx
+    x = self.x.act
+    K, pad, h = self.K, self.pad, self.halo
+    assert not self.strided, "the stride-2 stem needs no data gradient in the depth-sharded 3D net"
+    De, He, We = (x.D + 2 * h) << self.up[0], x.H << self.up[1], x.W << self.up[2]
+    tgt = self._dxe()
+    d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
+                      (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]))
+    ops.conv_fprop(d)
+    dz = tgt
+    if self.up != (0, 0, 0):
+        dz = self._dz()
+        ops.upsample_bwd(tgt, dz, self.up)
+    _sh.halo_reduce(ctx.shard, dz, h, self._halo_tmp().buf)
+    plane = x.H * x.W * dz.ld
+    interior = ops.Act(dz.buf, dz.off + h * plane, x.N, x.D, x.H, x.W, x.C, dz.ld, dz.dtype)
+    if self.bn is not None:
+        self.bn.backward(self.x, interior)
+    else:
+        ops.upsample_bwd(interior, self.x.grad, (0, 0, 0), accumulate=self.x.grad_mode())
+
+
+ConvLayer._backward_halo = _conv_backward_halo
+
+
 class StatsOp:
     """tf.nn.moments of a freshly written tensor / slab, once, shared by every consumer BN.  When the tensor has a
     single batch-stat consumer BN over exactly these channels, `fuse(bn)` folds it in the same two launches."""
@@ -563,6 +627,7 @@ class StatsOp:
     def __init__(self, ctx, var):
         self.ctx, self.var = ctx, var
         self.fused = None
+        self.sync_buf = ctx.fvec(2 * var.C)
         ctx.need_ws(var.act.M, var.C)
         var.stats()
         ctx.fwd.append(self.forward)
@@ -578,6 +643,11 @@ class StatsOp:
             return
         mean, var = self.var.stats()
         bn = self.fused
+        if ctx.shard is not None and ctx.shard.world > 1:
+            # local moments -> global moments over all depth shards (equal shard sizes), then the consumers fold
+            ops.bn_stats(self.var.act, mean, var, ctx.ws)
+            _sh.sync_stats(ctx.shard, mean, var, self.var.act.M, self.var.act.M * ctx.shard.world, self.sync_buf)
+            return
         if bn is None:
             ops.bn_stats(self.var.act, mean, var, ctx.ws)
             return
@@ -591,32 +661,48 @@ class StatsOp:
 class MaterializeLayer:
     """z = relu(BN(+Scale)(x)) written out (where the activation feeds a pool / a skip / the HFF add)."""
 
-    def __init__(self, ctx, x, bn):
-        self.ctx, self.x, self.bn = ctx, x, bn
+    def __init__(self, ctx, x, bn, halo=0):
+        self.ctx, self.x, self.bn, self.halo = ctx, x, bn, halo
         a = x.act
-        self.out = ctx.new_var(a.N, a.D, a.H, a.W, a.C)
+        self.out = ctx.new_var(a.N, a.D + 2 * halo, a.H, a.W, a.C)
         if ctx.grad_enabled:
             self.out.require_grad()
+        if halo:
+            self._halo_tmp = ctx.scratch("halo_tmp", 1, 2 * halo, a.H, a.W, a.C)
         ctx.need_ws(a.M, a.C)
         ctx.fwd.append(self.forward)
         ctx.bwd.append(self.backward)
 
+    def _interior(self, act):
+        a, h = self.x.act, self.halo
+        return ops.Act(act.buf, act.off + h * a.H * a.W * act.ld, a.N, a.D, a.H, a.W, a.C, act.ld, act.dtype)
+
     def forward(self):
         self.bn.fold(self.x)
-        ops.affine_act(self.x.act, self.bn.a, self.bn.b, self.bn.relu, self.out.act)
+        if self.halo:
+            ops.affine_act(self.x.act, self.bn.a, self.bn.b, self.bn.relu, self._interior(self.out.act))
+            _sh.halo_exchange(self.ctx.shard, self.out.act, self.halo)
+        else:
+            ops.affine_act(self.x.act, self.bn.a, self.bn.b, self.bn.relu, self.out.act)
 
     def backward(self):
-        if self.out.root.needs_grad:
+        if not self.out.root.needs_grad:
+            return
+        if self.halo:
+            _sh.halo_reduce(self.ctx.shard, self.out.grad, self.halo, self._halo_tmp().buf)
+            self.bn.backward(self.x, self._interior(self.out.grad))
+        else:
             self.bn.backward(self.x, self.out.grad)
 
 
 class MaxPoolLayer:
     """ZeroPadding(1) + MaxPooling 3x3(x3) stride 2 (denseunet.py:169-170, denseunet3d.py:135-136)."""
 
-    def __init__(self, ctx, x, out=None):
-        self.ctx, self.x = ctx, x
+    def __init__(self, ctx, x, out=None, pad_d=1):
+        """pad_d=0: x already carries the neighbouring depth planes as halo (depth sharding)"""
+        self.ctx, self.x, self.pad_d = ctx, x, pad_d
         a = x.act
-        Do = 1 if a.D == 1 else (a.D - 1) // 2 + 1
+        Do = 1 if a.D == 1 else (a.D + 2 * pad_d - 3) // 2 + 1
         dims = (a.N, Do, (a.H - 1) // 2 + 1, (a.W - 1) // 2 + 1)
         self.out = out if out is not None else ctx.new_var(*dims, a.C)
         assert (self.out.act.N, self.out.act.D, self.out.act.H, self.out.act.W) == dims
@@ -624,12 +710,12 @@ class MaxPoolLayer:
             self.out.require_grad()
         oa = self.out.act
         self.argmax = torch.zeros(oa.M * a.C, dtype=torch.uint8, device=ctx.dev) if self.x.root.needs_grad else None
-        ctx.fwd.append(lambda: ops.maxpool_fwd(self.x.act, self.out.act, self.argmax))
+        ctx.fwd.append(lambda: ops.maxpool_fwd(self.x.act, self.out.act, self.argmax, self.pad_d))
         ctx.bwd.append(self.backward)
 
     def backward(self):
         if self.out.root.needs_grad and self.x.root.needs_grad:
-            ops.maxpool_bwd(self.argmax, self.out.grad, self.x.grad, self.x.grad_mode())
+            ops.maxpool_bwd(self.argmax, self.out.grad, self.x.grad, self.x.grad_mode(), self.pad_d)
 
 
 class AvgPoolLayer:

@@ -45,8 +45,8 @@ class History:
 
 class Model:
     def __init__(self, kind, args_b, input_size, input_cols=None, dtype="bf16", variant=None, name=None,
-                 nb_layers2d=(6, 12, 36, 24), nb_layers3d=(3, 4, 12, 8), seed=4321):
-        self.kind = kind                  # "2d" | "hybrid"
+                 nb_layers2d=(6, 12, 36, 24), nb_layers3d=(3, 4, 12, 8), seed=4321, shard=None):
+        self.kind = kind                  # "2d" | "hybrid" | "3d"
         self.name = name
         self.dtype = HDU_BF16 if dtype in ("bf16", HDU_BF16) else HDU_F32
         self.variant = variant
@@ -76,6 +76,20 @@ class Model:
             hi = min(7, D)
             self.loss_layer = LossLayer(ctx, self.logits, [(1 * H * W, (hi - 1) * H * W)])
             self.output_shape = (1, H, W, D, 3)
+        elif kind == "3d":
+            # stand-alone DenseNet3D on a 4-channel volume; with `shard` this rank holds input_cols LOCAL depth planes
+            if args_b != 1:
+                raise ValueError("one volume per step")
+            H = W = input_size
+            D = input_cols
+            ctx.shard = shard
+            self.input_shape = (1, H, W, D, 4)
+            self.x_stage = torch.zeros(D * H * W * 4, dtype=torch.float32, device=ctx.dev)
+            self.x_in = ctx.new_var(1, D, H, W, ops.cpad(4, dt))
+            ctx.fwd.append(lambda: ops.cast_pad(self.x_stage, D * H * W, 4, self.x_in.act))
+            self.logits = _m.build_dense_net_3d_standalone(ctx, self.x_in, nb_layers=nb_layers3d)
+            self.loss_layer = LossLayer(ctx, self.logits, [(0, D * H * W)])
+            self.output_shape = (1, H, W, D, 3)
         else:
             raise ValueError(kind)
         self.logits.require_grad()
@@ -96,6 +110,8 @@ class Model:
             raise ValueError("expected input of shape %s, got %s" % (self.input_shape, tuple(x.shape)))
         if self.kind == "2d":
             self.x_stage.copy_(x.reshape(-1).to(self.ctx.dev), non_blocking=True)
+        elif self.kind == "3d":  # (1,H,W,D,4) -> depth-major [D][H][W][4]
+            self.x_stage.copy_(x[0].permute(2, 0, 1, 3).contiguous().reshape(-1).to(self.ctx.dev))
         else:  # (1,H,W,D,1) -> depth-major [D][H][W]
             self.vol.copy_(x[0, :, :, :, 0].permute(2, 0, 1).contiguous().reshape(-1).to(self.ctx.dev))
 
@@ -106,7 +122,7 @@ class Model:
             if tuple(y.shape) != want:
                 raise ValueError("expected labels of shape %s, got %s" % (want, tuple(y.shape)))
             return y.reshape(-1)
-        want = self.input_shape
+        want = self.input_shape[:4] + (1,)
         if tuple(y.shape) != want:
             raise ValueError("expected labels of shape %s, got %s" % (want, tuple(y.shape)))
         return np.ascontiguousarray(y[0, :, :, :, 0].transpose(2, 0, 1)).reshape(-1)

@@ -74,8 +74,8 @@ _SIGS = {
     "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
                                 c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
-    "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_p]),
-    "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_p]),
+    "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_int, c_p]),
+    "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_int, c_p]),
     "hdu_avgpool2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p]),
     "hdu_avgpool2_bwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_p]),
     "hdu_upsample_bwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p,

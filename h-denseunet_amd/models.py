@@ -131,16 +131,20 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     N, D, H, W = a.N, a.D, a.H, a.W
     assert H % 32 == 0 and W % 32 == 0 and D % 4 == 0, "H,W multiples of 32 and D a multiple of 4 (SURVEY.md A.2)"
     nb_filter = 96
+    sharded = ctx.shard is not None and ctx.shard.world > 1
+    hl = 1 if sharded else 0      # depth halo of every 3x3x3 conv / of the max pool; the 7x7x7 stride-2 stem needs 3
+    if sharded:
+        assert D % 4 == 0, "local depth must be a multiple of 4"
     conv1 = ConvLayer(ctx, "3dconv1", x_in, nb_filter, (7, 7, 7), (2, 2, 2), (3, 3, 3), use_bias=False, keras_nd=3,
-                      cin_logical=4)
+                      cin_logical=4, halo=3 if sharded else 0)
     st = StatsOp(ctx, conv1.out)
     bn1 = BNLayer(ctx, "3dconv1_bn", nb_filter, EPS_DENSE, 0.99, "batch", True, "3dconv1_scale", True)
     st.fuse(bn1)
-    z0 = MaterializeLayer(ctx, conv1.out, bn1).out
-    d0 = z0.act.D
+    z0 = MaterializeLayer(ctx, conv1.out, bn1, halo=hl).out
+    d0 = conv1.out.act.D
     d, h, w = (d0 - 1) // 2 + 1, H // 4, W // 4
     buf = ctx.new_var(N, d, h, w, nb_filter + nb_layers[0] * growth)
-    MaxPoolLayer(ctx, z0, out=buf.slab(0, nb_filter))
+    MaxPoolLayer(ctx, z0, out=buf.slab(0, nb_filter), pad_d=0 if sharded else 1)
     _stats(ctx, buf.slab(0, nb_filter), blk_mode)
 
     def dense_block(stage, nlayers, buf, c0):
@@ -153,7 +157,7 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
             bn_b = BNLayer(ctx, base + "_x2_bn", growth * 4, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x2_scale", True)
             _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (3, 3, 3), pad=(1, 1, 1), bn=bn_b, use_bias=False,
-                      out=buf.slab(c, growth), keras_nd=3)
+                      out=buf.slab(c, growth), keras_nd=3, halo=hl)
             _stats(ctx, buf.slab(c, growth), blk_mode)
             c += growth
         return c
@@ -185,7 +189,8 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     filt = [504 if nb_layers == (3, 4, 12, 8) else nb_filter, 224, 192, 96, 64]
     cur, cur_bn = buf, bn5
     for i in range(5):
-        cu = ConvLayer(ctx, "3dconv_up%d" % i, cur, filt[i], (3, 3, 3), pad=(1, 1, 1), bn=cur_bn, up=ups[i], keras_nd=3)
+        cu = ConvLayer(ctx, "3dconv_up%d" % i, cur, filt[i], (3, 3, 3), pad=(1, 1, 1), bn=cur_bn, up=ups[i], keras_nd=3,
+                       halo=hl)
         st = StatsOp(ctx, cu.out)
         cur_bn = BNLayer(ctx, "3dbn_up%d" % i, cu.out.C, 1e-3, 0.99, "batch", True)
         st.fuse(cur_bn)
@@ -247,4 +252,13 @@ def build_hybrid(ctx, vol, D, H, W, variant="3dpart", nb_layers2d=(6, 12, 36, 24
     fbn = BNLayer(ctx, "final_bn", fc.out.C, 1e-3, 0.99, "batch", True)
     st.fuse(fbn)
     cls = ConvLayer(ctx, "2d3dclassifer", fc.out, 3, (1, 1, 1), bn=fbn, keras_nd=3)
+    return cls.out
+
+
+def build_dense_net_3d_standalone(ctx, x_in, nb_layers=(3, 4, 12, 8)):
+    """DenseNet3D with its own head (`3dclassifer`, denseunet3d.py:187) as a stand-alone segmentation net: the
+    network of BASELINE configs[4] (one 512^3 volume, depth-sharded).  All BNs in batch-statistics mode
+    (denseunet3d.py variant)."""
+    feat, bn = build_dense_net_3d(ctx, x_in, variant="3dpart", nb_layers=nb_layers)
+    cls = ConvLayer(ctx, "3dclassifer", feat, 3, (1, 1, 1), bn=bn, keras_nd=3)
     return cls.out

@@ -222,15 +222,16 @@ def colsum(x, out, ws):
     check(_l.get().hdu_colsum(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(out), ws.ptr, ws.nbytes, stream()), "hdu_colsum")
 
 
-def maxpool_fwd(x, y, argmax=None):
+def maxpool_fwd(x, y, argmax=None, pad_d=1):
     check(_l.get().hdu_maxpool3s2_fwd(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, y.ptr, y.ld,
-                                      ctypes.c_void_p(argmax.data_ptr()) if argmax is not None else None, stream()),
+                                      ctypes.c_void_p(argmax.data_ptr()) if argmax is not None else None, pad_d,
+                                      stream()),
           "hdu_maxpool3s2_fwd")
 
 
-def maxpool_bwd(argmax, dy, dx, accumulate=False):
+def maxpool_bwd(argmax, dy, dx, accumulate=False, pad_d=1):
     check(_l.get().hdu_maxpool3s2_bwd(dx.dtype, ctypes.c_void_p(argmax.data_ptr()), dy.ptr, dy.ld, dx.N, dx.D, dx.H,
-                                      dx.W, dx.C, dx.ptr, dx.ld, 1 if accumulate else 0, stream()),
+                                      dx.W, dx.C, dx.ptr, dx.ld, 1 if accumulate else 0, pad_d, stream()),
           "hdu_maxpool3s2_bwd")
 
 

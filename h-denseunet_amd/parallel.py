@@ -56,3 +56,25 @@ def shard_depth(D, world, rank):
     """[begin, end) of the depth planes owned by `rank` when one volume is sharded on the depth axis"""
     per = D // world
     return rank * per, (rank + 1) * per if rank < world - 1 else D
+
+
+def depth_shard_info(backend=None):
+    """ShardInfo of this process (one process per GPU / per depth shard)"""
+    from .shard import ShardInfo
+    rank, world = init_process_group_from_env(backend)
+    return ShardInfo(rank, world)
+
+
+def attach_depth_shard(model):
+    """gradient exchange of a depth-sharded model: every rank holds PARTIAL filter / BN gradients of the one volume
+    (its own voxels), so the flat gradient buffer is summed; the loss is normalised by the global voxel count."""
+    sh = model.ctx.shard
+    if sh is None or sh.world == 1:
+        return model
+
+    def allreduce(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
+
+    model.set_data_parallel(sh.world, allreduce)
+    broadcast_parameters(model)
+    return model

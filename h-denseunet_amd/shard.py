@@ -1,0 +1,100 @@
+"""Depth-axis sharding of ONE volume across ranks (BASELINE configs[4]; new capability, SURVEY.md section 8e -- the
+reference only has batch towers, K.utils2/multi_gpu.py).
+
+Rank r owns a contiguous range of depth planes at every resolution level (depth-major layout: a plane is one
+contiguous memory range).  Every depth-coupled layer keeps `h` halo planes on both sides of its input buffer:
+
+  forward : halo_exchange  -- my first/last interior planes -> neighbours' halo planes (global edges stay zero =
+                              the reference's ZeroPadding3D / SAME padding)
+  backward: halo_reduce    -- gradients that landed on my halo planes go back to the owning neighbour and are ADDED
+                              to its boundary planes
+  BN      : sync statistics -- all-reduce of per-channel (n*mean, n*(var+mean^2)) forward and (S1, S2) backward, so a
+                              sharded step equals the single-device step.
+
+Exchanges are point-to-point with the two depth neighbours (RCCL send/recv over xGMI; gloo in the CPU tests);
+nothing here touches the per-voxel data path kernels.
+"""
+import torch
+import torch.distributed as dist
+
+
+class ShardInfo:
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    @property
+    def lo(self):
+        return self.rank - 1 if self.rank > 0 else None
+
+    @property
+    def hi(self):
+        return self.rank + 1 if self.rank < self.world - 1 else None
+
+
+def _planes(act, p0, n):
+    """flat view of planes [p0, p0+n) of a full-width activation (C == ld)"""
+    assert act.C == act.ld and act.N == 1
+    plane = act.H * act.W * act.ld
+    return act.buf[act.off + p0 * plane: act.off + (p0 + n) * plane]
+
+
+def halo_exchange(sh, act, h):
+    """act: [1][Dl+2h][H][W][C]; fills the 2 x h halo planes from the depth neighbours"""
+    if sh is None or sh.world == 1:
+        return
+    D = act.D
+    ops_ = []
+    if sh.lo is not None:
+        ops_.append(dist.P2POp(dist.isend, _planes(act, h, h), sh.lo, sh.group))
+        ops_.append(dist.P2POp(dist.irecv, _planes(act, 0, h), sh.lo, sh.group))
+    if sh.hi is not None:
+        ops_.append(dist.P2POp(dist.isend, _planes(act, D - 2 * h, h), sh.hi, sh.group))
+        ops_.append(dist.P2POp(dist.irecv, _planes(act, D - h, h), sh.hi, sh.group))
+    for r in dist.batch_isend_irecv(ops_):
+        r.wait()
+
+
+def halo_reduce(sh, act, h, tmp):
+    """act holds gradients for Dl+2h planes; halo-plane gradients are returned to their owners and accumulated.
+    tmp: scratch tensor of at least 2*h planes."""
+    if sh is None or sh.world == 1:
+        return
+    D = act.D
+    plane = act.H * act.W * act.ld
+    ops_ = []
+    r_lo = tmp[:h * plane]
+    r_hi = tmp[h * plane:2 * h * plane]
+    if sh.lo is not None:
+        ops_.append(dist.P2POp(dist.isend, _planes(act, 0, h), sh.lo, sh.group))
+        ops_.append(dist.P2POp(dist.irecv, r_lo, sh.lo, sh.group))
+    if sh.hi is not None:
+        ops_.append(dist.P2POp(dist.isend, _planes(act, D - h, h), sh.hi, sh.group))
+        ops_.append(dist.P2POp(dist.irecv, r_hi, sh.hi, sh.group))
+    for r in dist.batch_isend_irecv(ops_):
+        r.wait()
+    if sh.lo is not None:
+        _planes(act, h, h).add_(r_lo)
+    if sh.hi is not None:
+        _planes(act, D - 2 * h, h).add_(r_hi)
+
+
+def allreduce_sum(sh, t):
+    if sh is not None and sh.world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
+    return t
+
+
+def sync_stats(sh, mean, var, n_local, n_global, buf):
+    """local (mean, biased var) over n_local pixels -> global statistics over n_global pixels, in place.
+    buf: float32 [2*C] scratch."""
+    if sh is None or sh.world == 1:
+        return
+    C = mean.numel()
+    b1, b2 = buf[:C], buf[C:2 * C]
+    torch.mul(mean, float(n_local), out=b1)
+    torch.addcmul(var, mean, mean, out=b2)
+    b2.mul_(float(n_local))
+    dist.all_reduce(buf[:2 * C], op=dist.ReduceOp.SUM, group=sh.group)
+    torch.div(b1, float(n_global), out=mean)
+    torch.div(b2, float(n_global), out=var)
+    var.addcmul_(mean, mean, value=-1.0).clamp_(min=0.0)

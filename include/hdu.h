@@ -187,9 +187,10 @@ int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* o
  * Avg pool: 2x2 stride 2 over (H,W); depth is not pooled (denseunet3d.py:102). */
 int hdu_maxpool3s2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
                        int64_t ldy, uint8_t* argmax /* optional [N*Do*Ho*Wo][C]: winning tap, 255 = padding */,
+                       int pad_d /* 1 = reference; 0 = depth halo planes supplied by the caller (depth sharding) */,
                        void* stream);
 int hdu_maxpool3s2_bwd(int dtype, const uint8_t* argmax, const void* dy, int64_t lddy, int N, int D, int H, int W,
-                       int C, void* dx, int64_t lddx, int accumulate, void* stream);
+                       int C, void* dx, int64_t lddx, int accumulate, int pad_d, void* stream);
 int hdu_avgpool2_fwd(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, void* y,
                      int64_t ldy, void* stream);
 int hdu_avgpool2_bwd(int dtype, const void* dy, int64_t lddy, int N, int D, int H, int W, int C, void* dx,

@@ -1,0 +1,78 @@
+"""worker of tests/test_depth_shard_gloo.py: one volume split on the depth axis over 2 ranks (gloo, emulator build).
+Every rank also runs the UNSHARDED net on the whole volume and checks that the sharded step reproduces it:
+logits of its own planes, loss, all-reduced gradients, updated weights."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    pkg = importlib.import_module("h-denseunet_amd")
+    pkg.lib.use_emulator_for_tests()
+    import parity_utils as U
+    par, ka = U.pkg("parallel"), U.pkg("keras_api")
+    sh = par.depth_shard_info("gloo")
+    rank, world = sh.rank, sh.world
+    H, D = int(os.environ.get("SHARD_TEST_H", "32")), 8 * world
+    Dl = D // world
+    nb = (1, 1, 2, 1)
+    rng = np.random.default_rng(5)
+    vol = rng.normal(0, 50, (1, H, H, D, 4)).astype(np.float32)
+    lab = rng.integers(0, 3, (1, H, H, D, 1))
+    mk = U.pkg("densenet3d_sharded").dense_net3d
+
+    def compile_(m):
+        m.ctx.dropout_enabled = False
+        m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy])
+
+    # unsharded reference (same on every rank)
+    full = mk(U.make_args(1, H, D), dtype="f32", nb_layers3d=nb, seed=11)
+    compile_(full)
+    w0 = full.get_weights_dict()
+    # perturb BN / Scale parameters so identities cannot hide bugs
+    r2 = np.random.default_rng(9)
+    for n, arrs in w0.items():
+        if full.ctx.layer_kind[n] in ("bn", "scale"):
+            w0[n] = [(a + r2.normal(0, 0.1, a.shape)).astype(np.float32) if i != 3 else (a * r2.uniform(0.5, 1.5, a.shape)).astype(np.float32)
+                     for i, a in enumerate(arrs)]
+    full.set_weights_dict(w0)
+    loss_full = full.train_on_batch(vol, lab)
+    logits_full = full._download_logits().cpu().numpy()
+    g_full = full.ctx.G[:full.ctx.n_trainable].clone()
+    p_full = full.ctx.P.clone()
+
+    # sharded
+    m = mk(U.make_args(1, H, Dl), dtype="f32", nb_layers3d=nb, seed=3 + rank, shard=sh)
+    compile_(m)
+    m.set_weights_dict(w0)
+    par.attach_depth_shard(m)
+    sl = slice(rank * Dl, (rank + 1) * Dl)
+    loss = m.train_on_batch(vol[:, :, :, sl], lab[:, :, :, sl])
+    logits = m._download_logits().cpu().numpy()
+    e_log = float(np.abs(logits - logits_full[:, :, :, sl]).max() / max(1.0, np.abs(logits_full).max()))
+    g = m.ctx.G[:m.ctx.n_trainable]
+    e_g = float((g - g_full).norm() / g_full.norm())
+    e_p = float((m.ctx.P[:m.ctx.n_trainable] - p_full[:m.ctx.n_trainable]).abs().max())
+    # moving statistics (sync-BN): identical to the unsharded run
+    e_mv = float((m.ctx.P[m.ctx.n_trainable:] - p_full[m.ctx.n_trainable:]).abs().max())
+    print("rank %d: logits %.2e grad %.2e weights %.2e moving %.2e loss %.6f vs %.6f" % (rank, e_log, e_g, e_p, e_mv, loss, loss_full), flush=True)
+    assert e_log < 2e-4, e_log
+    assert abs(loss - loss_full) < 1e-4 * abs(loss_full)
+    assert e_g < 2e-2, e_g
+    assert e_p < 1e-5 and e_mv < 1e-4
+    dist.barrier()
+    if rank == 0:
+        print("SHARD_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

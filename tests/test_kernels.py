@@ -368,6 +368,33 @@ def test_maxpool(hdu, dtype, dims):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_maxpool_depth_halo_mode(hdu, dtype):
+    """pad_d=0: the caller supplies the neighbouring depth planes (depth sharding); equals the padded pool on the
+    interior of a volume whose first/last planes play the halo role"""
+    ops = ops_mod()
+    N, D, H, W, C = 1, 8, 6, 6, 8
+    x = q(rnd((N, D, H, W, C), 3, 1.0, dtype).clamp_min(0) + 0.01, dtype)
+    full = ops.Act.alloc(N, (D - 1) // 2 + 1, 3, 3, C, dtype)
+    ops.maxpool_fwd(mkact(ops, x, dtype), full)                       # reference pooling of the whole volume
+    # shard = planes 3..6 with halo plane 3 (low) and plane 8(absent -> zero)... take interior planes 4..7, halo 3 and zeros
+    sh = torch.zeros((N, 6, H, W, C), dtype=torch.float64)
+    sh[:, 0] = x[:, 3]
+    sh[:, 1:5] = x[:, 4:8]
+    out = ops.Act.alloc(N, 2, 3, 3, C, dtype)
+    am = torch.zeros(2 * 9 * C, dtype=torch.uint8, device=ops.device())
+    ops.maxpool_fwd(mkact(ops, sh, dtype), out, am, pad_d=0)
+    assert float((out.to_torch().cpu() - full.to_torch().cpu()[:, 2:4]).abs().max()) == 0.0
+    dy = rnd((N, 2, 3, 3, C), 5, 1.0, dtype)
+    dx = ops.Act.alloc(N, 6, H, W, C, dtype)
+    ops.maxpool_bwd(am, mkact(ops, dy, dtype), dx, pad_d=0)
+    xr = sh.clone().requires_grad_(True)
+    yr = F.max_pool3d(F.pad(xr.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 0, 0)), 3, 2).permute(0, 2, 3, 4, 1)
+    (yr * dy).sum().backward()
+    nz = sh > 0
+    assert_close(dx.to_torch().cpu().double()[nz], xr.grad[nz], dtype, scale=float(xr.grad.abs().max()), what="maxpool halo bwd")
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_avgpool_upsample(hdu, dtype):
     ops = ops_mod()
     N, D, H, W, C = 1, 3, 8, 6, 16
