@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # conv FLOPs (2*MAC) per slice, fwd + dgrad + wgrad (stem dgrad skipped)
-TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3}
+TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3d": 121.3}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 
 
@@ -35,6 +35,12 @@ def build(config, dtype, b, size, cols):
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy_2ddense
     elif config == "3dpart":
         m = importlib.import_module("h-denseunet_amd.denseunet3d").denseunet_3d(args, dtype=dtype)
+        loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
+    elif config == "shard3d":
+        par = importlib.import_module("h-denseunet_amd.parallel")
+        sh = par.depth_shard_info("nccl")
+        m = importlib.import_module("h-denseunet_amd.densenet3d_sharded").dense_net3d(args, dtype=dtype, shard=sh)
+        par.attach_depth_shard(m)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
     else:
         m = importlib.import_module("h-denseunet_amd.hybridnet").dense_rnn_net(args, dtype=dtype)
@@ -130,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="2d", choices=["2d", "3dpart", "end2end"])
+    ap.add_argument("--config", default="2d", choices=["2d", "3dpart", "end2end", "shard3d"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
@@ -153,12 +159,24 @@ def main():
     size = a.size or (512 if a.config == "2d" else 224)
     cols = a.cols if a.config != "2d" else None
 
+    if a.config == "shard3d":
+        # ONE volume of --cols depth planes split over the ranks (strong scaling); every rank builds the same phantom
+        # and keeps its own planes.  No hipGraph: the step contains the neighbour exchanges.
+        assert cols % (4 * world) == 0, "--cols must be a multiple of 4*world"
+        gcols, cols = cols, cols // world
+        a.no_graph = True
     m = build(a.config, a.dtype, b, size, cols)
-    if world > 1:
+    if world > 1 and a.config != "shard3d":
         par.attach_data_parallel(m)
     synth = importlib.import_module("h-denseunet_amd.synth")
     kind = "2d" if a.config == "2d" else "hybrid"
-    x, y = synth.synthetic_batch(kind, b, size, cols, seed=1234 + rank)
+    if a.config == "shard3d":
+        xv, yv = synth.synthetic_batch("hybrid", 1, size, gcols, seed=1234)
+        rng = np.random.default_rng(99)
+        xv = np.concatenate([xv, rng.normal(0, 60, xv.shape[:4] + (3,)).astype(np.float32)], -1)
+        x, y = xv[:, :, :, rank * cols:(rank + 1) * cols], yv[:, :, :, rank * cols:(rank + 1) * cols]
+    else:
+        x, y = synth.synthetic_batch(kind, b, size, cols, seed=1234 + rank)
     m._upload_x(x)
     m.loss_layer.set_labels(m._labels_internal(y))
     torch.cuda.synchronize()
@@ -184,18 +202,22 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / a.steps * 1e3
-    slices_per_step = (b if kind == "2d" else cols) * world
+    slices_per_step = (b if kind == "2d" else cols) * world   # shard3d: cols is per rank -> the whole volume
     value = slices_per_step / (ms / 1e3)
     loss = m.loss_value()
 
     out = {
-        "metric": "CT slices/sec fwd+bwd (%s)" % ("2D 512^2" if a.config == "2d" else "3D 224x224x12"),
+        "metric": "CT slices/sec fwd+bwd (%s)" % ("2D 512^2" if a.config == "2d" else
+                                                   ("3D %dx%dx%d depth-sharded" % (size, size, cols * world) if a.config == "shard3d"
+                                                    else "3D 224x224x12")),
         "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "strong" if a.config == "shard3d" else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on",
         "config": {"workload": {"2d": "2D DenseUNet-161 train step, batch %d x %dx%d per GPU (BASELINE configs[1])" % (b, size, size),
                                 "3dpart": "denseunet_3d train step, %dx%dx%d (BASELINE configs[2])" % (size, size, cols or 0),
-                                "end2end": "dense_rnn_net end2end train step, %dx%dx%d (BASELINE configs[3])" % (size, size, cols or 0)}[a.config],
+                                "end2end": "dense_rnn_net end2end train step, %dx%dx%d (BASELINE configs[3])" % (size, size, cols or 0),
+                                "shard3d": "3D DenseNet train step on ONE %dx%dx%d volume, depth-sharded (BASELINE configs[4] shape family)" % (size, size, (cols or 0) * world)}[a.config],
                    "global_batch_slices": slices_per_step, "parallelism": "dp%d" % world, "hipgraph": not a.no_graph,
                    "loss": round(loss, 5),
                    "step_conv_tflops": round(TRAIN_GFLOP_PER_SLICE[a.config] * slices_per_step / world / ms, 2)},
@@ -212,7 +234,7 @@ def main():
                                "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1], 3),
                                                         "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
             out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
         print(json.dumps(out))
     if world > 1:

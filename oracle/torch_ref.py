@@ -382,6 +382,12 @@ def dense_net_3d(P, img, variant="3dpart", reduction=0.5, nb_layers=(3, 4, 12, 8
     return x
 
 
+def dense_net_3d_standalone(P, img, nb_layers=(3, 4, 12, 8)):
+    """DenseNet3D with its own `3dclassifer` head (denseunet3d.py:105-190): returns the logits `x` of :187"""
+    feat = dense_net_3d(P, img, variant="3dpart", nb_layers=nb_layers)
+    return P.conv("3dclassifer", feat, 3, (1, 1, 1), padding="same")
+
+
 # --------------------------------------------------------------------------- hybrid nets
 def hybrid_net(P, img, variant="3dpart", nb_layers2d=(6, 12, 36, 24), nb_layers3d=(3, 4, 12, 8)):
     """denseunet3d.py:393-439 (`denseunet_3d`, variant '3dpart') / hybridnet.py:379-423 (`dense_rnn_net`,

@@ -26,10 +26,17 @@ def make_args(b, size, cols=None):
 def oracle_forward_fn(kind, variant, nb2d, nb3d):
     if kind == "2d":
         return lambda P, x: R.dense_unet_2d(P, x, variant=variant, nb_layers=nb2d)[1]
+    if kind == "3d":
+        return lambda P, x: R.dense_net_3d_standalone(P, x, nb_layers=nb3d)
     return lambda P, x: R.hybrid_net(P, x, variant=variant, nb_layers2d=nb2d, nb_layers3d=nb3d)
 
 
 def synthetic_batch(kind, b, size, cols, seed=1234):
+    if kind == "3d":   # 4-channel volume: CT + three pseudo-probability channels (what the 2D branch would supply)
+        x, y = pkg("synth").synthetic_batch("hybrid", b, size, cols, seed)
+        rng = np.random.default_rng(seed + 1)
+        extra = rng.normal(0.0, 60.0, x.shape[:4] + (3,)).astype(np.float32)
+        return np.concatenate([x, extra], -1), y
     return pkg("synth").synthetic_batch(kind, b, size, cols, seed)
 
 
@@ -44,6 +51,8 @@ def build_pair(kind, variant, b, size, cols, dtype, nb2d, nb3d, seed=4321, odtyp
     if kind == "2d":
         mod = pkg("denseunet" if variant == "denseunet" else "densenet")
         m = mod.DenseUNet(reduction=0.5, args=make_args(b, size), dtype=dtype, nb_layers=nb2d)
+    elif kind == "3d":
+        m = pkg("densenet3d_sharded").dense_net3d(make_args(b, size, cols), dtype=dtype, nb_layers3d=nb3d)
     elif variant == "3dpart":
         m = pkg("denseunet3d").denseunet_3d(make_args(b, size, cols), dtype=dtype, nb_layers2d=nb2d, nb_layers3d=nb3d)
     else:
@@ -56,7 +65,8 @@ def build_pair(kind, variant, b, size, cols, dtype, nb2d, nb3d, seed=4321, odtyp
 
 
 def loss_fn_for(kind):
-    return R.weighted_crossentropy_2ddense if kind == "2d" else R.weighted_crossentropy
+    # the stand-alone 3D net is trained on every voxel (the 1:7 slice of loss.py:6-7 belongs to the 8-slice hybrid)
+    return R.weighted_crossentropy if kind == "hybrid" else R.weighted_crossentropy_2ddense
 
 
 def rel_err(a, b):

@@ -23,6 +23,7 @@ def _pair(kind, variant, b, size, cols, dtype):
     ("2d", "densenet", 2, 224, None),
     ("hybrid", "3dpart", 1, 224, 12),           # configs[2]
     ("hybrid", "end2end", 1, 224, 12),          # configs[3]
+    ("3d", "3dpart", 1, 224, 12),               # the per-shard network of configs[4] (unsharded)
 ])
 def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
     m, P, fwd = _pair(kind, variant, b, size, cols, "f32")
@@ -62,7 +63,7 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
     assert worst[0] < 5e-2, "gradient L2 mismatch: %s" % (worst,)
     # SGD update direction: updated weights moved by (-lr*g*(1+momentum)) -> compare deltas on the classifier
     w_after = m.get_weights_dict()
-    last = "dense167classifer" if kind == "2d" else "2d3dclassifer"
+    last = {"2d": "dense167classifer", "hybrid": "2d3dclassifer", "3d": "3dclassifer"}[kind]
     d_got = w_after[last][0] - w_before[last][0]
     d_ref = P.numpy()[last][0] - w_before[last][0]
     assert np.linalg.norm(d_got - d_ref) <= 2e-2 * np.linalg.norm(d_ref) + 1e-9

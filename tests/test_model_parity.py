@@ -15,6 +15,7 @@ CASES = [
     pytest.param("2d", "densenet", 1, 64, None, id="densenet-noskips"),
     pytest.param("hybrid", "3dpart", 1, 32, 8, id="denseunet_3d-3dpart"),
     pytest.param("hybrid", "end2end", 1, 32, 8, id="dense_rnn_net-end2end"),
+    pytest.param("3d", "3dpart", 1, 32, 8, id="densenet3d-standalone"),
 ]
 
 
