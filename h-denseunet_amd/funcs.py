@@ -1,0 +1,50 @@
+"""Drop-in for lib/funcs.py:4-51 `predict_tumor_inwindow`: z-sliding-window inference with score averaging
+(SURVEY.md section 8f, row N1).  Same arguments and return values; differences in mechanism only:
+ * the CT volume, the accumulated `score` and `score_num` stay resident in HBM for the whole sweep (the reference
+   round-trips every window through numpy and grows the TF graph with K.softmax/K.eval nodes per iteration,
+   lib/funcs.py:31-32);
+ * each window is copied device-to-device into the model's input buffer and run with Model.predict's launch list
+   (learning_phase 0).
+The 3-class softmax and the accumulation are a handful of torch element-wise ops on the logits (post-processing, not
+part of the per-voxel network path)."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def predict_tumor_inwindow(model, imgs_test, num, mini, maxi, args):
+    batch = args.b
+    img_deps, img_rows, img_cols = args.input_size, args.input_size, args.input_cols
+    if batch != 1 or model.kind != "hybrid":
+        raise ValueError("predict_tumor_inwindow drives the hybrid nets with b=1 (test.py:27-29)")
+    window_cols = img_cols // 4                       # lib/funcs.py:12 (py2 integer division)
+    x, y, z = imgs_test.shape[:3]
+    if x < img_deps or y < img_rows or z < img_cols:
+        raise ValueError("volume smaller than the network window")
+    right_cols = int(min(z, maxi[2] + 10) - img_cols)
+    left_cols = max(0, min(mini[2] - 5, right_cols))
+    dev = model.ctx.dev
+    # depth-major resident copy of the cropped volume: [z][deps][rows]
+    vol = torch.as_tensor(np.ascontiguousarray(np.asarray(imgs_test[:img_deps, :img_rows, :], np.float32).transpose(2, 0, 1))).to(dev)
+    score = torch.zeros((z, img_deps, img_rows, num), dtype=torch.float32, device=dev)
+    score_num = torch.zeros((z, 1, 1, 1), dtype=torch.float32, device=dev)
+    ctx = model.ctx
+    a = model.logits.act
+    for cols in range(left_cols, right_cols + window_cols, window_cols):
+        c0 = z - img_cols if cols > z - img_cols else cols        # lib/funcs.py:26-28: last window is clamped
+        model.vol.copy_(vol[c0:c0 + img_cols].reshape(-1))
+        ctx.learning_phase = 0
+        try:
+            ctx.prep_weights()
+            ctx.run_forward()
+        finally:
+            ctx.learning_phase = 1
+        ops.cast_out(a, 3, model.out_stage)
+        prob = torch.softmax(model.out_stage.reshape(img_cols, img_deps, img_rows, 3), dim=-1)
+        score[c0 + 1:c0 + img_cols - 1] += prob[1:-1, :, :, :num]   # first / last slice of each window dropped (:33)
+        score_num[c0 + 1:c0 + img_cols - 1] += 1
+    score = score / (score_num + 1e-4)
+    out = np.zeros((x, y, z, num), np.float32)
+    out[:img_deps, :img_rows] = score.permute(1, 2, 0, 3).cpu().numpy()
+    return out[:, :, :, num - 2], out[:, :, :, num - 1]

@@ -1,0 +1,40 @@
+"""N1: z-sliding-window inference (lib/funcs.py:4-51) -- the HBM-resident implementation equals a literal numpy
+restatement of the reference loop driven through Model.predict."""
+import numpy as np
+
+import parity_utils as U
+
+
+def reference_loop(model, imgs_test, num, mini, maxi, args):
+    """lib/funcs.py:4-51 restated with numpy (softmax via numpy instead of K.softmax/K.eval)"""
+    batch, img_deps, img_rows, img_cols = args.b, args.input_size, args.input_size, args.input_cols
+    window_cols = img_cols // 4
+    box_test = np.zeros((batch, img_deps, img_rows, img_cols, 1), dtype="float32")
+    x, y, z = imgs_test.shape
+    right_cols = int(min(z, maxi[2] + 10) - img_cols)
+    left_cols = max(0, min(mini[2] - 5, right_cols))
+    score = np.zeros((x, y, z, num), dtype="float32")
+    score_num = np.zeros((x, y, z, num), dtype="int16")
+    for cols in range(left_cols, right_cols + window_cols, window_cols):
+        c0 = z - img_cols if cols > z - img_cols else cols
+        box_test[0, :, :, :, 0] = imgs_test[0:img_deps, 0:img_rows, c0:c0 + img_cols]
+        m = model.predict(box_test, batch_size=batch, verbose=0)
+        e = np.exp(m - m.max(-1, keepdims=True))
+        m = (e / e.sum(-1, keepdims=True))[:, :, :, 1:-1, :]
+        score[0:img_deps, 0:img_rows, c0 + 1:c0 + img_cols - 1, :] += m[0]
+        score_num[0:img_deps, 0:img_rows, c0 + 1:c0 + img_cols - 1, :] += 1
+    score = score / (score_num + 1e-4)
+    return score[:, :, :, num - 2], score[:, :, :, num - 1]
+
+
+def test_sliding_window_matches_reference_loop(emu_lib):
+    args = U.make_args(1, 32, 8)
+    model = U.pkg("hybridnet").dense_rnn_net(args, dtype="f32", nb_layers2d=(2, 2, 2, 2), nb_layers3d=(1, 1, 2, 1))
+    vol, _ = U.pkg("synth").synthetic_ct((32, 32, 12), seed=3)
+    mini, maxi = (0, 0, 4), (31, 31, 9)
+    s1, s2 = U.pkg("funcs").predict_tumor_inwindow(model, vol, 3, mini, maxi, args)
+    r1, r2 = reference_loop(model, vol, 3, mini, maxi, args)
+    assert s1.shape == (32, 32, 12)
+    np.testing.assert_allclose(s1, r1, atol=2e-6)
+    np.testing.assert_allclose(s2, r2, atol=2e-6)
+    assert float(np.abs(s1).max()) > 0
