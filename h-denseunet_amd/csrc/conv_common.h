@@ -24,6 +24,7 @@ struct ConvK {
   unsigned drop_seed;
   const unsigned* drop_seed_dev;
   int xcd_swizzle;
+  int debug_flags;            // developer experiments only (HDU_TUNE_DEBUG): 1 = skip operand DMA, 2 = skip MFMA
   int vec_out;                // output rows are 16-byte addressable (DMA kernels' vector epilogue)
 };
 

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 
   // ---- per-thread k state: this thread always stages 16-byte chunk `kc` of the K tile ----
   int k = kc * CH;
+  int tap_i = 0;
   int c, kd, kh, kw;
   {
     const int tap = k / p.Cin;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
     c += BK;
     while (c >= p.Cin) {
       c -= p.Cin;
+      ++tap_i;
       if (++kw == p.KW) {
         kw = 0;
         if (++kh == p.KH) {
@@ -742,7 +744,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
 // swizzle is applied by permuting which logical k-chunk each lane fetches.
 __device__ __attribute__((aligned(16))) unsigned hdu_zero_page[16];
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
@@ -774,29 +776,42 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   const char* zero = (const char*)hdu_zero_page;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
+  // per-row state.  FAST (no up-sampling, <= 32 taps, tensor < 2^31 elements): a tap-validity bitmask and an
+  // element offset per row are computed ONCE, so a DMA in the K loop costs a shift/and, one add and the pointer add.
   int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
+  unsigned rmask[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const long long m = m0 + r0 + i * 32;
-    if (m < p.M) {
-      const int ow = (int)(m % p.Wo);
-      long long t = m / p.Wo;
-      const int oh = (int)(t % p.Ho);
-      t /= p.Ho;
-      const int od = (int)(t % p.Do);
-      rn[i] = (int)(t / p.Do);
-      rid[i] = od * p.sd - p.pd;
-      rih[i] = oh * p.sh - p.ph;
-      riw[i] = ow * p.sw - p.pw;
+    const unsigned m = (unsigned)(m0 + r0 + i * 32);     // M < 2^31 (checked on the host)
+    rmask[i] = 0u;
+    if ((long long)m < p.M) {
+      const unsigned ow = m % (unsigned)p.Wo;
+      unsigned t = m / (unsigned)p.Wo;
+      const unsigned oh = t % (unsigned)p.Ho;
+      t /= (unsigned)p.Ho;
+      const unsigned od = t % (unsigned)p.Do;
+      rn[i] = (int)(t / (unsigned)p.Do);
+      rid[i] = (int)od * p.sd - p.pd;
+      rih[i] = (int)oh * p.sh - p.ph;
+      riw[i] = (int)ow * p.sw - p.pw;
       rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
+      if (FAST) {
+        unsigned mw = 0u, mhw = 0u, mall = 0u;
+        for (int q = 0; q < p.KW; ++q) mw |= ((unsigned)(riw[i] + q) < (unsigned)p.We ? 1u : 0u) << q;
+        for (int q = 0; q < p.KH; ++q) if ((unsigned)(rih[i] + q) < (unsigned)p.He) mhw |= mw << (q * p.KW);
+        for (int q = 0; q < p.KD; ++q) if ((unsigned)(rid[i] + q) < (unsigned)p.De) mall |= mhw << (q * p.KH * p.KW);
+        rmask[i] = mall;
+        rpix[i] *= (int)p.ldx;                             // element offset of tap (0,0,0), channel 0
+      }
     } else {
       rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
     }
   }
   int k = kcl * CH;
-  int c, kd, kh, kw;
+  int c, kd, kh, kw, tap_i;
   {
     const int tap = k / p.Cin;
+    tap_i = tap;
     c = k - tap * p.Cin;
     kw = tap % p.KW;
     const int t = tap / p.KW;
@@ -816,15 +831,25 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     char* Bs = As + BM * 128;
     const bool kvalid = kd < p.KD;
     const int tapoff = (kd * p.He + kh) * p.We + kw;
+    if (FAST) {
+      const int toff = tapoff * (int)p.ldx + c;            // element offset of this lane's (tap, channel chunk)
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
-      const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
-                      (unsigned)iw < (unsigned)p.We;
-      const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
-                          : rpix[i] + tapoff;
-      const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
-      hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = kvalid && ((rmask[i] >> tap_i) & 1u);
+        const char* g = ok ? (const char*)(xp + (rpix[i] + toff)) : zero;
+        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
+        const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                        (unsigned)iw < (unsigned)p.We;
+        const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
+                            : rpix[i] + tapoff;
+        const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
@@ -840,6 +865,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     c += BK;
     while (c >= p.Cin) {
       c -= p.Cin;
+      ++tap_i;
       if (++kw == p.KW) {
         kw = 0;
         if (++kh == p.KH) {
@@ -863,9 +889,9 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {
       advance();
-      issue_tile(buf ^ 1);
+      if (!(p.debug_flags & 1)) issue_tile(buf ^ 1);     // debug: measure the loop without operand traffic
     }
-    {
+    if (!(p.debug_flags & 2)) {                           // debug: measure the loop without MFMA / LDS reads
       const char* As = smem + buf * STAGE;
       const char* Bs = As + BM * 128;
 #pragma unroll
@@ -912,7 +938,7 @@ template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_n() {
   else { static_assert(N == 0, "add the vmcnt immediate"); }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
@@ -946,29 +972,42 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   const char* zero = (const char*)hdu_zero_page;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
+  // per-row state.  FAST (no up-sampling, <= 32 taps, tensor < 2^31 elements): a tap-validity bitmask and an
+  // element offset per row are computed ONCE, so a DMA in the K loop costs a shift/and, one add and the pointer add.
   int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
+  unsigned rmask[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const long long m = m0 + r0 + i * 32;
-    if (m < p.M) {
-      const int ow = (int)(m % p.Wo);
-      long long t = m / p.Wo;
-      const int oh = (int)(t % p.Ho);
-      t /= p.Ho;
-      const int od = (int)(t % p.Do);
-      rn[i] = (int)(t / p.Do);
-      rid[i] = od * p.sd - p.pd;
-      rih[i] = oh * p.sh - p.ph;
-      riw[i] = ow * p.sw - p.pw;
+    const unsigned m = (unsigned)(m0 + r0 + i * 32);     // M < 2^31 (checked on the host)
+    rmask[i] = 0u;
+    if ((long long)m < p.M) {
+      const unsigned ow = m % (unsigned)p.Wo;
+      unsigned t = m / (unsigned)p.Wo;
+      const unsigned oh = t % (unsigned)p.Ho;
+      t /= (unsigned)p.Ho;
+      const unsigned od = t % (unsigned)p.Do;
+      rn[i] = (int)(t / (unsigned)p.Do);
+      rid[i] = (int)od * p.sd - p.pd;
+      rih[i] = (int)oh * p.sh - p.ph;
+      riw[i] = (int)ow * p.sw - p.pw;
       rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
+      if (FAST) {
+        unsigned mw = 0u, mhw = 0u, mall = 0u;
+        for (int q = 0; q < p.KW; ++q) mw |= ((unsigned)(riw[i] + q) < (unsigned)p.We ? 1u : 0u) << q;
+        for (int q = 0; q < p.KH; ++q) if ((unsigned)(rih[i] + q) < (unsigned)p.He) mhw |= mw << (q * p.KW);
+        for (int q = 0; q < p.KD; ++q) if ((unsigned)(rid[i] + q) < (unsigned)p.De) mall |= mhw << (q * p.KH * p.KW);
+        rmask[i] = mall;
+        rpix[i] *= (int)p.ldx;                             // element offset of tap (0,0,0), channel 0
+      }
     } else {
       rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
     }
   }
   int k = kcl * CH;
-  int c, kd, kh, kw;
+  int c, kd, kh, kw, tap_i;
   {
     const int tap = k / p.Cin;
+    tap_i = tap;
     c = k - tap * p.Cin;
     kw = tap % p.KW;
     const int t = tap / p.KW;
@@ -987,15 +1026,25 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     char* Bs = As + BM * 128;
     const bool kvalid = kd < p.KD;
     const int tapoff = (kd * p.He + kh) * p.We + kw;
+    if (FAST) {
+      const int toff = tapoff * (int)p.ldx + c;            // element offset of this lane's (tap, channel chunk)
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
-      const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
-                      (unsigned)iw < (unsigned)p.We;
-      const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
-                          : rpix[i] + tapoff;
-      const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
-      hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = kvalid && ((rmask[i] >> tap_i) & 1u);
+        const char* g = ok ? (const char*)(xp + (rpix[i] + toff)) : zero;
+        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int id = rid[i] + kd, ih = rih[i] + kh, iw = riw[i] + kw;
+        const bool ok = kvalid && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                        (unsigned)iw < (unsigned)p.We;
+        const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
+                            : rpix[i] + tapoff;
+        const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
@@ -1007,6 +1056,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     c += BK;
     while (c >= p.Cin) {
       c -= p.Cin;
+      ++tap_i;
       if (++kw == p.KW) {
         kw = 0;
         if (++kh == p.KH) {
@@ -1410,9 +1460,18 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   k->drop_seed_dev = d->drop_seed_dev;
   k->xcd_swizzle = g_tuning[HDU_TUNE_XCD_SWIZZLE];
   k->vec_out = 1;
+  k->debug_flags = g_tuning[HDU_TUNE_DEBUG];
   if (!wgrad && d->y && (d->Cout % ch || d->ldy % ch || (uintptr_t)d->y % 16))
     return hdu_set_error(HDU_ERR_ARG, "conv: Cout / output pixel stride must be multiples of the 16-byte chunk and y 16-byte aligned");
   return 0;
+}
+
+// FAST addressing needs: no up-sampling, <= 32 taps, every element offset of the input within int32
+static bool igemm_fast_ok(const ConvK& k) {
+  if (g_tuning[HDU_TUNE_NO_FAST]) return false;
+  if ((k.ud | k.uh | k.uw) != 0 || k.KD * k.KH * k.KW > 32) return false;
+  const long long span = ((long long)k.N * k.De * k.He * k.We + (long long)k.He * k.We * 8) * k.ldx;
+  return span < (1ll << 31);
 }
 
 template <typename T, int BM, int BN, int WMv, int WNv>
@@ -1424,12 +1483,16 @@ static void launch_igemm(const ConvK& k, hipStream_t s) {
     constexpr int NSD = STAGE * 6 <= 160 * 1024 ? 6 : 4;
     const long long nblk = (long long)grid.x * grid.y;
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
-    if (STAGE * NSD <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128)))
-      HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD>), grid, dim3(256), 0, s, k);
-    else if (mode == 3)
-      HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3>), grid, dim3(256), 0, s, k);
-    else
-      HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
+    const bool fast = igemm_fast_ok(k);
+    if (STAGE * NSD <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128))) {
+      if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, k);
+      else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, k);
+    } else if (mode == 3) {
+      HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3, false>), grid, dim3(256), 0, s, k);
+    } else {
+      if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true>), grid, dim3(256), 0, s, k);
+      else HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, false>), grid, dim3(256), 0, s, k);
+    }
   } else
     HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
 }

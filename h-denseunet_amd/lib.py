@@ -132,6 +132,10 @@ def load(path=None):
     _backend = _lib.hdu_backend().decode()
     if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
         _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_NO_FAST" in os.environ:
+        _lib.hdu_set_tuning(5, int(os.environ["HDU_NO_FAST"]))
+    if "HDU_DEBUG_FLAGS" in os.environ:
+        _lib.hdu_set_tuning(4, int(os.environ["HDU_DEBUG_FLAGS"]))
     if "HDU_XCD_SWIZZLE" in os.environ:
         _lib.hdu_set_tuning(3, int(os.environ["HDU_XCD_SWIZZLE"]))
     if "HDU_WGRAD_TARGET" in os.environ:
