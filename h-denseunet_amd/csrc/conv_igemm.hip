@@ -921,21 +921,47 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 // workgroup per CU), where latency rather than occupancy limits the K loop and one workgroup may take the LDS.
 template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_n() {
   if constexpr (N == 0) { HDU_WAIT_VMCNT(0); }
+  else if constexpr (N == 1) { HDU_WAIT_VMCNT(1); }
   else if constexpr (N == 2) { HDU_WAIT_VMCNT(2); }
   else if constexpr (N == 3) { HDU_WAIT_VMCNT(3); }
   else if constexpr (N == 4) { HDU_WAIT_VMCNT(4); }
   else if constexpr (N == 5) { HDU_WAIT_VMCNT(5); }
   else if constexpr (N == 6) { HDU_WAIT_VMCNT(6); }
+  else if constexpr (N == 7) { HDU_WAIT_VMCNT(7); }
   else if constexpr (N == 8) { HDU_WAIT_VMCNT(8); }
   else if constexpr (N == 9) { HDU_WAIT_VMCNT(9); }
   else if constexpr (N == 10) { HDU_WAIT_VMCNT(10); }
+  else if constexpr (N == 11) { HDU_WAIT_VMCNT(11); }
   else if constexpr (N == 12) { HDU_WAIT_VMCNT(12); }
+  else if constexpr (N == 13) { HDU_WAIT_VMCNT(13); }
+  else if constexpr (N == 14) { HDU_WAIT_VMCNT(14); }
   else if constexpr (N == 15) { HDU_WAIT_VMCNT(15); }
   else if constexpr (N == 16) { HDU_WAIT_VMCNT(16); }
+  else if constexpr (N == 17) { HDU_WAIT_VMCNT(17); }
   else if constexpr (N == 18) { HDU_WAIT_VMCNT(18); }
+  else if constexpr (N == 19) { HDU_WAIT_VMCNT(19); }
   else if constexpr (N == 20) { HDU_WAIT_VMCNT(20); }
+  else if constexpr (N == 21) { HDU_WAIT_VMCNT(21); }
+  else if constexpr (N == 22) { HDU_WAIT_VMCNT(22); }
+  else if constexpr (N == 23) { HDU_WAIT_VMCNT(23); }
   else if constexpr (N == 24) { HDU_WAIT_VMCNT(24); }
-  else { static_assert(N == 0, "add the vmcnt immediate"); }
+  else if constexpr (N == 25) { HDU_WAIT_VMCNT(25); }
+  else if constexpr (N == 26) { HDU_WAIT_VMCNT(26); }
+  else if constexpr (N == 27) { HDU_WAIT_VMCNT(27); }
+  else if constexpr (N == 28) { HDU_WAIT_VMCNT(28); }
+  else if constexpr (N == 29) { HDU_WAIT_VMCNT(29); }
+  else if constexpr (N == 30) { HDU_WAIT_VMCNT(30); }
+  else if constexpr (N == 31) { HDU_WAIT_VMCNT(31); }
+  else if constexpr (N == 32) { HDU_WAIT_VMCNT(32); }
+  else if constexpr (N == 33) { HDU_WAIT_VMCNT(33); }
+  else if constexpr (N == 34) { HDU_WAIT_VMCNT(34); }
+  else if constexpr (N == 35) { HDU_WAIT_VMCNT(35); }
+  else if constexpr (N == 36) { HDU_WAIT_VMCNT(36); }
+  else if constexpr (N == 37) { HDU_WAIT_VMCNT(37); }
+  else if constexpr (N == 38) { HDU_WAIT_VMCNT(38); }
+  else if constexpr (N == 39) { HDU_WAIT_VMCNT(39); }
+  else if constexpr (N == 40) { HDU_WAIT_VMCNT(40); }
+  else { static_assert(N <= 40, "add the vmcnt immediate"); }
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST>
@@ -1232,9 +1258,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
     const int buf = st & 1;
     if (st + 1 < nsteps) {
       advance_pixels();
-      issue_tile(buf ^ 1, m_begin + (long long)(st + 1) * PX);
+      if (!(p.debug_flags & 1)) issue_tile(buf ^ 1, m_begin + (long long)(st + 1) * PX);
     }
-    {
+    if (!(p.debug_flags & 2)) {
       const char* Xt = smem + buf * STAGE;
       const char* Dt = Xt + PX * XROWB;
 #pragma unroll
@@ -1273,7 +1299,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int kcol = kcol0 + wave * 32 + j * 16 + (lane & 15);
-        if (kcol < p.Ktot) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
+        if (kcol < p.Ktot && !(p.debug_flags & 4)) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
       }
     }
 }
@@ -1497,38 +1523,48 @@ static void launch_igemm(const ConvK& k, hipStream_t s) {
     HDU_LAUNCH((conv_igemm_kernel<T, BM, BN, WMv, WNv>), grid, dim3(256), 0, s, k);
 }
 
-// tile choice: the N tile that wastes the fewest padded output channels (ties -> widest); 64-row tiles for small images
+// tile choice.  Every N tile re-loads the whole A operand (the activations), and for Cout <= 192 a single N tile also
+// writes full output rows, so wide tiles are preferred: cost model = n_tiles * (BN + 32) (MFMA columns + the A-load
+// expressed in column equivalents); 64-row tiles below 16 K pixels.
 static void choose_igemm(const ConvK& k, int* bm, int* bn) {
-  const int cands[4] = {128, 64, 48, 32};
+  const int cands[6] = {192, 128, 96, 64, 48, 32};
   int best = 64;
   long long best_cost = -1;
-  for (int i = 0; i < 4; ++i) {
+  const int maxbn = g_tuning[HDU_TUNE_MAX_BN] > 0 ? g_tuning[HDU_TUNE_MAX_BN] : 128;   // 192 measured slower
+  for (int i = 0; i < 6; ++i) {
     const int c = cands[i];
-    if (c == 128 && (k.Cout < 256 || k.M < 4096)) continue;
-    const long long padded = (long long)((k.Cout + c - 1) / c) * c;
-    if (best_cost < 0 || padded < best_cost) { best_cost = padded; best = c; }
+    if (c > maxbn) continue;
+    const long long ntiles = (k.Cout + c - 1) / c;
+    const long long cost = ntiles * (c + 32);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
   }
   *bn = best;
-  *bm = (k.M <= 16384 && best != 128) ? 64 : 128;
+  *bm = (k.M <= 16384) ? 64 : 128;
+}
+
+template <int BM, int BN> struct WaveLayout {           // (waves along M, waves along N)
+  static constexpr int WM = (BN >= 128) ? 2 : ((BM == 64 && (BN == 64 || BN == 32)) ? 2 : 4);
+  static constexpr int WN = 4 / WM;
+};
+
+template <typename T, int BM>
+static void dispatch_igemm_bn(const ConvK& k, int bn, hipStream_t s) {
+  switch (bn) {
+    case 192: launch_igemm<T, BM, 192, WaveLayout<BM, 192>::WM, WaveLayout<BM, 192>::WN>(k, s); return;
+    case 128: launch_igemm<T, BM, 128, WaveLayout<BM, 128>::WM, WaveLayout<BM, 128>::WN>(k, s); return;
+    case 96: launch_igemm<T, BM, 96, WaveLayout<BM, 96>::WM, WaveLayout<BM, 96>::WN>(k, s); return;
+    case 64: launch_igemm<T, BM, 64, WaveLayout<BM, 64>::WM, WaveLayout<BM, 64>::WN>(k, s); return;
+    case 48: launch_igemm<T, BM, 48, WaveLayout<BM, 48>::WM, WaveLayout<BM, 48>::WN>(k, s); return;
+    default: launch_igemm<T, BM, 32, WaveLayout<BM, 32>::WM, WaveLayout<BM, 32>::WN>(k, s); return;
+  }
 }
 
 template <typename T>
 static void dispatch_igemm(const ConvK& k, hipStream_t s) {
   int bm, bn;
   choose_igemm(k, &bm, &bn);
-  if (bm == 64) {
-    switch (bn) {
-      case 64: launch_igemm<T, 64, 64, 2, 2>(k, s); return;
-      case 48: launch_igemm<T, 64, 48, 4, 1>(k, s); return;
-      default: launch_igemm<T, 64, 32, 2, 2>(k, s); return;
-    }
-  }
-  switch (bn) {
-    case 128: launch_igemm<T, 128, 128, 2, 2>(k, s); return;
-    case 64: launch_igemm<T, 128, 64, 4, 1>(k, s); return;
-    case 48: launch_igemm<T, 128, 48, 4, 1>(k, s); return;
-    default: launch_igemm<T, 128, 32, 4, 1>(k, s); return;
-  }
+  if (bm == 64) dispatch_igemm_bn<T, 64>(k, bn, s);
+  else dispatch_igemm_bn<T, 128>(k, bn, s);
 }
 
 extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
@@ -1662,7 +1698,7 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   } else {
     int bm, bn;
     choose_igemm(k, &bm, &bn);
-    const int wm = (bm == 128 && bn == 128) ? 2 : ((bm == 64 && bn != 48) ? 2 : 4);
+    const int wm = (bn >= 128) ? 2 : ((bm == 64 && (bn == 64 || bn == 32)) ? 2 : 4);
     const bool dma = k.pro_a == nullptr && k.skip == nullptr && k.vec_out;
     const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];

@@ -132,6 +132,8 @@ def load(path=None):
     _backend = _lib.hdu_backend().decode()
     if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
         _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_MAX_BN" in os.environ:
+        _lib.hdu_set_tuning(6, int(os.environ["HDU_MAX_BN"]))
     if "HDU_NO_FAST" in os.environ:
         _lib.hdu_set_tuning(5, int(os.environ["HDU_NO_FAST"]))
     if "HDU_DEBUG_FLAGS" in os.environ:

@@ -68,6 +68,8 @@ for (name, N, D, H, W, Cin, Cout, K, up, pro, st, pad) in (S2D if which == "2d" 
     T = K[0] * K[1] * K[2]
     w = (torch.randn(Cout * T * Cin, device="cuda") * 0.05).to(tdt)
     a = torch.rand(Cin, device="cuda") + 0.5; b = torch.rand(Cin, device="cuda") - 0.5
+    if os.environ.get("BENCH_NOPRO"):
+        pro = False          # model-like: inputs are materialised, every conv is the DMA form
     d = ops.conv_desc(x, ctypes.c_void_p(w.data_ptr()), y, K, st, pad, up, None, (a, b) if pro else None, True)
     flops = 2.0 * N * Do * Ho * Wo * Cout * T * Cin
     t_f = timeit(lambda: ops.conv_fprop(d))
