@@ -1305,6 +1305,148 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
 }
 
 // =====================================================================================
+// Halo-tile filter gradient for 2D 3x3 stride-1 "same" convolutions (bf16).
+// The im2col view used by conv_wgrad_dma_kernel re-loads every input pixel once per tap and the output gradient
+// once per k-column tile: measured, that kernel is bound by L2->LDS DMA traffic.  Here a workgroup owns a spatial
+// tile of 4 x 32 output pixels and 32 input channels: it DMAs the (4+2) x (32+2) input halo tile and the dy tile
+// ONCE and forms all 9 taps from LDS (transpose reads at shifted pixel addresses), i.e. 9x the MFMA work per byte.
+// Accumulators: 9 taps x [BCO x 32] per workgroup; wave w owns (tap, 16-channel tile) combos w, w+4, ... and all
+// BCO/16 output-channel tiles, so each B fragment is reused BCO/16 times and each A fragment ~4.5 times.
+template <int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __restrict__ dw, int tiles_per_split) {
+  typedef bf16_t T;
+  constexpr int TH = 4, TW = 32, HC = TW + 2, HP = (TH + 2) * HC;      // 204 halo pixels
+  constexpr int HPP = 208;                                             // padded to 16-pixel DMA instructions
+  constexpr int XBYTES = HPP * 64;                                     // 32 channels * 2 B per halo pixel
+  constexpr int DROWB = 128;
+  constexpr int DBYTES = TH * TW * DROWB;
+  constexpr int STAGE = XBYTES + DBYTES;
+  constexpr int TMc = BCO / 16;
+  constexpr int NQ = 5;                                                // combos per wave (18 combos over 4 waves)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dyp = (const T*)p.y;
+  const char* zero = (const char*)hdu_zero_page;
+  const int c0 = blockIdx.x * 32;
+  const int co0 = blockIdx.y * BCO;
+  const int H = p.He, W = p.We;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = p.N * tiles_y * tiles_x;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  int t_end = t_begin + tiles_per_split;
+  if (t_end > ntiles) t_end = ntiles;
+
+  // dy tile lane roles (as in conv_wgrad_dma_kernel): physical chunk tid&7 of tile pixels (tid>>3)+32*j
+  const int dpx0 = tid >> 3;
+  const int gd = ((dpx0 >> 1) & 1) | (((dpx0 >> 3) & 1) << 1);
+  const int dp16 = tid & 7;
+  const int dcl = ((((dp16 >> 1) ^ gd) << 1) | (dp16 & 1));
+  const bool dvalid = dcl * 8 < BCO && co0 + dcl * 8 < p.Cout;
+
+  auto issue_tile = [&](int buf, int t) {
+    char* Xh = smem + buf * STAGE;
+    char* Dt = Xh + XBYTES;
+    const int txi = t % tiles_x;
+    const int r = t / tiles_x;
+    const int tyi = r % tiles_y;
+    const int n = r / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    // input halo tile: instruction jj covers halo pixels jj*16 .. jj*16+15 (4 x 16-byte chunks each)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jj = j * 4 + wave;
+      if (jj < HPP / 16) {                                  // wave-uniform
+        const int hp = jj * 16 + (lane >> 2);
+        const int pc = lane & 3;                           // physical 16-byte chunk inside the pixel's 64 B
+        const int lc = ((((pc >> 1) ^ ((hp >> 3) & 1)) << 1) | (pc & 1));
+        const int hr = hp / HC, hc = hp - hr * HC;
+        const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const char* g = ok ? (const char*)(xp + ((long long)(n * H + iy) * W + ix) * p.ldx + c0 + lc * 8) : zero;
+        hdu_glds16(g, Xh + jj * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tp = dpx0 + j * 32;                        // tile pixel = ty*32 + tx
+      const int oy = y0 + (tp >> 5), ox = x0 + (tp & 31);
+      const bool ok = dvalid && oy < H && ox < W;
+      const char* g = ok ? (const char*)(dyp + ((long long)(n * H + oy) * W + ox) * p.ldy + co0 + dcl * 8) : zero;
+      hdu_glds16(g, Dt + (j * 32 + wave * 8) * DROWB);
+    }
+  };
+
+  f32x4 acc[NQ][TMc];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < TMc; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (t_begin < t_end) issue_tile(0, t_begin);
+  __syncthreads();
+  const int li = lane & 15, lg = lane >> 4;
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    if (t + 1 < t_end) issue_tile(buf ^ 1, t + 1);
+    {
+      const char* Xh = smem + buf * STAGE;
+      const char* Dt = Xh + XBYTES;
+#pragma unroll
+      for (int kg = 0; kg < TH; ++kg) {                    // k-group = tile row kg: 32 pixels
+        u32x4 af[TMc];
+        const int prow = kg * 32 + lg * 8 + (li >> 2);
+#pragma unroll
+        for (int i = 0; i < TMc; ++i) {
+          const int bc = (i * 16 + (li & 3) * 4) * 2;
+          const u32x2 lo = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow, bc));
+          const u32x2 hi = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow + 4, bc));
+          af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int combo = wave + 4 * q;
+          if (combo < 18) {                                // wave-uniform
+            const int tap = combo >> 1, ct = combo & 1;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int hp = (kg + kh) * HC + lg * 8 + (li >> 2) + kw;
+            const int hp2 = hp + 4;
+            const u32x2 lo = hdu_lds_tr16_b64(Xh + hp * 64 + ((ct ^ ((hp >> 3) & 1)) << 5) + (li & 3) * 8);
+            const u32x2 hi = hdu_lds_tr16_b64(Xh + hp2 * 64 + ((ct ^ ((hp2 >> 3) & 1)) << 5) + (li & 3) * 8);
+            const u32x4 bf = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int i = 0; i < TMc; ++i) acc[q][i] = Mma<T>::kgroup(af[i], bf, acc[q][i]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int combo = wave + 4 * q;
+    if (combo >= 18) continue;
+    const int tap = combo >> 1, ct = combo & 1;
+    const int c = c0 + ct * 16 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < TMc; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
+        if (co < p.Cout && c < p.Cin) atomicAdd(dw + (long long)co * p.Ktot + tap * p.Cin + c, acc[q][i][r]);
+      }
+  }
+}
+
+// =====================================================================================
 // strided data gradient (only the stride-2 stems need it; tiny share of the FLOPs): direct gather form,
 // one thread per (input pixel, 16-byte channel chunk).  w is the forward filter [Cout][T][Cin] in dtype T.
 template <typename T>
@@ -1434,10 +1576,10 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep
 // ------------------------------------------------------------------ host-side dispatch
 #include "hdu_host.h"
 
-int g_tuning[8] = {2, 0, 0, 1, 0, 0, 0, 0};
+int g_tuning[16] = {2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" int hdu_set_tuning(int key, int value) {
-  if (key < 0 || key >= 8) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
+  if (key < 0 || key >= 16) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
   g_tuning[key] = value;
   return 0;
 }
@@ -1628,9 +1770,35 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
     HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
 }
 
+static bool wgrad_halo_ok(const ConvK& k) {
+  return !g_tuning[HDU_TUNE_NO_HALO] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 && k.KH == 3 && k.KW == 3 &&
+         k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 && (k.ud | k.uh | k.uw) == 0 &&
+         k.Di == 1 && k.Cin % 32 == 0 && k.We >= 32;
+}
+
+template <int BCO>
+static void launch_wgrad_halo(const ConvK& k, float* dw, hipStream_t s) {
+  const int tiles = k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32);
+  const unsigned gx = (unsigned)(k.Cin / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
+  const int target = g_tuning[HDU_TUNE_HALO_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_HALO_TARGET_WGS] : 512;
+  int want = target / (int)(gx * gy);
+  if (want < 1) want = 1;
+  if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;      // >= 2 tiles per workgroup
+  if (want < 1) want = 1;
+  const int per = (tiles + want - 1) / want;
+  const unsigned gz = (unsigned)((tiles + per - 1) / per);
+  HDU_LAUNCH((conv_wgrad_halo_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, per);
+}
+
 template <typename T>
 static void dispatch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
   const int best = choose_wgrad(k);
+  if (sizeof(T) == 2 && wgrad_halo_ok(k)) {
+    if (best == 64) launch_wgrad_halo<64>(k, dw, s);
+    else if (best == 48) launch_wgrad_halo<48>(k, dw, s);
+    else launch_wgrad_halo<32>(k, dw, s);
+    return;
+  }
   if (sizeof(T) == 2) {
     if (best == 64) launch_wgrad_tr<64>(k, dw, s);
     else if (best == 48) launch_wgrad_tr<48>(k, dw, s);
@@ -1694,7 +1862,8 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   const char* t = d->dtype == HDU_BF16 ? "bf16" : "f32";
   if (op == 1) {
     const bool dma = k.pro_a == nullptr && k.skip == nullptr;
-    snprintf(buf, buflen, d->dtype == HDU_BF16 ? (dma ? "conv_wgrad_dma_kernel<%d>" : "conv_wgrad_tr_kernel<%d>") : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
+    if (d->dtype == HDU_BF16 && wgrad_halo_ok(k)) snprintf(buf, buflen, "conv_wgrad_halo_kernel<%d>", choose_wgrad(k));
+    else snprintf(buf, buflen, d->dtype == HDU_BF16 ? (dma ? "conv_wgrad_dma_kernel<%d>" : "conv_wgrad_tr_kernel<%d>") : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
   } else {
     int bm, bn;
     choose_igemm(k, &bm, &bn);

@@ -43,10 +43,12 @@ const char* hdu_backend(void);
 int hdu_abi_version(void);
 /* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES = LDS ring depth of the DMA implicit GEMM (2 or 3) */
 #define HDU_TUNE_DMA_STAGES 0
-#define HDU_TUNE_MAX_BN 6            /* widest N tile the dispatcher may pick (default 192) */
+#define HDU_TUNE_HALO_TARGET_WGS 7    /* workgroups a halo-tile filter-gradient launch aims for */
+#define HDU_TUNE_MAX_BN 6            /* widest N tile the dispatcher may pick (default 128) */
 #define HDU_TUNE_NO_FAST 5           /* 1 = disable the bitmask/32-bit-offset addressing path (A/B) */
 #define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!) */
 #define HDU_TUNE_XCD_SWIZZLE 3       /* 1 = XCD-aware tile order in the implicit GEMM (default) */
+#define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
 int hdu_set_tuning(int key, int value);
