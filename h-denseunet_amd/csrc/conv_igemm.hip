@@ -1447,6 +1447,187 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __
 }
 
 // =====================================================================================
+// Halo-tile forward / data-gradient GEMM for 2D 3x3 stride-1 "same" convolutions (bf16, DMA operands).
+// Workgroup = 4 x 32 output pixels x BN output channels; K loop over 32-channel chunks.  Per chunk ONE DMA of the
+// (4+2) x (32+2) input halo tile (64 B per pixel) and of the filters of all 9 taps for these 32 channels; the 9 taps
+// are then formed from LDS (A fragments = shifted pixel windows of the halo tile).  L2->LDS traffic per MAC drops
+// ~2.3x against the im2col tiling.  Wave w owns tile row w (two 16-pixel m-tiles) and all BN/16 n-tiles.
+// LDS swizzle: the 16-byte chunk c of pixel/filter-row r is stored at chunk c ^ PI[(r >> 2) & 3], PI = {0,3,2,1}:
+// the two row sets of a ds_read_b128 lane group ({0-3,12-15} with chunk g, {4-11} with chunk g+1) then cover all
+// 16 bank slots.
+__device__ __forceinline__ int halo_swz(int r) { return (0x6C >> (((r >> 2) & 3) * 2)) & 3; }   // {0,3,2,1}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
+  typedef bf16_t T;
+  constexpr int TH = 4, TW = 32, HC = TW + 2, HP = (TH + 2) * HC, HPP = 208;
+  constexpr int XBYTES = HPP * 64;
+  constexpr int WROWB = 9 * 64;                          // filter row: 9 taps x 32 channels x 2 B
+  constexpr int WCH = BN * 36;                           // 16-byte chunks of the filter tile
+  constexpr int W_IT = (WCH + 255) / 256;
+  constexpr int WBYTES = ((WCH + 63) / 64) * 1024;       // whole wave instructions
+  constexpr int STAGE = XBYTES + WBYTES;
+  constexpr int TN = BN / 16;
+  constexpr int BM = TH * TW;
+  static_assert(2 * STAGE <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ wp = (const T*)p.w;
+  const char* zero = (const char*)hdu_zero_page;
+  const int H = p.He, W = p.We;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int t = blockIdx.x;
+  const int txi = t % tiles_x;
+  const int r_ = t / tiles_x;
+  const int tyi = r_ % tiles_y;
+  const int n = r_ / tiles_y;
+  const int y0 = tyi * TH, x0 = txi * TW;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- fixed DMA roles of this lane
+  // halo tile: instruction jj = j*4 + wave covers halo pixels jj*16 .. +15
+  const char* xsrc[4];
+  int xlc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jj = j * 4 + wave;
+    const int hp = jj * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ halo_swz(hp);
+    const int hr = hp / HC, hc = hp - hr * HC;
+    const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+    const bool ok = jj < HPP / 16 && hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    xsrc[j] = ok ? (const char*)(xp + ((long long)(n * H + iy) * W + ix) * p.ldx + lc * 8) : nullptr;
+    xlc[j] = lc * 8;
+  }
+  // filter tile: flat chunk q = (row, tap, chunk-in-tap): instruction covers 64 consecutive chunks
+  const char* wsrc[W_IT];
+  int wlc[W_IT];
+#pragma unroll
+  for (int j = 0; j < W_IT; ++j) {
+    const int q = (j * 4 + wave) * 64 + lane;
+    const int row = q / 36, rem = q - row * 36;
+    const int tap = rem >> 2;
+    const int lc = (rem & 3) ^ halo_swz(row);
+    const int co = n0 + row;
+    const bool ok = q < WCH && co < p.Cout;
+    wsrc[j] = ok ? (const char*)(wp + ((long long)co * 9 + tap) * p.Cin + lc * 8) : nullptr;
+    wlc[j] = lc * 8;
+  }
+
+  auto issue_chunk = [&](int buf, int c0) {
+    char* Xh = smem + buf * STAGE;
+    char* Ws = Xh + XBYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int jj = j * 4 + wave;
+      if (jj < HPP / 16) {
+        const char* g = (xsrc[j] != nullptr && c0 + xlc[j] < p.Cin) ? xsrc[j] + c0 * 2 : zero;
+        hdu_glds16(g, Xh + jj * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W_IT; ++j) {
+      const int jj = j * 4 + wave;
+      if (jj * 64 < WCH) {
+        const char* g = (wsrc[j] != nullptr && c0 + wlc[j] < p.Cin) ? wsrc[j] + c0 * 2 : zero;
+        hdu_glds16(g, Ws + jj * 1024);
+      }
+    }
+  };
+
+  f32x4 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (p.Cin + 31) / 32;
+  issue_chunk(0, 0);
+  __syncthreads();
+  const int li = lane & 15, lg = lane >> 4;
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nchunks) issue_chunk(buf ^ 1, (kc + 1) * 32);
+    {
+      const char* Xh = smem + buf * STAGE;
+      const char* Ws = Xh + XBYTES;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        u32x4 af[2], bf[TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hp = (wave + kh) * HC + i * 16 + li + kw;
+          af[i] = *(const u32x4*)(Xh + hp * 64 + ((lg ^ halo_swz(hp)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 16 + li;
+          bf[j] = *(const u32x4*)(Ws + row * WROWB + tap * 64 + ((lg ^ halo_swz(row)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias / dropout in registers, LDS-staged 16-byte row stores (tile pixel -> image pixel)
+  constexpr int ROWB = BN * 2 + 16;
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tx = i * 16 + lg * 4 + r;
+      const int row = wave * 32 + tx;
+      const long long m = ((long long)(n * H + y0 + wave)) * W + x0 + tx;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = j * 16 + li;
+        const int nn = n0 + col;
+        float v = acc[i][j][r];
+        if (p.bias && nn < p.Cout) v += p.bias[nn];
+        if (p.drop_scale != 0.f) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)nn, dseed);
+          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
+        }
+        Chunk<T>::store1((T*)(smem + row * ROWB) + col, v);
+      }
+    }
+  __syncthreads();
+  T* __restrict__ yp = (T*)p.y;
+  constexpr int NCC = BN / 8;
+  for (int q = tid; q < BM * NCC; q += 256) {
+    const int row = q / NCC, cc = q - row * NCC;
+    const int oy = y0 + (row >> 5), ox = x0 + (row & 31);
+    const int nn = n0 + cc * 8;
+    if (oy >= H || ox >= W || nn >= p.Cout) continue;
+    u32x4 v = *(const u32x4*)(smem + row * ROWB + cc * 16);
+    T* dst = yp + (((long long)(n * H + oy)) * W + ox) * p.ldy + nn;
+    if (p.accumulate) {
+      float f[8], g[8];
+      Chunk<T>::unpack(v, f);
+      Chunk<T>::unpack(*(const u32x4*)dst, g);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) f[jj] += g[jj];
+      v = Chunk<T>::pack(f);
+    }
+    *(u32x4*)dst = v;
+  }
+}
+
+// =====================================================================================
 // strided data gradient (only the stride-2 stems need it; tiny share of the FLOPs): direct gather form,
 // one thread per (input pixel, 16-byte channel chunk).  w is the forward filter [Cout][T][Cin] in dtype T.
 template <typename T>
@@ -1709,11 +1890,46 @@ static void dispatch_igemm(const ConvK& k, hipStream_t s) {
   else dispatch_igemm_bn<T, 128>(k, bn, s);
 }
 
+static bool fprop_halo_ok(const ConvK& k, int dtype) {
+  return dtype == HDU_BF16 && !g_tuning[HDU_TUNE_NO_HALO_FPROP] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 &&
+         k.KH == 3 && k.KW == 3 && k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 &&
+         (k.ud | k.uh | k.uw) == 0 && k.Di == 1 && k.Cin % 8 == 0 && k.We >= 32 && k.He >= 4 &&
+         // measured: pays when the K loop is long (>= 4 chunks of 32 channels) and one N tile covers Cout
+         k.Cin >= 128 && k.Cout <= 96;
+}
+
+static int choose_halo_bn(const ConvK& k) {
+  const int cands[4] = {96, 64, 48, 32};     // 128 would need 174 KB of LDS for the two stages
+  int best = 64;
+  long long best_cost = -1;
+  for (int i = 0; i < 4; ++i) {
+    const int c = cands[i];
+    const long long cost = (long long)((k.Cout + c - 1) / c) * (c + 24);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+template <int BN>
+static void launch_halo_fprop(const ConvK& k, hipStream_t s) {
+  const unsigned tiles = (unsigned)(k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32));
+  HDU_LAUNCH((conv_halo_fprop_kernel<BN>), dim3(tiles, (unsigned)((k.Cout + BN - 1) / BN)), dim3(256), 0, s, k);
+}
+
 extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
   ConvK k;
   if (int e = fill_convk(d, &k, false)) return e;
   if (!d->y) return hdu_set_error(HDU_ERR_ARG, "conv_fprop: null output");
   if (k.M == 0) return 0;
+  if (fprop_halo_ok(k, d->dtype)) {
+    switch (choose_halo_bn(k)) {
+      case 96: launch_halo_fprop<96>(k, (hipStream_t)stream); break;
+      case 64: launch_halo_fprop<64>(k, (hipStream_t)stream); break;
+      case 48: launch_halo_fprop<48>(k, (hipStream_t)stream); break;
+      default: launch_halo_fprop<32>(k, (hipStream_t)stream); break;
+    }
+    return hdu_check_launch("conv_fprop(halo)");
+  }
   if (d->dtype == HDU_BF16) dispatch_igemm<bf16_t>(k, (hipStream_t)stream);
   else dispatch_igemm<float>(k, (hipStream_t)stream);
   return hdu_check_launch("conv_fprop");
@@ -1864,6 +2080,8 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const bool dma = k.pro_a == nullptr && k.skip == nullptr;
     if (d->dtype == HDU_BF16 && wgrad_halo_ok(k)) snprintf(buf, buflen, "conv_wgrad_halo_kernel<%d>", choose_wgrad(k));
     else snprintf(buf, buflen, d->dtype == HDU_BF16 ? (dma ? "conv_wgrad_dma_kernel<%d>" : "conv_wgrad_tr_kernel<%d>") : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
+  } else if (fprop_halo_ok(k, d->dtype)) {
+    snprintf(buf, buflen, "conv_halo_fprop_kernel<%d>", choose_halo_bn(k));
   } else {
     int bm, bn;
     choose_igemm(k, &bm, &bn);

@@ -48,6 +48,7 @@ int hdu_abi_version(void);
 #define HDU_TUNE_NO_FAST 5           /* 1 = disable the bitmask/32-bit-offset addressing path (A/B) */
 #define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!) */
 #define HDU_TUNE_XCD_SWIZZLE 3       /* 1 = XCD-aware tile order in the implicit GEMM (default) */
+#define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
 #define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
