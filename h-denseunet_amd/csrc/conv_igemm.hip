@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   }
 
   // ---- epilogue: bias, dropout, optional accumulate, store ----
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // =====================================================================================
@@ -687,11 +687,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
 
 // ---- epilogue shared by the DMA kernels: bias / dropout in registers, then the tile goes through LDS so that every
 // lane writes (and, in accumulate mode, reads) one full 16-byte chunk of a row: 8 lanes cover a 128-byte line.
-template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int SMEM>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][TN], char* smem, long long m0, int n0,
                                                int wm, int wn, int lane, int tid) {
   constexpr int CH = Chunk<T>::CH;
-  constexpr int ROWB = BN * (int)sizeof(T) + 16;     // +16 B: consecutive rows start on different banks
+  // +16 B: consecutive rows start on different banks; dropped when the padded tile would not fit the operand stages
+  // (f32 128x128: 128 * 528 B > 64 KB)
+  constexpr int ROWB = BN * (int)sizeof(T) + (BM * (BN * (int)sizeof(T) + 16) <= SMEM ? 16 : 0);
+  static_assert(BM * ROWB <= SMEM, "epilogue staging tile must fit the LDS of the operand stages");
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
   __syncthreads();                                   // all MFMA operand reads of the last K tile are done
 #pragma unroll
@@ -911,7 +914,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     __syncthreads();
   }
 
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // NS-stage ring variant: tiles t+1 .. t+NS-1 stay in flight while tile t is multiplied.  Per iteration: counted
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NS * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
@@ -1850,11 +1853,11 @@ static void launch_igemm(const ConvK& k, hipStream_t s) {
 // writes full output rows, so wide tiles are preferred: cost model = n_tiles * (BN + 32) (MFMA columns + the A-load
 // expressed in column equivalents); 64-row tiles below 16 K pixels.
 static void choose_igemm(const ConvK& k, int* bm, int* bn) {
-  const int cands[6] = {192, 128, 96, 64, 48, 32};
+  const int cands[5] = {128, 96, 64, 48, 32};     // 192 measured slower (and its f32 tile cannot be staged)
   int best = 64;
   long long best_cost = -1;
-  const int maxbn = g_tuning[HDU_TUNE_MAX_BN] > 0 ? g_tuning[HDU_TUNE_MAX_BN] : 128;   // 192 measured slower
-  for (int i = 0; i < 6; ++i) {
+  const int maxbn = g_tuning[HDU_TUNE_MAX_BN] > 0 ? g_tuning[HDU_TUNE_MAX_BN] : 128;
+  for (int i = 0; i < 5; ++i) {
     const int c = cands[i];
     if (c > maxbn) continue;
     const long long ntiles = (k.Cout + c - 1) / c;
@@ -1873,7 +1876,6 @@ template <int BM, int BN> struct WaveLayout {           // (waves along M, waves
 template <typename T, int BM>
 static void dispatch_igemm_bn(const ConvK& k, int bn, hipStream_t s) {
   switch (bn) {
-    case 192: launch_igemm<T, BM, 192, WaveLayout<BM, 192>::WM, WaveLayout<BM, 192>::WN>(k, s); return;
     case 128: launch_igemm<T, BM, 128, WaveLayout<BM, 128>::WM, WaveLayout<BM, 128>::WN>(k, s); return;
     case 96: launch_igemm<T, BM, 96, WaveLayout<BM, 96>::WM, WaveLayout<BM, 96>::WN>(k, s); return;
     case 64: launch_igemm<T, BM, 64, WaveLayout<BM, 64>::WM, WaveLayout<BM, 64>::WN>(k, s); return;

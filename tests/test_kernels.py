@@ -94,6 +94,7 @@ CONV_CASES = [
     dict(N=1, D=8, H=10, W=10, Cin=8, Cout=96, K=(7, 7, 7), s=(2, 2, 2), p=(3, 3, 3), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="stem7x7x7s2"),
     dict(N=1, D=1, H=40, W=36, Cin=64, Cout=8, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=True, bias=True, ldin=None, ldout=None, id="classifier_pad8"),
     dict(N=1, D=1, H=70, W=66, Cin=32, Cout=264, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="wide_bn128"),
+    dict(N=1, D=1, H=130, W=128, Cin=8, Cout=128, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="tile128x128_ragged_m"),
     dict(N=2, D=1, H=10, W=37, Cin=64, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=96, ldout=64, id="halo_tile_ragged_slab"),
     dict(N=1, D=1, H=8, W=64, Cin=32, Cout=64, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="halo_tile_exact"),
 ]
