@@ -131,6 +131,24 @@ def cpu_baseline(config, size, cols):
                                                         "one %dx%dx%d volume" % (size, size, cols), t2 - t1)}
 
 
+def pmc_traffic(kernel, config, dtype):
+    """HBM bytes per launch of `kernel` from the committed PMC summaries (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes over this same bench command, profiles/): FETCH_SIZE [KB] x2 (gfx950 counts a 128-B request as 64 B,
+    MI355X_MICROARCH.md "HBM") + WRITE_SIZE [KB].  None when no summary of this config / kernel is committed."""
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_%s_%s_%s.txt" % (ctr, config, dtype))
+        if not os.path.exists(path):
+            return None
+        lines = open(path).read().split("\n")
+        for i, ln in enumerate(lines):
+            if ln.startswith("void " + kernel + "(") and i + 1 < len(lines) and ctr in lines[i + 1]:
+                vals[ctr] = float(lines[i + 1].split()[-1])
+    if len(vals) != 2:
+        return None
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,7 +247,9 @@ def main():
             ach = fl / (tms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[a.dtype]
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "launches_per_step": n,
+                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, a.config, a.dtype),
+                               "traffic_unit": "HBM bytes per launch, PMC (profiles/r01_pmc_*), avg over the layer shapes",
+                               "kernel": name, "launches_per_step": n,
                                "avg_launch_ms": round(tms / n, 4),
                                "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1], 3),
                                                         "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   const int wn = wave % WAVES_N;
   const int kc = tid & 7;
   const int r0 = tid >> 3;
-  const long long m0 = (long long)(p.xcd_swizzle ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
+  const long long m0 = (long long)((p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ sp = (const T*)p.skip;
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   const int wn = wave % WAVES_N;
   const int r0 = tid >> 3;
   const int kcl = (tid & 7) ^ (r0 & 7);   // logical chunk this lane fetches (it lands at physical chunk tid&7)
-  const long long m0 = (long long)(p.xcd_swizzle ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
+  const long long m0 = (long long)((p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ wp = (const T*)p.w;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   const int wn = wave % WAVES_N;
   const int r0 = tid >> 3;
   const int kcl = (tid & 7) ^ (r0 & 7);
-  const long long m0 = (long long)(p.xcd_swizzle ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
+  const long long m0 = (long long)((p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ wp = (const T*)p.w;
@@ -1166,9 +1166,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
   const char* zero = (const char*)hdu_zero_page;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
-  const int kcol0 = blockIdx.x * BKC;
-  const int co0 = blockIdx.y * BCO;
-  const long long m_begin = (long long)blockIdx.z * rows_per_split;
+  unsigned wbx, wby, wbz;
+  if (!wgrad_block(p, &wbx, &wby, &wbz)) return;
+  const int kcol0 = (int)wbx * BKC;
+  const int co0 = (int)wby * BCO;
+  const long long m_begin = (long long)wbz * rows_per_split;
   long long m_end = m_begin + rows_per_split;
   if (m_end > p.M) m_end = p.M;
 
@@ -1338,12 +1340,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ dyp = (const T*)p.y;
   const char* zero = (const char*)hdu_zero_page;
-  const int c0 = blockIdx.x * 32;
-  const int co0 = blockIdx.y * BCO;
+  unsigned wbx, wby, wbz;
+  if (!wgrad_block(p, &wbx, &wby, &wbz)) return;
+  const int c0 = (int)wbx * 32;
+  const int co0 = (int)wby * BCO;
   const int H = p.He, W = p.We;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles = p.N * tiles_y * tiles_x;
-  const int t_begin = blockIdx.z * tiles_per_split;
+  const int t_begin = (int)wbz * tiles_per_split;
   int t_end = t_begin + tiles_per_split;
   if (t_end > ntiles) t_end = ntiles;
 
@@ -1963,8 +1967,12 @@ static int choose_wgrad(const ConvK& k) {
   return best;
 }
 
-template <int BCO>
-static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s);
+// 1-D grid of the XCD-grouped filter-gradient kernels (wgrad_block in conv_common.h)
+static unsigned wgrad_grid(const ConvK& k) {
+  const unsigned per = (unsigned)(k.wg_gx * k.wg_gy);
+  return (k.xcd_swizzle & 2) ? 8u * (unsigned)((k.wg_gz + 7) / 8) * per : (unsigned)k.wg_gz * per;
+}
+
 
 template <int BCO>
 static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
@@ -1979,12 +1987,15 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
   const int min_steps = g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] : 4;
   if (want > (steps + min_steps - 1) / min_steps) want = (steps + min_steps - 1) / min_steps;
   if (want < 1) want = 1;
+  if ((k.xcd_swizzle & 2) && want >= 6) want = (want + 4) / 8 * 8;        // whole pixel splits per XCD: balance the 8 XCDs
   long long steps_per = (steps + want - 1) / want;
   const long long rows_per = steps_per * PX;
   const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);
-  if (k.pro_a == nullptr && k.skip == nullptr)
-    HDU_LAUNCH((conv_wgrad_dma_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
-  else
+  if (k.pro_a == nullptr && k.skip == nullptr) {
+    ConvK kk = k;
+    kk.wg_gx = (int)gx; kk.wg_gy = (int)gy; kk.wg_gz = (int)gz;
+    HDU_LAUNCH((conv_wgrad_dma_kernel<BCO>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
+  } else
     HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
 }
 
@@ -2003,9 +2014,12 @@ static void launch_wgrad_halo(const ConvK& k, float* dw, hipStream_t s) {
   if (want < 1) want = 1;
   if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;      // >= 2 tiles per workgroup
   if (want < 1) want = 1;
+  if ((k.xcd_swizzle & 2) && want >= 6) want = (want + 4) / 8 * 8;
   const int per = (tiles + want - 1) / want;
   const unsigned gz = (unsigned)((tiles + per - 1) / per);
-  HDU_LAUNCH((conv_wgrad_halo_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, per);
+  ConvK kk = k;
+  kk.wg_gx = (int)gx; kk.wg_gy = (int)gy; kk.wg_gz = (int)gz;
+  HDU_LAUNCH((conv_wgrad_halo_kernel<BCO>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, per);
 }
 
 template <typename T>
