@@ -12,3 +12,5 @@ static inline unsigned hdu_grid_1d(long long work_items, int per_block, unsigned
   if (b > (long long)cap) b = cap;
   return (unsigned)b;
 }
+
+extern int g_tuning[16];   // hdu_set_tuning values (conv_igemm.hip)

@@ -175,6 +175,40 @@ __device__ __forceinline__ void hdu_glds16(const void* gsrc, char* lds_wave_base
 #define HDU_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
 
+// keeps the instruction scheduler from sinking a group of hoisted loads back towards their uses
+#ifdef HDU_EMU
+#define HDU_SCHED_BARRIER() do { } while (0)
+#else
+#define HDU_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// "last workgroup finishes the job" hand-off without cache flushes.  An agent-scope release fence (buffer_wbl2) writes
+// back EVERY dirty line of the XCD's L2 -- measured +17 us per launch here, the L2 is full of the previous kernel's
+// output.  Instead the partial results themselves are agent-scope relaxed atomic stores / loads (sc1: written through
+// to / read from the device coherence point, no fence needed for coherence of the location); ordering comes from
+// s_waitcnt vmcnt(0) (the stores have been acknowledged) + the workgroup barrier before ONE lane takes the ticket.
+#ifdef HDU_EMU
+__device__ __forceinline__ unsigned hdu_ticket(unsigned* counter) { return atomicAdd(counter, 1u); }
+__device__ __forceinline__ void hdu_store_agent(float* p, float v) { *p = v; }
+__device__ __forceinline__ float hdu_load_agent(const float* p) { return *p; }
+__device__ __forceinline__ void hdu_store_agent_u32(unsigned* p, unsigned v) { *p = v; }
+#define HDU_WAIT_STORES() do { } while (0)
+#else
+__device__ __forceinline__ unsigned hdu_ticket(unsigned* counter) {
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hdu_store_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float hdu_load_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hdu_store_agent_u32(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define HDU_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // counter-based hash RNG for dropout masks (stateless; fwd and bwd regenerate the same mask)
 __host__ __device__ __forceinline__ unsigned hdu_hash32(unsigned long long idx, unsigned seed) {
   unsigned h = (unsigned)idx * 0x9E3779B1u;

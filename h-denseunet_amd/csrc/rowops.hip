@@ -7,86 +7,7 @@
 
 // ====================================================================== per-channel reductions
 enum { RED_STATS = 0, RED_BNBWD = 1, RED_COLSUM = 2 };
-
-struct RedK {
-  const void* x;
-  const void* dz;
-  long long ldx, lddz, M, rows_per_block;
-  int C;
-  int relu;
-  const float* a;
-  const float* b;
-  const float* mean;
-  const float* rstd;
-  float* partial;  // [gridDim.x][2][C]
-};
-
-template <typename T, int MODE, int COLS>
-__global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
-  constexpr int CH = Chunk<T>::CH;
-  constexpr int ROWS = 256 / COLS;
-  __shared__ float red[2][ROWS][COLS * CH];
-  const int tid = threadIdx.x;
-  const int cc = tid % COLS;
-  const int rl = tid / COLS;
-  const int c0 = (blockIdx.y * COLS + cc) * CH;
-  const bool active = c0 < p.C;
-  const T* __restrict__ xp = (const T*)p.x;
-  const T* __restrict__ dzp = (const T*)p.dz;
-
-  float s1[CH], s2[CH], k0[CH], k1[CH], k2[CH], k3[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; k0[j] = 0.f; k1[j] = 0.f; k2[j] = 0.f; k3[j] = 0.f; }
-  if (active) {
-    if (MODE == RED_STATS) {
-      // shifted sums: the shift (row 0 of the tensor) removes the cancellation of E[x^2]-E[x]^2
-      Chunk<T>::unpack(*(const u32x4*)(xp + c0), k0);
-    } else if (MODE == RED_BNBWD) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        k0[j] = p.a[c0 + j]; k1[j] = p.b[c0 + j]; k2[j] = p.mean[c0 + j]; k3[j] = p.rstd[c0 + j];
-      }
-    }
-    const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
-    long long r_end = r_begin + p.rows_per_block;
-    if (r_end > p.M) r_end = p.M;
-    for (long long r = r_begin + rl; r < r_end; r += ROWS) {
-      float f[CH];
-      Chunk<T>::unpack(*(const u32x4*)(xp + r * p.ldx + c0), f);
-      if (MODE == RED_STATS) {
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { const float d = f[j] - k0[j]; s1[j] += d; s2[j] += d * d; }
-      } else if (MODE == RED_BNBWD) {
-        float g[CH];
-        Chunk<T>::unpack(*(const u32x4*)(dzp + r * p.lddz + c0), g);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const float s = k0[j] * f[j] + k1[j];
-          const float gg = (!p.relu || s > 0.f) ? g[j] : 0.f;
-          s1[j] += gg;
-          s2[j] += gg * ((f[j] - k2[j]) * k3[j]);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < CH; ++j) s1[j] += f[j];
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < CH; ++j) { red[0][rl][cc * CH + j] = s1[j]; red[1][rl][cc * CH + j] = s2[j]; }
-  __syncthreads();
-  for (int q = tid; q < 2 * COLS * CH; q += 256) {
-    const int s = q / (COLS * CH);
-    const int col = q % (COLS * CH);
-    const int c = blockIdx.y * COLS * CH + col;
-    if (c < p.C) {
-      float t = 0.f;
-#pragma unroll 4
-      for (int r = 0; r < ROWS; ++r) t += red[s][r][col];
-      p.partial[((long long)blockIdx.x * 2 + s) * p.C + c] = t;
-    }
-  }
-}
+enum { ROW_UNROLL = 4 };   // rows of loads each thread of a row kernel keeps in flight
 
 // optional per-channel epilogue of the finalize kernel (saves the separate bn_fold / bn_bwd_coef launches)
 struct FinK {
@@ -135,6 +56,167 @@ __device__ __forceinline__ void bn_coef_channel(int c, float invM, int batch_sta
   if (dsbeta) dsbeta[c] = S1;
 }
 
+// one channel's totals -> outputs (+ the optional BN fold / BN-backward-coefficient epilogue)
+template <typename T, int MODE>
+__device__ __forceinline__ void finalize_channel(int c, double a1, double a2, long long M, const void* x, float* o1,
+                                                 float* o2, const FinK& fin) {
+  if (MODE == 0) {   // RED_STATS
+    const double shift = (double)Chunk<T>::load1((const T*)x + c);
+    const double m1 = a1 / (double)M;
+    double var = a2 / (double)M - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    o1[c] = (float)(shift + m1);
+    o2[c] = (float)var;
+    if (fin.kind == 1)
+      bn_fold_channel(c, (float)(shift + m1), (float)var, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a,
+                      fin.b, fin.rstd, fin.mov_mean, fin.mov_var, fin.momentum);
+  } else {
+    o1[c] = (float)a1;
+    if (o2) o2[c] = (float)a2;
+    if (MODE == 1 && fin.kind == 2)   // RED_BNBWD
+      bn_coef_channel(c, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma, fin.beta, fin.sgamma, fin.rstd_in,
+                      fin.k1, fin.k2, fin.k3, fin.dgamma, fin.dbeta, fin.dsgamma, fin.dsbeta);
+  }
+}
+
+struct RedK {
+  const void* x;
+  const void* dz;
+  long long ldx, lddz, M, rows_per_block;
+  int C;
+  int relu;
+  const float* a;
+  const float* b;
+  const float* mean;
+  const float* rstd;
+  float* partial;  // [gridDim.x][2][C]
+  // fused finalize (small tensors): the workgroup that draws the last ticket of its column group sums the partials
+  unsigned* counter;   // [gridDim.y] tickets, zero between launches (reset by the last workgroup); NULL = two kernels
+  float* o1;
+  float* o2;
+  FinK fin;
+};
+
+template <typename T, int MODE, int COLS>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[2][ROWS][COLS * CH];
+  const int tid = threadIdx.x;
+  const int cc = tid % COLS;
+  const int rl = tid / COLS;
+  const int c0 = (blockIdx.y * COLS + cc) * CH;
+  const bool active = c0 < p.C;
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ dzp = (const T*)p.dz;
+
+  float s1[CH], s2[CH], k0[CH], k1[CH], k2[CH], k3[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; k0[j] = 0.f; k1[j] = 0.f; k2[j] = 0.f; k3[j] = 0.f; }
+  if (active) {
+    if (MODE == RED_STATS) {
+      // shifted sums: the shift (row 0 of the tensor) removes the cancellation of E[x^2]-E[x]^2
+      Chunk<T>::unpack(*(const u32x4*)(xp + c0), k0);
+    } else if (MODE == RED_BNBWD) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        k0[j] = p.a[c0 + j]; k1[j] = p.b[c0 + j]; k2[j] = p.mean[c0 + j]; k3[j] = p.rstd[c0 + j];
+      }
+    }
+    const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+    long long r_end = r_begin + p.rows_per_block;
+    if (r_end > p.M) r_end = p.M;
+    // one row's contribution; the loop below keeps ROW_UNROLL rows of loads in flight per thread (a one-row loop
+    // serialises on the full memory latency twice per row: measured as the limiter of every row kernel)
+    auto body = [&](const u32x4& xv, const u32x4& gv) {
+      float f[CH];
+      Chunk<T>::unpack(xv, f);
+      if (MODE == RED_STATS) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float d = f[j] - k0[j]; s1[j] += d; s2[j] += d * d; }
+      } else if (MODE == RED_BNBWD) {
+        float g[CH];
+        Chunk<T>::unpack(gv, g);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float s = k0[j] * f[j] + k1[j];
+          const float gg = (!p.relu || s > 0.f) ? g[j] : 0.f;
+          s1[j] += gg;
+          s2[j] += gg * ((f[j] - k2[j]) * k3[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) s1[j] += f[j];
+      }
+    };
+    long long r = r_begin + rl;
+    for (; r + (ROW_UNROLL - 1) * ROWS < r_end; r += ROW_UNROLL * ROWS) {
+      u32x4 xv[ROW_UNROLL], gv[ROW_UNROLL];
+#pragma unroll
+      for (int u = 0; u < ROW_UNROLL; ++u) xv[u] = *(const u32x4*)(xp + (r + u * ROWS) * p.ldx + c0);
+      if (MODE == RED_BNBWD) {
+#pragma unroll
+        for (int u = 0; u < ROW_UNROLL; ++u) gv[u] = *(const u32x4*)(dzp + (r + u * ROWS) * p.lddz + c0);
+      }
+      HDU_SCHED_BARRIER();
+#pragma unroll
+      for (int u = 0; u < ROW_UNROLL; ++u) body(xv[u], gv[u]);
+    }
+    for (; r < r_end; r += ROWS) {
+      u32x4 gv = u32x4{0u, 0u, 0u, 0u};
+      if (MODE == RED_BNBWD) gv = *(const u32x4*)(dzp + r * p.lddz + c0);
+      body(*(const u32x4*)(xp + r * p.ldx + c0), gv);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { red[0][rl][cc * CH + j] = s1[j]; red[1][rl][cc * CH + j] = s2[j]; }
+  __syncthreads();
+  for (int q = tid; q < 2 * COLS * CH; q += 256) {
+    const int s = q / (COLS * CH);
+    const int col = q % (COLS * CH);
+    const int c = blockIdx.y * COLS * CH + col;
+    if (c < p.C) {
+      float t = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < ROWS; ++r) t += red[s][r][col];
+      float* dst = p.partial + ((long long)blockIdx.x * 2 + s) * p.C + c;
+      if (p.counter == nullptr) *dst = t; else hdu_store_agent(dst, t);
+    }
+  }
+  if (p.counter == nullptr) return;
+  // ---- fused finalize: last workgroup of this column group
+  __shared__ int s_last;
+  __shared__ double fred[2][256];
+  HDU_WAIT_STORES();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = hdu_ticket(p.counter + blockIdx.y);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  constexpr int NCL = COLS * CH > 256 ? 256 : COLS * CH;      // channels of the group (<= 256)
+  constexpr int PL = 256 / NCL;                               // partial lanes per channel
+  const int cl = tid % NCL, pl = tid / NCL;
+  const int c = blockIdx.y * COLS * CH + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < p.C) {
+    for (int b = pl; b < (int)gridDim.x; b += PL) {
+      a1 += (double)hdu_load_agent(p.partial + ((long long)b * 2 + 0) * p.C + c);
+      if (MODE != RED_COLSUM) a2 += (double)hdu_load_agent(p.partial + ((long long)b * 2 + 1) * p.C + c);
+    }
+  }
+  fred[0][tid] = a1;
+  fred[1][tid] = a2;
+  __syncthreads();
+  if (pl == 0 && c < p.C) {
+#pragma unroll
+    for (int q = 1; q < PL; ++q) { a1 += fred[0][q * NCL + cl]; a2 += fred[1][q * NCL + cl]; }
+    finalize_channel<T, MODE>(c, a1, a2, p.M, p.x, p.o1, p.o2, p.fin);
+  }
+  if (tid == 0) hdu_store_agent_u32(p.counter + blockIdx.y, 0u);   // ready for the next launch that uses this slot
+}
+
 // sums the per-block partials (double accumulation) and post-processes per mode.
 // 256 threads = 8 channels x 32 partial lanes: lane p strides over the row blocks, then an LDS tree over the lanes.
 template <typename T, int MODE>
@@ -164,23 +246,7 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   if (pl == 0 && c < C) {
     a1 = red[0][0][cl];
     a2 = red[1][0][cl];
-    if (MODE == RED_STATS) {
-      const double shift = (double)Chunk<T>::load1((const T*)x + c);
-      const double m1 = a1 / (double)M;
-      double var = a2 / (double)M - m1 * m1;
-      if (var < 0.0) var = 0.0;
-      o1[c] = (float)(shift + m1);
-      o2[c] = (float)var;
-      if (fin.kind == 1)
-        bn_fold_channel(c, (float)(shift + m1), (float)var, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a,
-                        fin.b, fin.rstd, fin.mov_mean, fin.mov_var, fin.momentum);
-    } else {
-      o1[c] = (float)a1;
-      if (o2) o2[c] = (float)a2;
-      if (MODE == RED_BNBWD && fin.kind == 2)
-        bn_coef_channel(c, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma, fin.beta, fin.sgamma, fin.rstd_in,
-                        fin.k1, fin.k2, fin.k3, fin.dgamma, fin.dbeta, fin.dsgamma, fin.dsbeta);
-    }
+    finalize_channel<T, MODE>(c, a1, a2, M, x, o1, o2, fin);
   }
 }
 
@@ -188,6 +254,17 @@ static int red_cols_for(int nchunks) {
   int cols = 4;
   while (cols < nchunks && cols < 32) cols <<= 1;
   return cols;
+}
+// Optional single-launch reduction for small tensors (<= 8192 pixels): at most 64 row blocks per column group, summed
+// by the group's last workgroup (ticket counter, agent-scope partials).  Measured SLOWER than the separate
+// 8-channel x 32-lane finalize kernel on the 2D bench (250 vs 284 slices/s): the last workgroup reads 64 x 2 x 256
+// partials through one CU with device-scope loads, which costs more than the launch it saves.  OFF by default
+// (HDU_TUNE_FUSED_FINALIZE); kept because the emulator/GPU tests cover it and a tree version may pay later.
+enum { RED_FUSED_MAX_GX = 64, RED_COUNTER_SLOTS = 64, RED_COUNTER_GY = 64 };
+__device__ unsigned hdu_red_counters[RED_COUNTER_SLOTS * RED_COUNTER_GY];
+static unsigned g_red_slot = 0;
+static bool red_fused(long long M, unsigned gy) {
+  return g_tuning[HDU_TUNE_FUSED_FINALIZE] && M <= 8192 && gy <= RED_COUNTER_GY;
 }
 static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx, unsigned* gy, long long* rpb) {
   const int ch = dtype == HDU_BF16 ? 8 : 4;
@@ -200,6 +277,7 @@ static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);  // >= 4 rows per thread
   if (maxb < 1) maxb = 1;
   if (want > maxb) want = maxb;
+  if (red_fused(M, *gy) && want > RED_FUSED_MAX_GX) want = RED_FUSED_MAX_GX;
   *rpb = (M + want - 1) / want;
   if (*rpb < 1) *rpb = 1;
   *gx = (unsigned)((M + *rpb - 1) / *rpb);
@@ -243,6 +321,20 @@ static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_
     return hdu_set_error(HDU_ERR_WORKSPACE, "reduce: workspace too small (see hdu_reduce_ws_bytes)");
   k.rows_per_block = rpb;
   k.partial = (float*)ws;
+  if (red_fused(k.M, gy)) {
+#ifdef HDU_EMU
+    unsigned* base = hdu_red_counters;
+#else
+    static unsigned* base = nullptr;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(hdu_red_counters)) != hipSuccess)
+      return hdu_set_error(HDU_ERR_LAUNCH, "reduce: counter symbol");
+#endif
+    k.counter = base + (size_t)(g_red_slot++ % RED_COUNTER_SLOTS) * RED_COUNTER_GY;
+    k.o1 = o1; k.o2 = o2; k.fin = fin;
+    if (dtype == HDU_BF16) run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
+    else run_reduce<float, MODE>(k, cols, gx, gy, s);
+    return hdu_check_launch(what);
+  }
   const unsigned fb = (unsigned)((k.C + 7) / 8);
   if (dtype == HDU_BF16) {
     run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
@@ -391,9 +483,9 @@ __global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
   long long r_end = r_begin + p.rows_per_block;
   if (r_end > p.M) r_end = p.M;
-  for (long long m = r_begin + rl; m < r_end; m += ROWS) {
+  auto body = [&](long long m, const u32x4& xv) {
     float f[CH];
-    Chunk<T>::unpack(*(const u32x4*)(xp + m * p.ldx + c0), f);
+    Chunk<T>::unpack(xv, f);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float s = a[j] * f[j] + b[j];
@@ -401,7 +493,17 @@ __global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
       f[j] = s;
     }
     *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(f);
+  };
+  long long m = r_begin + rl;
+  for (; m + (ROW_UNROLL - 1) * ROWS < r_end; m += ROW_UNROLL * ROWS) {
+    u32x4 xv[ROW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) xv[u] = *(const u32x4*)(xp + (m + u * ROWS) * p.ldx + c0);
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) body(m + u * ROWS, xv[u]);
   }
+  for (; m < r_end; m += ROWS) body(m, *(const u32x4*)(xp + m * p.ldx + c0));
 }
 
 template <typename T, int COLS>
@@ -426,10 +528,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
   long long r_end = r_begin + p.rows_per_block;
   if (r_end > p.M) r_end = p.M;
-  for (long long m = r_begin + rl; m < r_end; m += ROWS) {
+  auto body = [&](long long m, const u32x4& xv, const u32x4& gv, const u32x4& ov) {
     float f[CH], g[CH], o[CH];
-    Chunk<T>::unpack(*(const u32x4*)(xp + m * p.ldx + c0), f);
-    Chunk<T>::unpack(*(const u32x4*)(dzp + m * p.lddz + c0), g);
+    Chunk<T>::unpack(xv, f);
+    Chunk<T>::unpack(gv, g);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       const float s = a[j] * f[j] + b[j];
@@ -441,15 +543,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
       }
       o[j] = d;
     }
-    T* dst = op + m * p.ldo + c0;
     if (p.accumulate) {
       float old[CH];
-      Chunk<T>::unpack(*(const u32x4*)dst, old);
+      Chunk<T>::unpack(ov, old);
 #pragma unroll
       for (int j = 0; j < CH; ++j) o[j] += old[j];
     }
-    *(u32x4*)dst = Chunk<T>::pack(o);
+    *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(o);
+  };
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  long long m = r_begin + rl;
+  for (; m + (ROW_UNROLL - 1) * ROWS < r_end; m += ROW_UNROLL * ROWS) {
+    u32x4 xv[ROW_UNROLL], gv[ROW_UNROLL], ov[ROW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) xv[u] = *(const u32x4*)(xp + (m + u * ROWS) * p.ldx + c0);
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) gv[u] = *(const u32x4*)(dzp + (m + u * ROWS) * p.lddz + c0);
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) ov[u] = p.accumulate ? *(const u32x4*)(op + (m + u * ROWS) * p.ldo + c0) : z4;
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) body(m + u * ROWS, xv[u], gv[u], ov[u]);
   }
+  for (; m < r_end; m += ROWS)
+    body(m, *(const u32x4*)(xp + m * p.ldx + c0), *(const u32x4*)(dzp + m * p.lddz + c0),
+         p.accumulate ? *(const u32x4*)(op + m * p.ldo + c0) : z4);
 }
 
 // geometry shared by the row kernels: column groups of COLS chunks, row blocks sized to ~2048 workgroups
@@ -517,23 +635,11 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
     d = (int)(t % De);
     n = (int)(t / De);
   }
-  for (; m < r_end; m += ROWS) {
-    const long long src = ups ? ((((long long)n * p.D + (d >> p.ud)) * p.H + (h >> p.uh)) * p.W + (w >> p.uw)) : m;
-    float f[CH];
-    Chunk<T>::unpack(*(const u32x4*)(xp + src * p.ldx + c0), f);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      float s = a[j] * f[j] + b[j];
-      if (p.relu) s = s > 0.f ? s : 0.f;
-      f[j] = s;
-    }
-    if (sp) {
-      float g[CH];
-      Chunk<T>::unpack(*(const u32x4*)(sp + m * p.ldskip + c0), g);
-#pragma unroll
-      for (int j = 0; j < CH; ++j) f[j] += g[j];
-    }
-    *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(f);
+  auto src_of = [&]() -> long long {
+    return ups ? ((((long long)n * p.D + (d >> p.ud)) * p.H + (h >> p.uh)) * p.W + (w >> p.uw)) : m;
+  };
+  auto advance = [&]() {
+    m += ROWS;
     if (ups) {
       w += ROWS;
       while (w >= We) {
@@ -547,6 +653,46 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
         }
       }
     }
+  };
+  auto body = [&](long long mo, const u32x4& xv, const u32x4& sv) {
+    float f[CH];
+    Chunk<T>::unpack(xv, f);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float s = a[j] * f[j] + b[j];
+      if (p.relu) s = s > 0.f ? s : 0.f;
+      f[j] = s;
+    }
+    if (sp) {
+      float g[CH];
+      Chunk<T>::unpack(sv, g);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) f[j] += g[j];
+    }
+    *(u32x4*)(op + mo * p.ldo + c0) = Chunk<T>::pack(f);
+  };
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  while (m + (ROW_UNROLL - 1) * ROWS < r_end) {
+    u32x4 xv[ROW_UNROLL], sv[ROW_UNROLL];
+    long long mo[ROW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      mo[u] = m;
+      xv[u] = *(const u32x4*)(xp + src_of() * p.ldx + c0);
+      advance();
+    }
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) sv[u] = sp ? *(const u32x4*)(sp + mo[u] * p.ldskip + c0) : z4;
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) body(mo[u], xv[u], sv[u]);
+  }
+  while (m < r_end) {
+    const long long mo = m;
+    const u32x4 xv = *(const u32x4*)(xp + src_of() * p.ldx + c0);
+    const u32x4 sv = sp ? *(const u32x4*)(sp + mo * p.ldskip + c0) : z4;
+    body(mo, xv, sv);
+    advance();
   }
 }
 

@@ -132,6 +132,8 @@ def load(path=None):
     _backend = _lib.hdu_backend().decode()
     if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
         _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_FUSED_FINALIZE" in os.environ:
+        _lib.hdu_set_tuning(10, int(os.environ["HDU_FUSED_FINALIZE"]))
     if "HDU_NO_HALO_FPROP" in os.environ:
         _lib.hdu_set_tuning(9, int(os.environ["HDU_NO_HALO_FPROP"]))
     if "HDU_NO_HALO" in os.environ:

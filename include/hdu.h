@@ -47,7 +47,8 @@ int hdu_abi_version(void);
 #define HDU_TUNE_MAX_BN 6            /* widest N tile the dispatcher may pick (default 128) */
 #define HDU_TUNE_NO_FAST 5           /* 1 = disable the bitmask/32-bit-offset addressing path (A/B) */
 #define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!) */
-#define HDU_TUNE_XCD_SWIZZLE 3       /* 1 = XCD-aware tile order in the implicit GEMM (default) */
+#define HDU_TUNE_XCD_SWIZZLE 3       /* bit0 = XCD-aware tile order in the implicit GEMM (default on); bit1 = XCD-grouped filter-gradient grid (off: measured slower) */
+#define HDU_TUNE_FUSED_FINALIZE 10   /* 1 = small-tensor reductions finish in the last workgroup of the same launch (off: measured slower) */
 #define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
 #define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */

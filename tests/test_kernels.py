@@ -253,7 +253,8 @@ def test_dropout_epilogue_consistent(hdu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(2, 1, 13, 11, 48, 72, 8), (1, 3, 7, 7, 8, None, 0), (1, 1, 33, 37, 264, None, 0), (1, 1, 5, 5, 96, 128, 16)])
+@pytest.mark.parametrize("shape", [(2, 1, 13, 11, 48, 72, 8), (1, 3, 7, 7, 8, None, 0), (1, 1, 33, 37, 264, None, 0), (1, 1, 5, 5, 96, 128, 16),
+                                   (1, 1, 96, 97, 16, None, 0)])   # > 8192 pixels: separate finalize kernel
 def test_bn_stats_fold(hdu, dtype, shape):
     ops = ops_mod()
     N, D, H, W, C, ld, coff = shape
