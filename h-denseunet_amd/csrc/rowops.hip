@@ -228,7 +228,19 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
   const int c = blockIdx.x * 8 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int b = pl; b < nblk; b += 32) {
+    int b = pl;
+    for (; b + 7 * 32 < nblk; b += 8 * 32) {      // 16 loads in flight per lane (a one-partial loop pays the latency each time)
+      float v1[8], v2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v1[u] = partial[((long long)(b + u * 32) * 2 + 0) * C + c];
+        v2[u] = MODE != RED_COLSUM ? partial[((long long)(b + u * 32) * 2 + 1) * C + c] : 0.f;
+      }
+      HDU_SCHED_BARRIER();
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a1 += (double)v1[u]; a2 += (double)v2[u]; }
+    }
+    for (; b < nblk; b += 32) {
       a1 += (double)partial[((long long)b * 2 + 0) * C + c];
       if (MODE != RED_COLSUM) a2 += (double)partial[((long long)b * 2 + 1) * C + c];
     }
@@ -1111,13 +1123,24 @@ __global__ __launch_bounds__(256) void wce_kernel(const T* __restrict__ logits, 
   if (threadIdx.x < 4) partial[(long long)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ void wce_finalize_kernel(const float* __restrict__ partial, int nblk, float* loss_sum, float* class_count) {
-  const int q = threadIdx.x;
-  if (q >= 4) return;
+// 256 threads = 4 quantities (loss, 3 class counts) x 64 partial lanes, then an LDS tree (a single thread per quantity
+// walking 2048 partials cost 170 us per step)
+__global__ __launch_bounds__(256) void wce_finalize_kernel(const float* __restrict__ partial, int nblk, float* loss_sum,
+                                                            float* class_count) {
+  __shared__ double red[64][4];
+  const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
   double a = 0.0;
-  for (int b = 0; b < nblk; ++b) a += (double)partial[(long long)b * 4 + q];
-  if (q == 0) *loss_sum += (float)a;
-  else if (class_count) class_count[q - 1] += (float)a;
+  for (int b = pl; b < nblk; b += 64) a += (double)partial[(long long)b * 4 + q];
+  red[pl][q] = a;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (pl < s) red[pl][q] += red[pl + s][q];
+    __syncthreads();
+  }
+  if (pl == 0) {
+    if (q == 0) *loss_sum += (float)red[0][0];
+    else if (class_count) class_count[q - 1] += (float)red[0][q];
+  }
 }
 
 extern "C" int hdu_wce_loss(int dtype, const void* logits, int64_t ldl, const uint8_t* labels, int64_t M, float w0,
@@ -1135,7 +1158,7 @@ extern "C" int hdu_wce_loss(int dtype, const void* logits, int64_t ldl, const ui
                labels, (long long)M, w0, w1, w2, grad_scale, (float*)dlogits, (long long)lddl, C_pad, (float*)ws);
   else
     return hdu_set_error(HDU_ERR_ARG, "wce_loss: bad dtype");
-  HDU_LAUNCH(wce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, (int)g, loss_sum,
+  HDU_LAUNCH(wce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (int)g, loss_sum,
              class_count);
   return hdu_check_launch("wce_loss");
 }
