@@ -96,14 +96,15 @@ def instrumented_step(m):
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += fl
-        b = bym.setdefault(mm, [0, 0.0, 0.0])
+        b = bym.setdefault((mm, name), [0, 0.0, 0.0])
         b[0] += 1
         b[1] += e0.elapsed_time(e1)
         b[2] += fl
     if os.environ.get("HDU_BENCH_VERBOSE"):
         for mm in sorted(bym):
             b = bym[mm]
-            print("M=%8d launches=%4d ms=%7.3f TF=%6.1f" % (mm, b[0], b[1], b[2] / (b[1] * 1e-3) / 1e12), file=sys.stderr)
+            print("M=%8d %-44s launches=%4d ms=%7.3f us/launch=%7.1f TF=%6.1f" %
+                  (mm[0], mm[1], b[0], b[1], b[1] / b[0] * 1e3, b[2] / (b[1] * 1e-3) / 1e12), file=sys.stderr)
     return agg
 
 

@@ -53,12 +53,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   for (int i = 0; i < A_IT; ++i) {
     const long long m = m0 + r0 + i * 32;
     if (m < p.M) {
-      const int ow = (int)(m % p.Wo);
-      long long t = m / p.Wo;
-      const int oh = (int)(t % p.Ho);
-      t /= p.Ho;
-      const int od = (int)(t % p.Do);
-      rn[i] = (int)(t / p.Do);
+      const unsigned mu = (unsigned)m;                    // M < 2^31 (checked on the host): 32-bit divisions
+      const int ow = (int)(mu % (unsigned)p.Wo);
+      unsigned t = mu / (unsigned)p.Wo;
+      const int oh = (int)(t % (unsigned)p.Ho);
+      t /= (unsigned)p.Ho;
+      const int od = (int)(t % (unsigned)p.Do);
+      rn[i] = (int)(t / (unsigned)p.Do);
       rid[i] = od * p.sd - p.pd;
       rih[i] = oh * p.sh - p.ph;
       riw[i] = ow * p.sw - p.pw;
@@ -280,12 +281,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 #pragma unroll
   for (int i = 0; i < X_IT; ++i) {
     const long long m = m_begin + pxl + i * (256 / NCC);
-    const int ow = (int)(m % p.Wo);
-    long long t = m / p.Wo;
-    const int oh = (int)(t % p.Ho);
-    t /= p.Ho;
-    sod[i] = (int)(t % p.Do);
-    sn[i] = (int)(t / p.Do);
+    const unsigned mu = (unsigned)m;                      // M < 2^31 (checked on the host): 32-bit divisions
+    const int ow = (int)(mu % (unsigned)p.Wo);
+    unsigned t = mu / (unsigned)p.Wo;
+    const int oh = (int)(t % (unsigned)p.Ho);
+    t /= (unsigned)p.Ho;
+    sod[i] = (int)(t % (unsigned)p.Do);
+    sn[i] = (int)(t / (unsigned)p.Do);
     soh[i] = oh;
     sow[i] = ow;
   }
@@ -521,12 +523,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long long m = m_begin + pxl + i * 16;
-    const int ow = (int)(m % p.Wo);
-    long long t = m / p.Wo;
-    const int oh = (int)(t % p.Ho);
-    t /= p.Ho;
-    sod[i] = (int)(t % p.Do);
-    sn[i] = (int)(t / p.Do);
+    const unsigned mu = (unsigned)m;                      // M < 2^31 (checked on the host): 32-bit divisions
+    const int ow = (int)(mu % (unsigned)p.Wo);
+    unsigned t = mu / (unsigned)p.Wo;
+    const int oh = (int)(t % (unsigned)p.Ho);
+    t /= (unsigned)p.Ho;
+    sod[i] = (int)(t % (unsigned)p.Do);
+    sn[i] = (int)(t / (unsigned)p.Do);
     soh[i] = oh;
     sow[i] = ow;
   }
@@ -1141,7 +1144,9 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 }
 
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
-template <int BCO>
+// PW = point-wise (1x1x1, stride 1, no padding, no up-sampling): input pixel == output pixel, so the per-row
+// (n, d, h, w) decode, the tap bounds tests and the per-step carry loops disappear from the K loop.
+template <int BCO, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
   typedef bf16_t T;
   constexpr int CH = 8;
@@ -1193,13 +1198,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
   int sn[4], sod[4], soh[4], sow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (PW) { sn[i] = sod[i] = soh[i] = sow[i] = 0; continue; }
     const long long m = m_begin + pxl + i * 16;
-    const int ow = (int)(m % p.Wo);
-    long long t = m / p.Wo;
-    const int oh = (int)(t % p.Ho);
-    t /= p.Ho;
-    sod[i] = (int)(t % p.Do);
-    sn[i] = (int)(t / p.Do);
+    const unsigned mu = (unsigned)m;                      // M < 2^31 (checked on the host): 32-bit divisions
+    const int ow = (int)(mu % (unsigned)p.Wo);
+    unsigned t = mu / (unsigned)p.Wo;
+    const int oh = (int)(t % (unsigned)p.Ho);
+    t /= (unsigned)p.Ho;
+    sod[i] = (int)(t % (unsigned)p.Do);
+    sn[i] = (int)(t / (unsigned)p.Do);
     soh[i] = oh;
     sow[i] = ow;
   }
@@ -1216,12 +1223,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long m = mt + pxl + i * 16;
-      const int id = sod[i] * p.sd - p.pd + kd, ih = soh[i] * p.sh - p.ph + kh, iw = sow[i] * p.sw - p.pw + kw;
-      const bool ok = kvalid && m < m_end && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
-                      (unsigned)iw < (unsigned)p.We;
-      const int src = ups ? ((sn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
-                          : ((sn[i] * p.De + id) * p.He + ih) * p.We + iw;
-      const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+      const char* g;
+      if (PW) {
+        g = (kvalid && m < m_end) ? (const char*)(xp + m * p.ldx + c) : zero;
+      } else {
+        const int id = sod[i] * p.sd - p.pd + kd, ih = soh[i] * p.sh - p.ph + kh, iw = sow[i] * p.sw - p.pw + kw;
+        const bool ok = kvalid && m < m_end && (unsigned)id < (unsigned)p.De && (unsigned)ih < (unsigned)p.He &&
+                        (unsigned)iw < (unsigned)p.We;
+        const int src = ups ? ((sn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
+                            : ((sn[i] * p.De + id) * p.He + ih) * p.We + iw;
+        g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+      }
       hdu_glds16(g, Xt + (i * 16 + wave * 4) * XROWB);
     }
 #pragma unroll
@@ -1233,6 +1245,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
   };
 
   auto advance_pixels = [&]() {
+    if (PW) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       sow[i] += PX;
@@ -1994,7 +2007,10 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
   if (k.pro_a == nullptr && k.skip == nullptr) {
     ConvK kk = k;
     kk.wg_gx = (int)gx; kk.wg_gy = (int)gy; kk.wg_gz = (int)gz;
-    HDU_LAUNCH((conv_wgrad_dma_kernel<BCO>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
+    const bool pw = k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 && (k.pd | k.ph | k.pw) == 0 &&
+                    (k.ud | k.uh | k.uw) == 0;
+    if (pw) HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, true>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
+    else HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, false>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
   } else
     HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
 }
