@@ -782,6 +782,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   const char* zero = (const char*)hdu_zero_page;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
+  const bool pointwise = p.KD * p.KH * p.KW == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && (p.pd | p.ph | p.pw) == 0 &&
+                         !(p.debug_flags & 8);
   // per-row state.  FAST (no up-sampling, <= 32 taps, tensor < 2^31 elements): a tap-validity bitmask and an
   // element offset per row are computed ONCE, so a DMA in the K loop costs a shift/and, one add and the pointer add.
   int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
@@ -790,7 +792,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   for (int i = 0; i < A_IT; ++i) {
     const unsigned m = (unsigned)(m0 + r0 + i * 32);     // M < 2^31 (checked on the host)
     rmask[i] = 0u;
-    if ((long long)m < p.M) {
+    if (FAST && pointwise) {                             // 1x1x1 stride 1 no padding: input pixel == output pixel
+      rn[i] = 0; rid[i] = 0; rih[i] = 0; riw[i] = 0;
+      rpix[i] = (long long)m < p.M ? (int)m * (int)p.ldx : 0;
+      rmask[i] = (long long)m < p.M ? 1u : 0u;
+    } else if ((long long)m < p.M) {
       const unsigned ow = m % (unsigned)p.Wo;
       unsigned t = m / (unsigned)p.Wo;
       const unsigned oh = t % (unsigned)p.Ho;
@@ -1004,6 +1010,8 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   const char* zero = (const char*)hdu_zero_page;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
+  const bool pointwise = p.KD * p.KH * p.KW == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && (p.pd | p.ph | p.pw) == 0 &&
+                         !(p.debug_flags & 8);
   // per-row state.  FAST (no up-sampling, <= 32 taps, tensor < 2^31 elements): a tap-validity bitmask and an
   // element offset per row are computed ONCE, so a DMA in the K loop costs a shift/and, one add and the pointer add.
   int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
@@ -1012,7 +1020,11 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   for (int i = 0; i < A_IT; ++i) {
     const unsigned m = (unsigned)(m0 + r0 + i * 32);     // M < 2^31 (checked on the host)
     rmask[i] = 0u;
-    if ((long long)m < p.M) {
+    if (FAST && pointwise) {                             // 1x1x1 stride 1 no padding: input pixel == output pixel
+      rn[i] = 0; rid[i] = 0; rih[i] = 0; riw[i] = 0;
+      rpix[i] = (long long)m < p.M ? (int)m * (int)p.ldx : 0;
+      rmask[i] = (long long)m < p.M ? 1u : 0u;
+    } else if ((long long)m < p.M) {
       const unsigned ow = m % (unsigned)p.Wo;
       unsigned t = m / (unsigned)p.Wo;
       const unsigned oh = t % (unsigned)p.Ho;
