@@ -284,7 +284,7 @@ static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   *cols = red_cols_for(nchunks);
   *gy = (unsigned)((nchunks + *cols - 1) / *cols);
   const int rows = 256 / *cols;
-  long long want = 1024 / *gy;
+  long long want = (g_tuning[HDU_TUNE_RED_WGS] > 0 ? g_tuning[HDU_TUNE_RED_WGS] : 1024) / *gy;
   if (want < 1) want = 1;
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);  // >= 4 rows per thread
   if (maxb < 1) maxb = 1;
@@ -591,7 +591,7 @@ static void row_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   *cols = c;
   *gy = (unsigned)((nchunks + c - 1) / c);
   const int rows = 256 / c;
-  long long want = 2048 / *gy;
+  long long want = (g_tuning[HDU_TUNE_ROW_WGS] > 0 ? g_tuning[HDU_TUNE_ROW_WGS] : 2048) / *gy;
   if (want < 1) want = 1;
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);
   if (maxb < 1) maxb = 1;

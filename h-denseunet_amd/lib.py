@@ -132,6 +132,10 @@ def load(path=None):
     _backend = _lib.hdu_backend().decode()
     if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
         _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_RED_WGS" in os.environ:
+        _lib.hdu_set_tuning(11, int(os.environ["HDU_RED_WGS"]))
+    if "HDU_ROW_WGS" in os.environ:
+        _lib.hdu_set_tuning(12, int(os.environ["HDU_ROW_WGS"]))
     if "HDU_FUSED_FINALIZE" in os.environ:
         _lib.hdu_set_tuning(10, int(os.environ["HDU_FUSED_FINALIZE"]))
     if "HDU_NO_HALO_FPROP" in os.environ:

@@ -48,9 +48,19 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
     assert e <= 2e-4 * scale, "train-mode logits: max abs err %.3e (scale %.3g)" % (e, scale)
     assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
     assert min(U.dice_vs_oracle(got_l, rl)) >= 1 - 1e-3
-    # gradients: relative L2 error per tensor (max-norm is dominated by single ReLU flips at f32 roundoff)
+    # gradients: relative L2 error per tensor (max-norm is dominated by single ReLU flips at f32 roundoff).
+    # Calibration: the float32 oracle differs from ITSELF by this much when only its convolution algorithm changes
+    # (torch mkldnn on/off, 224x224x12): end2end worst 1.0 % / median 0.07 %, 3dpart worst 3.3 % / median 1.4 % (the
+    # frozen-2D-net graph is chaotic: 1.4e-4 on the logits already).  Measured here (MI355X): 2d-512 0.44 % / 0.03 %,
+    # densenet 1.8 % / 0.5 %, 3dpart 2.9 % / 1.7 %, end2end 1.1 % / 0.09 %, 3d 2.3 % / 0.26 %.  The per-config bounds
+    # are ~2x those; a kernel that dropped 4 of 128 tile rows (3 % of the pixels) measured 5.8-10 % / 0.9 % and a
+    # norm ratio of 0.96, i.e. it fails all three checks.
+    tol_worst, tol_median = {("2d", "denseunet"): (2e-2, 3e-3), ("2d", "densenet"): (4e-2, 1.5e-2),
+                             ("hybrid", "3dpart"): (6e-2, 4e-2), ("hybrid", "end2end"): (3e-2, 5e-3),
+                             ("3d", "3dpart"): (5e-2, 1e-2)}[(kind, variant)]
     gg = m.get_grads_dict()
     worst = (0.0, None)
+    rels, ratios = [], []
     rms_max = max(float(np.sqrt((g.numpy().astype(np.float64) ** 2).mean())) for g in ref_grads.values())
     for (name, i), g in ref_grads.items():
         a, r = gg[name][i].astype(np.float64), g.numpy().astype(np.float64)
@@ -58,9 +68,15 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
         # roundoff noise in both implementations
         den = max(np.linalg.norm(r), 1e-3 * rms_max * np.sqrt(r.size))
         rel = np.linalg.norm(a - r) / den
+        rels.append(rel)
+        if np.linalg.norm(r) > 1e-2 * rms_max * np.sqrt(r.size):
+            ratios.append(np.linalg.norm(a) / np.linalg.norm(r))
         if rel > worst[0]:
             worst = (rel, (name, i))
-    assert worst[0] < 5e-2, "gradient L2 mismatch: %s" % (worst,)
+    assert worst[0] < tol_worst, "gradient L2 mismatch: %s" % (worst,)
+    assert float(np.median(rels)) < tol_median, "median gradient error %.4f" % float(np.median(rels))
+    # a systematic deficit (dropped pixels / taps) shows as a norm ratio != 1 on average; noise averages out
+    assert abs(float(np.mean(ratios)) - 1.0) < 5e-3, "mean |got|/|ref| = %.4f" % float(np.mean(ratios))
     # SGD update direction: updated weights moved by (-lr*g*(1+momentum)) -> compare deltas on the classifier
     w_after = m.get_weights_dict()
     last = {"2d": "dense167classifer", "hybrid": "2d3dclassifer", "3d": "3dclassifer"}[kind]

@@ -26,6 +26,7 @@ S2D = [
     ("b4_x1_1x1_2064", 8, 1, 32, 32, 2064, 192, (1, 1, 1), (0, 0, 0), True, (1, 1, 1), (0, 0, 0)),
     ("b4_x2_3x3", 8, 1, 32, 32, 192, 48, (1, 3, 3), (0, 0, 0), True, (1, 1, 1), (0, 1, 1)),
     ("b5_x1_1x1_2160", 8, 1, 16, 16, 2160, 192, (1, 1, 1), (0, 0, 0), True, (1, 1, 1), (0, 0, 0)),
+    ("b5_x2_3x3", 8, 1, 16, 16, 192, 48, (1, 3, 3), (0, 0, 0), True, (1, 1, 1), (0, 1, 1)),
     ("trans4_1x1", 8, 1, 32, 32, 2112, 1056, (1, 1, 1), (0, 0, 0), True, (1, 1, 1), (0, 0, 0)),
     ("line0_1x1", 8, 1, 32, 32, 2112, 2208, (1, 1, 1), (0, 0, 0), False, (1, 1, 1), (0, 0, 0)),
     ("conv_up0", 8, 1, 16, 16, 2208, 768, (1, 3, 3), (0, 1, 1), True, (1, 1, 1), (0, 1, 1)),
