@@ -185,7 +185,7 @@ def main():
         gcols, cols = cols, cols // world
         a.no_graph = True
     m = build(a.config, a.dtype, b, size, cols)
-    if world > 1 and a.config != "shard3d":
+    if (world > 1 or os.environ.get("HDU_FORCE_DP") == "1") and a.config != "shard3d":
         par.attach_data_parallel(m)
     synth = importlib.import_module("h-denseunet_amd.synth")
     kind = "2d" if a.config == "2d" else "hybrid"
@@ -205,8 +205,10 @@ def main():
     for _ in range(a.warmup):
         m.train_step_resident()
 
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -216,7 +218,7 @@ def main():
         m.train_step_resident()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -258,7 +260,7 @@ def main():
         if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
             out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

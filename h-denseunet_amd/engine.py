@@ -97,6 +97,21 @@ class Var:
         return r.mean[self.c0:self.c0 + self.C], r.var[self.c0:self.c0 + self.C]
 
 
+class _BwdList(list):
+    """backward closures in forward order; remembers how many parameters existed when each one was appended, so that a
+    suffix of the list (= a prefix of the backward pass) can be mapped to the range of the flat gradient buffer it
+    completes (gradient buckets of the data-parallel exchange)"""
+
+    def __init__(self, ctx):
+        super().__init__()
+        self._ctx = ctx
+        self.mark = []
+
+    def append(self, fn):
+        super().append(fn)
+        self.mark.append(len(self._ctx.params))
+
+
 class Ctx:
     """Build + run context of one model."""
 
@@ -107,7 +122,7 @@ class Ctx:
         self.by_layer = OrderedDict()
         self.layer_kind = OrderedDict()
         self.fwd = []          # list of callables
-        self.bwd = []          # appended in forward order, executed reversed
+        self.bwd = _BwdList(self)   # appended in forward order, executed reversed
         self.vars = []
         self.learning_phase = 1
         self.pass_id = 0
@@ -286,13 +301,47 @@ class Ctx:
         for f in self.fwd:
             f()
 
-    def run_backward(self):
-        for v in self.vars:
-            v.written = False
-        self.wgrad_open = False
-        for f in reversed(self.bwd):
+    def run_backward(self, seg=None):
+        """the whole backward pass, or positions [seg[0], seg[1]) of it (in execution order) -- see grad_buckets"""
+        lo, hi = seg if seg is not None else (0, len(self.bwd))
+        if lo == 0:
+            for v in self.vars:
+                v.written = False
+            self.wgrad_open = False
+        order = list(reversed(self.bwd))
+        for f in order[lo:hi]:
             f()
         self.join_wgrad()
+
+    def grad_buckets(self, fractions):
+        """Cut the backward pass where the first-completed `fractions` of the trainable parameters have their final
+        gradient (layers own their parameters, parameters are laid out in creation order, the backward runs the
+        layers in reverse): returns [(pos_lo, pos_hi, off_lo, off_hi)] in execution order -- after positions
+        [pos_lo, pos_hi) of the backward have run, G[off_lo:off_hi] is complete and can be exchanged while the rest
+        of the backward computes."""
+        n = len(self.bwd)
+        tr = [p for p in self.params if p.trainable]
+        index_of = {id(p): i for i, p in enumerate(self.params)}
+        total = sum(p.numel for p in tr)
+        cuts = []          # (position in execution order, flat offset): everything at offsets >= off is complete
+        for f in sorted(fractions):
+            want, done, pos, off = f * total, 0, n, self.n_trainable
+            # walking the backward from the last layer: after bwd[k] ran, parameters created after mark[k-1] are done
+            for k in range(n - 1, -1, -1):
+                first = self.bwd.mark[k - 1] if k > 0 else 0
+                own = [p for p in tr if first <= index_of[id(p)]]
+                done = sum(p.numel for p in own)
+                if done >= want:
+                    pos, off = n - k, min([p.offset for p in own] + [self.n_trainable])
+                    break
+            if 0 < pos < n and (not cuts or pos > cuts[-1][0]):
+                cuts.append((pos, off))
+        out, prev_pos, prev_off = [], 0, self.n_trainable
+        for pos, off in cuts:
+            out.append((prev_pos, pos, off, prev_off))
+            prev_pos, prev_off = pos, off
+        out.append((prev_pos, n, 0, prev_off))
+        return out
 
     # Filter gradients only feed the optimiser: they run on a side stream, concurrently with the data-gradient /
     # BN-backward chain (forked after each dy is complete, joined once before the SGD update).  The many small

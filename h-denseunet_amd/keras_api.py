@@ -99,6 +99,8 @@ class Model:
         self.world_size = 1
         self._graph = None
         self._allreduce = None
+        self._allreduce_async = None
+        self._buckets = None
         self.inputs = [self.input_shape]
         self.outputs = [self.output_shape]
         self.stop_training = False
@@ -145,14 +147,20 @@ class Model:
             if fn is not None and getattr(fn, "__name__", "") not in ("weighted_crossentropy", "weighted_crossentropy_2ddense"):
                 raise ValueError("loss must be loss.weighted_crossentropy / weighted_crossentropy_2ddense")
 
-    def set_data_parallel(self, world_size, allreduce):
+    def set_data_parallel(self, world_size, allreduce, allreduce_async=None, bucket_fractions=(0.85,)):
         """one process per GPU: `allreduce(flat_grad_tensor)` sums gradients over ranks (RCCL); the loss of the
-        merged batch is a mean over ALL towers (multi_gpu.py:65-68 + loss.py:44)."""
+        merged batch is a mean over ALL towers (multi_gpu.py:65-68 + loss.py:44).
+        With `allreduce_async(t) -> work` (work.wait()) the exchange is bucketed: the backward pass is cut where the
+        first-completed `bucket_fractions` of the parameters (the decoder and the late dense blocks: most of the
+        bytes) have their final gradient; that bucket's all-reduce runs on the communication stream while the early
+        layers' backward still computes, and only the small last bucket is exposed."""
         self.world_size = world_size
         self._allreduce = allreduce
+        self._allreduce_async = allreduce_async
+        self._buckets = self.ctx.grad_buckets(bucket_fractions) if allreduce_async is not None else None
         self.loss_layer.global_scale = 1.0 / world_size
 
-    def _step_device(self):
+    def _step_head(self):
         ctx = self.ctx
         ctx.learning_phase = 1
         ctx.seed_dev.add_(1)
@@ -160,7 +168,14 @@ class Model:
         ctx.run_forward()
         ctx.G[:ctx.n_trainable].zero_()
         self.loss_layer.run(True)
-        ctx.run_backward()
+
+    def _step_device(self):
+        self._step_head()
+        self.ctx.run_backward()
+
+    def _exchange_bucket(self, bk):
+        lo, hi = bk[2], bk[3]
+        return self._allreduce_async(self.ctx.G[lo:hi]) if hi > lo else None
 
     def _step_update(self):
         ctx, opt = self.ctx, self.optimizer
@@ -176,16 +191,35 @@ class Model:
             raise RuntimeError("compile() the model first")
         if self._graph is not None:
             g_fb, g_upd = self._graph
-            g_fb.replay()
-            if self._allreduce is not None:
-                self._allreduce(self.ctx.G[:self.ctx.n_trainable])
+            if isinstance(g_fb, list):               # bucketed data parallel: one graph per backward segment
+                works = []
+                for g, bk in zip(g_fb, self._buckets):
+                    g.replay()
+                    works.append(self._exchange_bucket(bk))
+                for w in works:
+                    if w is not None:
+                        w.wait()
+            else:
+                g_fb.replay()
+                if self._allreduce is not None:
+                    self._allreduce(self.ctx.G[:self.ctx.n_trainable])
             if g_upd is not None:
                 g_upd.replay()
             self.optimizer.iterations += 1
             return
-        self._step_device()
-        if self._allreduce is not None:
-            self._allreduce(self.ctx.G[:self.ctx.n_trainable])
+        if self._buckets is not None:
+            self._step_head()
+            works = []
+            for bk in self._buckets:
+                self.ctx.run_backward((bk[0], bk[1]))
+                works.append(self._exchange_bucket(bk))
+            for w in works:
+                if w is not None:
+                    w.wait()
+        else:
+            self._step_device()
+            if self._allreduce is not None:
+                self._allreduce(self.ctx.G[:self.ctx.n_trainable])
         self._step_update()
 
     def capture_graph(self, warmup=2):
@@ -210,8 +244,18 @@ class Model:
                 self._step_device()
                 self._step_update()
         else:
-            with torch.cuda.graph(g_fb):
-                self._step_device()
+            if self._buckets is not None:
+                g_fb = []
+                for i, bk in enumerate(self._buckets):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        if i == 0:
+                            self._step_head()
+                        self.ctx.run_backward((bk[0], bk[1]))
+                    g_fb.append(g)
+            else:
+                with torch.cuda.graph(g_fb):
+                    self._step_device()
             g_upd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_upd):
                 self._step_update()

@@ -17,9 +17,12 @@ def init_process_group_from_env(backend=None):
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and os.environ.get("HDU_FORCE_DP") != "1":
         return 0, 1
-    rank = int(os.environ["RANK"])
+    # HDU_FORCE_DP=1: run the multi-process code path (process group, broadcast, eager all-reduce between the two
+    # hipGraphs) with a world of ONE -- the only way to exercise RCCL on a single-GPU box
+    os.environ.setdefault("MASTER_PORT", "29533")
+    rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -34,20 +37,34 @@ def attach_data_parallel(model, expected_world=None):
     rank, world = init_process_group_from_env()
     if expected_world is not None and world != expected_world and world != 1:
         raise RuntimeError("make_parallel asked for %d GPUs but WORLD_SIZE=%d" % (expected_world, world))
-    if world == 1:
+    if world == 1 and os.environ.get("HDU_FORCE_DP") != "1":
         return model
 
     def allreduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
-    model.set_data_parallel(world, allreduce)
+    def allreduce_async(t):
+        if os.environ.get("HDU_DP_SYNC_BUCKETS") == "1":      # A/B: bucketed but on the compute stream (no overlap)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+    # HDU_DP_BUCKETS: "0" (default) = one all-reduce after the backward; otherwise the parameter fractions at which the
+    # backward is cut, e.g. "0.85": decoder + dense blocks 5 and 4 first, exchanged under the rest of the backward.
+    # Opt-in: on the one GPU available this round the communication-stream hand-off alone cost 1.3 ms per step
+    # (world 1: 293 vs 308 slices/s), about what the overlap could save on 8 GPUs; to be re-measured on a real node.
+    spec = os.environ.get("HDU_DP_BUCKETS", "0")
+    if spec in ("0", ""):
+        model.set_data_parallel(world, allreduce)
+    else:
+        model.set_data_parallel(world, allreduce, allreduce_async, tuple(float(v) for v in spec.split(",")))
     broadcast_parameters(model)
     return model
 
 
 def broadcast_parameters(model, src=0):
     """identical initial weights on every rank (the towers of multi_gpu.py share one set of variables)"""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("HDU_FORCE_DP") == "1"):
         dist.broadcast(model.ctx.P, src=src)
         dist.broadcast(model.ctx.V, src=src)
 

@@ -43,6 +43,12 @@ def main():
     dp = make(seed=7 + rank)                  # different seeds: make_parallel must broadcast rank 0's weights
     ka.make_parallel(dp, 2, mini_batch=1)
     assert dp.world_size == 2
+    # bucketed exchange (HDU_DP_BUCKETS set by the test): the buckets tile the flat gradient buffer and the backward
+    bks = dp._buckets
+    assert bks is not None and len(bks) >= 3, bks
+    assert bks[0][0] == 0 and bks[-1][1] == len(dp.ctx.bwd) and bks[0][3] == dp.ctx.n_trainable and bks[-1][2] == 0
+    for a, b in zip(bks[:-1], bks[1:]):
+        assert a[1] == b[0] and a[2] == b[3] and a[0] < a[1] and a[2] < a[3], bks
     w0 = [torch.zeros_like(dp.ctx.P) for _ in range(world)]
     dist.all_gather(w0, dp.ctx.P)
     assert torch.equal(w0[0], w0[1]), "weights not broadcast"

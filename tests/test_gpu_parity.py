@@ -122,3 +122,21 @@ def test_train_loss_decreases_bf16(hip_lib):
         m.train_step_resident()
     l1 = m.loss_value()
     assert np.isfinite(l0) and np.isfinite(l1) and l1 < 0.7 * l0, (l0, l1)
+
+
+def test_rccl_data_parallel_path_world1(hip_lib):
+    """The multi-process code path (process group over RCCL, parameter broadcast, the eager flat all-reduce between
+    the two captured hipGraphs) with a world of ONE -- what a single-GPU box can exercise; world-2 numerics are covered
+    by the gloo test on CPU (tests/test_dp_gloo.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HDU_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(U.ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2",
+                          "--size", "64", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and np.isfinite(rec["config"]["loss"])
