@@ -20,18 +20,27 @@ struct FinK {
   float* k1; float* k2; float* k3; float* dgamma; float* dbeta; float* dsgamma; float* dsbeta;  // kind 2 outputs
 };
 
-__device__ __forceinline__ void bn_fold_channel(int c, float mu, float v, const float* gamma, const float* beta,
-                                                float eps, const float* sgamma, const float* sbeta, float* a, float* b,
-                                                float* rstd, float* mov_mean, float* mov_var, float momentum) {
+// tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
+__device__ __forceinline__ void bn_fold_coef(int c, float mu, float v, const float* gamma, const float* beta, float eps,
+                                             const float* sgamma, const float* sbeta, float* a, float* b, float* r_out) {
   const float r = 1.0f / sqrtf(v + eps);
   const float g = gamma ? gamma[c] : 1.f;
   const float be = beta ? beta[c] : 0.f;
   const float sg = sgamma ? sgamma[c] : 1.f;
   const float sb = sbeta ? sbeta[c] : 0.f;
-  // tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
   const float inv = g * r;
-  a[c] = sg * inv;
-  b[c] = sg * (be - mu * inv) + sb;
+  *a = sg * inv;
+  *b = sg * (be - mu * inv) + sb;
+  *r_out = r;
+}
+
+__device__ __forceinline__ void bn_fold_channel(int c, float mu, float v, const float* gamma, const float* beta,
+                                                float eps, const float* sgamma, const float* sbeta, float* a, float* b,
+                                                float* rstd, float* mov_mean, float* mov_var, float momentum) {
+  float ac, bc, r;
+  bn_fold_coef(c, mu, v, gamma, beta, eps, sgamma, sbeta, &ac, &bc, &r);
+  a[c] = ac;
+  b[c] = bc;
   if (rstd) rstd[c] = r;
   if (mov_mean) mov_mean[c] -= (mov_mean[c] - mu) * (1.f - momentum);
   if (mov_var) mov_var[c] -= (mov_var[c] - v) * (1.f - momentum);
@@ -617,6 +626,13 @@ struct MatK {
   long long ldx, ldskip, ldo, Mo, rows_per_block;
   int N, D, H, W, C;
   int ud, uh, uw, relu;
+  // optional in-kernel BN fold (saves the separate bn_fold launch of every dense-layer BN that shares slab statistics):
+  // every thread derives a/b of its own channels from (mean, var, gamma, beta, Scale); the first row block also stores
+  // a/b/rstd for the backward pass and updates the moving statistics
+  const float* f_mean; const float* f_var; const float* f_gamma; const float* f_beta; const float* f_sgamma;
+  const float* f_sbeta;
+  float f_eps, f_momentum;
+  float* f_a; float* f_b; float* f_rstd; float* f_mov_mean; float* f_mov_var;
 };
 
 template <typename T, int COLS>
@@ -630,8 +646,26 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
   const T* __restrict__ sp = (const T*)p.skip;
   T* __restrict__ op = (T*)p.out;
   float a[CH], b[CH];
+  if (p.f_mean) {
+    const bool writer = blockIdx.x == 0 && rl == 0;
 #pragma unroll
-  for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
+    for (int j = 0; j < CH; ++j) {
+      const int c = c0 + j;
+      const float mu = p.f_mean[c], v = p.f_var[c];
+      float r;
+      bn_fold_coef(c, mu, v, p.f_gamma, p.f_beta, p.f_eps, p.f_sgamma, p.f_sbeta, &a[j], &b[j], &r);
+      if (writer) {
+        p.f_a[c] = a[j];
+        p.f_b[c] = b[j];
+        if (p.f_rstd) p.f_rstd[c] = r;
+        if (p.f_mov_mean) p.f_mov_mean[c] -= (p.f_mov_mean[c] - mu) * (1.f - p.f_momentum);
+        if (p.f_mov_var) p.f_mov_var[c] -= (p.f_mov_var[c] - v) * (1.f - p.f_momentum);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
+  }
   const int We = p.W << p.uw, He = p.H << p.uh, De = p.D << p.ud;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
@@ -730,9 +764,32 @@ extern "C" int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, 
   return hdu_check_launch("affine_act");
 }
 
+static int materialize_impl(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
+                            const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
+                            void* out, int64_t ldout, void* stream, const MatK* fold);
+
 extern "C" int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
                                const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
                                void* out, int64_t ldout, void* stream) {
+  return materialize_impl(dtype, x, ldx, N, D, H, W, C, a, b, relu, ud, uh, uw, skip, ldskip, out, ldout, stream, nullptr);
+}
+
+extern "C" int hdu_materialize_bn(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C,
+                                  const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                  const float* sgamma, const float* sbeta, float* a, float* b, float* rstd,
+                                  float* mov_mean, float* mov_var, float momentum, int relu, int ud, int uh, int uw,
+                                  const void* skip, int64_t ldskip, void* out, int64_t ldout, void* stream) {
+  if (!mean || !var || !a || !b) return hdu_set_error(HDU_ERR_ARG, "materialize_bn: null pointer");
+  MatK f{};
+  f.f_mean = mean; f.f_var = var; f.f_gamma = gamma; f.f_beta = beta; f.f_sgamma = sgamma; f.f_sbeta = sbeta;
+  f.f_eps = eps; f.f_momentum = momentum; f.f_a = a; f.f_b = b; f.f_rstd = rstd; f.f_mov_mean = mov_mean;
+  f.f_mov_var = mov_var;
+  return materialize_impl(dtype, x, ldx, N, D, H, W, C, a, b, relu, ud, uh, uw, skip, ldskip, out, ldout, stream, &f);
+}
+
+static int materialize_impl(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
+                            const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
+                            void* out, int64_t ldout, void* stream, const MatK* fold) {
   if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "materialize: bad dtype");
   const int ch = dtype == HDU_BF16 ? 8 : 4;
   if (!x || !out || ((a == nullptr) != (b == nullptr)) || ((ud | uh | uw) & ~1))
@@ -740,6 +797,7 @@ extern "C" int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int
   if (C <= 0 || C % ch || ldx % ch || ldout % ch || (skip && ldskip % ch) || N <= 0 || D <= 0 || H <= 0 || W <= 0)
     return hdu_set_error(HDU_ERR_ARG, "materialize: C / strides must be multiples of the 16-byte chunk");
   MatK k{};
+  if (fold) k = *fold;
   k.x = x; k.skip = skip; k.out = out; k.a = a; k.b = b; k.ldx = ldx; k.ldskip = ldskip; k.ldo = ldout;
   k.N = N; k.D = D; k.H = H; k.W = W; k.C = C; k.ud = ud; k.uh = uh; k.uw = uw; k.relu = relu;
   k.Mo = (long long)N * (D << ud) * (H << uh) * (W << uw);

@@ -139,6 +139,9 @@ class Ctx:
         self.grad_enabled = True
         self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
+        # BN fold inside the materialise launch (hdu_materialize_bn): saves 82 tiny launches per step but makes every
+        # workgroup of 161 big launches derive its coefficients from six vectors -- measured 296 vs 310 slices/s: off
+        self.fuse_fold = os.environ.get("HDU_FUSE_FOLD", "0") == "1"
         # 0 = off, 1 = every layer, 2 = only layers with <= 16384 output pixels (latency-bound on their own)
         self.overlap_wgrad = int(os.environ.get("HDU_OVERLAP_WGRAD", "0"))
         self._side = None
@@ -393,22 +396,28 @@ class BNLayer:
     def needs_stats(self):
         return self.mode == "batch"
 
-    def fold(self, xvar):
+    def fold(self, xvar, defer=False):
+        """a/b/rstd of this pass.  defer=True (the caller materialises x right away): returns the argument tuple of
+        ops.materialize_bn instead of launching bn_fold, or None when nothing is left to do."""
         ctx = self.ctx
         sg = self.sg.data if self.sg else None
         sb = self.sb.data if self.sb else None
         self.batch_now = self.mode == "batch" and ctx.learning_phase == 1
         if self.batch_now and self.folded_pass == ctx.pass_id:
-            return   # the statistics reduction of this pass already folded this BN (StatsOp.fused)
+            return None  # the statistics reduction of this pass already folded this BN (StatsOp.fused)
         if self.batch_now:
             mean, var = xvar.stats()
-            ops.bn_fold(self.C, mean, var, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a, self.b,
-                        self.rstd, self.mm.data, self.mv.data, self.momentum)
             self.mean_used = mean
+            args = (mean, var, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a, self.b, self.rstd,
+                    self.mm.data, self.mv.data, self.momentum)
         else:
-            ops.bn_fold(self.C, self.mm.data, self.mv.data, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a,
-                        self.b, self.rstd)
             self.mean_used = self.mm.data
+            args = (self.mm.data, self.mv.data, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a, self.b,
+                    self.rstd, None, None, self.momentum)
+        if defer:
+            return args
+        ops.bn_fold(self.C, *args)
+        return None
 
     def backward(self, xvar, dz_act):
         """dz: gradient w.r.t. relu(a*x+b) at x's resolution.  Writes x.grad and the parameter gradients."""
@@ -559,14 +568,19 @@ class ConvLayer:
 
     def forward(self):
         ctx = self.ctx
+        deferred = None
         if self.bn is not None:
-            self.bn.fold(self.x)
+            deferred = self.bn.fold(self.x, defer=self.xin is not None and ctx.fuse_fold)
         if self.xin is not None:
             bn = self.bn
-            ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False,
-                            self.up if self.skip is not None else (0, 0, 0),
-                            self.skip.act if self.skip is not None else None,
-                            self.xin_interior if self.halo else self.xin.act)
+            up = self.up if self.skip is not None else (0, 0, 0)
+            skip = self.skip.act if self.skip is not None else None
+            dst = self.xin_interior if self.halo else self.xin.act
+            if deferred is not None:      # BN fold inside the materialise launch
+                ops.materialize_bn(self.x.act, *deferred, bn.relu, up, skip, dst)
+            else:
+                ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False, up,
+                                skip, dst)
             if self.halo:
                 _sh.halo_exchange(ctx.shard, self.xin.act, self.halo)
         if self.d_f_drop is not None and ctx.learning_phase == 1 and ctx.dropout_enabled:

@@ -73,6 +73,8 @@ _SIGS = {
     "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
     "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
                                 c_p, c_i64, c_p, c_i64, c_p]),
+    "hdu_materialize_bn": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
+                                   c_p, c_p, c_p, c_p, c_p, c_f, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_int, c_p]),
     "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_int, c_p]),

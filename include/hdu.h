@@ -186,6 +186,15 @@ int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, 
                     const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip, void* out,
                     int64_t ldout, void* stream);
 
+/* hdu_materialize with the BN(+Scale) fold of hdu_bn_fold done inside the same launch: a/b are derived per thread from
+ * (mean, var, gamma, beta, Scale); a, b, rstd and the moving statistics are ALSO written (first row block) exactly as
+ * hdu_bn_fold would -- K.layers/normalization.py:126-190 + lib/custom_layers.py:63-69 */
+int hdu_materialize_bn(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* mean,
+                       const float* var, const float* gamma, const float* beta, float eps, const float* sgamma,
+                       const float* sbeta, float* a, float* b, float* rstd, float* mov_mean, float* mov_var,
+                       float momentum, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip, void* out,
+                       int64_t ldout, void* stream);
+
 /* per-channel column sum: out[c] = sum_m x[m][c]   (bias gradients) */
 int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws, size_t ws_bytes,
                void* stream);

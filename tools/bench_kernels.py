@@ -87,5 +87,30 @@ for (name, N, D, H, W, Cin, Cout, K, up, pro, st, pad) in (S2D if which == "2d" 
     t_w = timeit(lambda: ops.conv_wgrad(d, dw))
     tot["wgrad"] += t_w
     line += " | wgrad %8.3f ms %7.1f TF" % (t_w, flops / t_w / 1e9)
+    if st == (1, 1, 1) and os.environ.get("BENCH_PAIR"):
+        # would a merged dgrad+wgrad launch pay?  Upper bound: the two kernels on two streams inside one hipGraph
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+        def pair():
+            cur = torch.cuda.current_stream()
+            s1.wait_stream(cur); s2.wait_stream(cur)
+            with torch.cuda.stream(s1):
+                ops.conv_fprop(dd)
+            with torch.cuda.stream(s2):
+                ops.conv_wgrad(d, dw)
+            cur.wait_stream(s1); cur.wait_stream(s2)
+
+        def seq():
+            ops.conv_fprop(dd); ops.conv_wgrad(d, dw)
+
+        res = []
+        for fn in (seq, pair):
+            fn(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(10):
+                    fn()
+            res.append(timeit(g.replay) / 10)
+        line += " | graph seq %6.1f us, 2 streams %6.1f us" % (res[0] * 1e3, res[1] * 1e3)
     print(line, flush=True)
 print("sum ms:", tot)
