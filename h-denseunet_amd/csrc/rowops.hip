@@ -293,7 +293,7 @@ static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   *cols = red_cols_for(nchunks);
   *gy = (unsigned)((nchunks + *cols - 1) / *cols);
   const int rows = 256 / *cols;
-  long long want = (g_tuning[HDU_TUNE_RED_WGS] > 0 ? g_tuning[HDU_TUNE_RED_WGS] : 1024) / *gy;
+  long long want = (g_tuning[HDU_TUNE_RED_WGS] > 0 ? g_tuning[HDU_TUNE_RED_WGS] : 512) / *gy;
   if (want < 1) want = 1;
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);  // >= 4 rows per thread
   if (maxb < 1) maxb = 1;

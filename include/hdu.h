@@ -48,7 +48,7 @@ int hdu_abi_version(void);
 #define HDU_TUNE_NO_FAST 5           /* 1 = disable the bitmask/32-bit-offset addressing path (A/B) */
 #define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!) */
 #define HDU_TUNE_XCD_SWIZZLE 3       /* bit0 = XCD-aware tile order in the implicit GEMM (default on); bit1 = XCD-grouped filter-gradient grid (off: measured slower) */
-#define HDU_TUNE_RED_WGS 11          /* workgroups a per-channel reduction aims for (default 1024) */
+#define HDU_TUNE_RED_WGS 11          /* workgroups a per-channel reduction aims for (default 512) */
 #define HDU_TUNE_ROW_WGS 12          /* workgroups an element-wise row kernel aims for (default 2048) */
 #define HDU_TUNE_FUSED_FINALIZE 10   /* 1 = small-tensor reductions finish in the last workgroup of the same launch (off: measured slower) */
 #define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
