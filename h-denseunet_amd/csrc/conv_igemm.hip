@@ -2119,11 +2119,16 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   ConvK k;
   if (int e = fill_convk(d, &k, op == 1)) return e;
   if (!buf || buflen < 8) return hdu_set_error(HDU_ERR_ARG, "conv_kernel_name: bad buffer");
-  const char* t = d->dtype == HDU_BF16 ? "bf16" : "f32";
+  // spelled exactly as rocprofv3 prints the instantiation (so bench.py's live numbers and profiles/ line up)
+  const char* t = d->dtype == HDU_BF16 ? "unsigned short" : "float";
   if (op == 1) {
     const bool dma = k.pro_a == nullptr && k.skip == nullptr;
+    const bool pw = k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 && (k.pd | k.ph | k.pw) == 0 &&
+                    (k.ud | k.uh | k.uw) == 0;
     if (d->dtype == HDU_BF16 && wgrad_halo_ok(k)) snprintf(buf, buflen, "conv_wgrad_halo_kernel<%d>", choose_wgrad(k));
-    else snprintf(buf, buflen, d->dtype == HDU_BF16 ? (dma ? "conv_wgrad_dma_kernel<%d>" : "conv_wgrad_tr_kernel<%d>") : "conv_wgrad_kernel<f32,%d>", choose_wgrad(k));
+    else if (d->dtype == HDU_BF16 && dma) snprintf(buf, buflen, "conv_wgrad_dma_kernel<%d, %s>", choose_wgrad(k), pw ? "true" : "false");
+    else if (d->dtype == HDU_BF16) snprintf(buf, buflen, "conv_wgrad_tr_kernel<%d>", choose_wgrad(k));
+    else snprintf(buf, buflen, "conv_wgrad_kernel<float, %d>", choose_wgrad(k));
   } else if (fprop_halo_ok(k, d->dtype)) {
     snprintf(buf, buflen, "conv_halo_fprop_kernel<%d>", choose_halo_bn(k));
   } else {
@@ -2136,9 +2141,11 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
     const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;
     const bool ring = dma && stage * nsd <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128));
-    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s,%d,%d,%d,%d,%d>", t, bm, bn, wm, 4 / wm, nsd);
-    else if (dma && mode == 3) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s,%d,%d,%d,%d,3>", t, bm, bn, wm, 4 / wm);
-    else snprintf(buf, buflen, "conv_igemm%s_kernel<%s,%d,%d,%d,%d>", dma ? "_dma" : "", t, bm, bn, wm, 4 / wm);
+    const char* fast = igemm_fast_ok(k) ? "true" : "false";
+    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, nsd, fast);
+    else if (dma && mode == 3) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, 3, false>", t, bm, bn, wm, 4 / wm);
+    else if (dma) snprintf(buf, buflen, "conv_igemm_dma_kernel<%s, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, fast);
+    else snprintf(buf, buflen, "conv_igemm_kernel<%s, %d, %d, %d, %d>", t, bm, bn, wm, 4 / wm);
   }
   return 0;
 }
