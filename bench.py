@@ -79,13 +79,18 @@ def instrumented_step(m):
         return f
 
     ops.conv_fprop, ops.conv_wgrad = wrap(orig_f, 0), wrap(orig_w, 1)
+    batched = ctx.wgrad_plan is not None
     try:
         g = m._graph
         m._graph = None
+        if batched:
+            ctx.set_batch_wgrad(False)     # per-layer filter-gradient launches so that each one can be timed
         try:
             m.train_step_resident()
         finally:
             m._graph = g
+            if batched:
+                ctx.set_batch_wgrad(True)
         torch.cuda.synchronize()
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w

@@ -53,8 +53,8 @@ __device__ __forceinline__ unsigned xcd_tile_index(unsigned bid, unsigned nblk) 
 // gradients drops 4x (71 MB -> 17 MB per launch) but the kernels get SLOWER (43.8 -> 48.7 us; layers with < 8 pixel
 // splits collapse onto few XCDs): they are bound by DMA issue latency, not by fabric bytes.  OFF by default (bit 1 of
 // HDU_TUNE_XCD_SWIZZLE).  Returns false for the padding workgroups.
-__device__ __forceinline__ bool wgrad_block(const ConvK& p, unsigned* bx, unsigned* by, unsigned* bz) {
-  const unsigned bid = blockIdx.x, per = (unsigned)(p.wg_gx * p.wg_gy);
+__device__ __forceinline__ bool wgrad_block(const ConvK& p, unsigned bid, unsigned* bx, unsigned* by, unsigned* bz) {
+  const unsigned per = (unsigned)(p.wg_gx * p.wg_gy);
   unsigned w;
   if (p.xcd_swizzle & 2) {
     const unsigned slot = bid >> 3;
@@ -68,3 +68,11 @@ __device__ __forceinline__ bool wgrad_block(const ConvK& p, unsigned* bx, unsign
   *bx = w / (unsigned)p.wg_gy;
   return *bz < (unsigned)p.wg_gz;
 }
+
+// One layer of a batched filter-gradient launch (hdu_wgrad_plan_*): the launch covers the workgroups of MANY layers;
+// a workgroup finds its layer by binary search over the first-workgroup table and then runs the ordinary kernel body.
+struct WgradEntry {
+  ConvK k;
+  float* dw;
+  long long per;        // pixel rows (DMA form) / spatial tiles (halo form) per workgroup split
+};

@@ -1159,7 +1159,8 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 // PW = point-wise (1x1x1, stride 1, no padding, no up-sampling): input pixel == output pixel, so the per-row
 // (n, d, h, w) decode, the tap bounds tests and the per-step carry loops disappear from the K loop.
 template <int BCO, bool PW>
-__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+__device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict__ dw, long long rows_per_split,
+                                               unsigned bid, char* smem) {
   typedef bf16_t T;
   constexpr int CH = 8;
   constexpr int PX = 64;
@@ -1169,7 +1170,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
   constexpr int TM = BCO / 16;
   constexpr int TN = 2;
   constexpr int STAGE = PX * (XROWB + DROWB);
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
   unsigned wbx, wby, wbz;
-  if (!wgrad_block(p, &wbx, &wby, &wbz)) return;
+  if (!wgrad_block(p, bid, &wbx, &wby, &wbz)) return;
   const int kcol0 = (int)wbx * BKC;
   const int co0 = (int)wby * BCO;
   const long long m_begin = (long long)wbz * rows_per_split;
@@ -1343,7 +1343,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __r
 // Accumulators: 9 taps x [BCO x 32] per workgroup; wave w owns (tap, 16-channel tile) combos w, w+4, ... and all
 // BCO/16 output-channel tiles, so each B fragment is reused BCO/16 times and each A fragment ~4.5 times.
 template <int BCO>
-__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __restrict__ dw, int tiles_per_split) {
+__device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restrict__ dw, int tiles_per_split, unsigned bid,
+                                                char* smem) {
   typedef bf16_t T;
   constexpr int TH = 4, TW = 32, HC = TW + 2, HP = (TH + 2) * HC;      // 204 halo pixels
   constexpr int HPP = 208;                                             // padded to 16-pixel DMA instructions
@@ -1353,7 +1354,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __
   constexpr int STAGE = XBYTES + DBYTES;
   constexpr int TMc = BCO / 16;
   constexpr int NQ = 5;                                                // combos per wave (18 combos over 4 waves)
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __
   const T* __restrict__ dyp = (const T*)p.y;
   const char* zero = (const char*)hdu_zero_page;
   unsigned wbx, wby, wbz;
-  if (!wgrad_block(p, &wbx, &wby, &wbz)) return;
+  if (!wgrad_block(p, bid, &wbx, &wby, &wbz)) return;
   const int c0 = (int)wbx * 32;
   const int co0 = (int)wby * BCO;
   const int H = p.He, W = p.We;
@@ -1476,6 +1476,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __
         if (co < p.Cout && c < p.Cin) atomicAdd(dw + (long long)co * p.Ktot + tap * p.Cin + c, acc[q][i][r]);
       }
   }
+}
+
+// ---- launch forms of the two bf16 filter-gradient bodies.  Single: one layer per launch (hdu_conv_wgrad).  Batched:
+// one launch covers MANY layers (hdu_wgrad_plan_run): filter gradients feed nothing but the optimiser, so the engine
+// defers them to the end of the backward pass; the late dense layers (2048..8192 pixels) that cannot fill the chip on
+// their own then share it, and ~135 launches per step (ramp-up, tail, drain each) become a handful.
+template <int BCO, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * (256 + 128)];
+  wgrad_dma_body<BCO, PW>(p, dw, rows_per_split, blockIdx.x, smem);
+}
+
+template <int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(ConvK p, float* __restrict__ dw, int tiles_per_split) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (208 * 64 + 4 * 32 * 128)];
+  wgrad_halo_body<BCO>(p, dw, tiles_per_split, blockIdx.x, smem);
+}
+
+// workgroup -> (layer, workgroup within the layer): begins[i] = first workgroup of layer i, ascending
+__device__ __forceinline__ int batched_find(const unsigned* __restrict__ begins, int n, unsigned bid) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (begins[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+template <int BCO, bool PW>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_batched_kernel(const WgradEntry* __restrict__ tab,
+                                                                     const unsigned* __restrict__ begins, int n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * (256 + 128)];
+  const int e = batched_find(begins, n, blockIdx.x);
+  const ConvK p = tab[e].k;
+  wgrad_dma_body<BCO, PW>(p, tab[e].dw, tab[e].per, blockIdx.x - begins[e], smem);
+}
+
+template <int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_batched_kernel(const WgradEntry* __restrict__ tab,
+                                                                      const unsigned* __restrict__ begins, int n) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (208 * 64 + 4 * 32 * 128)];
+  const int e = batched_find(begins, n, blockIdx.x);
+  const ConvK p = tab[e].k;
+  wgrad_halo_body<BCO>(p, tab[e].dw, (int)tab[e].per, blockIdx.x - begins[e], smem);
 }
 
 // =====================================================================================
@@ -1999,32 +2043,43 @@ static unsigned wgrad_grid(const ConvK& k) {
 }
 
 
-template <int BCO>
-static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
+static bool wgrad_pointwise(const ConvK& k) {
+  return k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 && (k.pd | k.ph | k.pw) == 0 &&
+         (k.ud | k.uh | k.uw) == 0;
+}
+
+// work grid of the DMA filter gradient: k-column tiles x filter-row tiles x pixel splits.  Pixel splits: fill the chip
+// (`target` workgroups) but keep >= min_steps steps of 64 pixels per workgroup so that the pipeline fill and the float
+// atomics of the partial tile are amortised.  Returns the pixel rows per split.
+static long long wgrad_dma_geometry(const ConvK& k, int BCO, int target, ConvK* kk, int default_min_steps = 4) {
   constexpr int PX = 64;
   const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
-  // pixel splits: fill the chip (~768 workgroups) but keep >= g_tuning[1] steps per workgroup so that the
-  // pipeline fill and the float atomics of the partial tile are amortised
-  const int target = g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768;
   long long want = target / ((long long)gx * gy);
   if (want < 1) want = 1;
   long long steps = (k.M + PX - 1) / PX;
-  const int min_steps = g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] : 4;
+  const int min_steps = g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] : default_min_steps;
   if (want > (steps + min_steps - 1) / min_steps) want = (steps + min_steps - 1) / min_steps;
   if (want < 1) want = 1;
   if ((k.xcd_swizzle & 2) && want >= 6) want = (want + 4) / 8 * 8;        // whole pixel splits per XCD: balance the 8 XCDs
   long long steps_per = (steps + want - 1) / want;
   const long long rows_per = steps_per * PX;
   const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);
+  *kk = k;
+  kk->wg_gx = (int)gx; kk->wg_gy = (int)gy; kk->wg_gz = (int)gz;
+  return rows_per;
+}
+
+template <int BCO>
+static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
+  const int target = g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768;
+  ConvK kk;
+  const long long rows_per = wgrad_dma_geometry(k, BCO, target, &kk);
   if (k.pro_a == nullptr && k.skip == nullptr) {
-    ConvK kk = k;
-    kk.wg_gx = (int)gx; kk.wg_gy = (int)gy; kk.wg_gz = (int)gz;
-    const bool pw = k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 && (k.pd | k.ph | k.pw) == 0 &&
-                    (k.ud | k.uh | k.uw) == 0;
-    if (pw) HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, true>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
+    if (wgrad_pointwise(k)) HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, true>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
     else HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, false>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
   } else
-    HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3(gx, gy, gz), dim3(256), 0, s, k, dw, rows_per);
+    HDU_LAUNCH((conv_wgrad_tr_kernel<BCO>), dim3((unsigned)kk.wg_gx, (unsigned)kk.wg_gy, (unsigned)kk.wg_gz), dim3(256), 0, s,
+               k, dw, rows_per);
 }
 
 static bool wgrad_halo_ok(const ConvK& k) {
@@ -2033,20 +2088,28 @@ static bool wgrad_halo_ok(const ConvK& k) {
          k.Di == 1 && k.Cin % 32 == 0 && k.We >= 32;
 }
 
-template <int BCO>
-static void launch_wgrad_halo(const ConvK& k, float* dw, hipStream_t s) {
+// work grid of the halo-tile filter gradient: 32-channel chunks x filter-row tiles x splits of the spatial tiles
+// (>= 2 tiles per workgroup).  Returns the tiles per split.
+static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk) {
   const int tiles = k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32);
   const unsigned gx = (unsigned)(k.Cin / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
-  const int target = g_tuning[HDU_TUNE_HALO_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_HALO_TARGET_WGS] : 512;
   int want = target / (int)(gx * gy);
   if (want < 1) want = 1;
-  if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;      // >= 2 tiles per workgroup
+  if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;
   if (want < 1) want = 1;
   if ((k.xcd_swizzle & 2) && want >= 6) want = (want + 4) / 8 * 8;
   const int per = (tiles + want - 1) / want;
   const unsigned gz = (unsigned)((tiles + per - 1) / per);
-  ConvK kk = k;
-  kk.wg_gx = (int)gx; kk.wg_gy = (int)gy; kk.wg_gz = (int)gz;
+  *kk = k;
+  kk->wg_gx = (int)gx; kk->wg_gy = (int)gy; kk->wg_gz = (int)gz;
+  return per;
+}
+
+template <int BCO>
+static void launch_wgrad_halo(const ConvK& k, float* dw, hipStream_t s) {
+  const int target = g_tuning[HDU_TUNE_HALO_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_HALO_TARGET_WGS] : 512;
+  ConvK kk;
+  const int per = wgrad_halo_geometry(k, BCO, target, &kk);
   HDU_LAUNCH((conv_wgrad_halo_kernel<BCO>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, per);
 }
 
@@ -2079,6 +2142,55 @@ extern "C" int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream) {
   if (d->dtype == HDU_BF16) dispatch_wgrad<bf16_t>(k, dw, (hipStream_t)stream);
   else dispatch_wgrad<float>(k, dw, (hipStream_t)stream);
   return hdu_check_launch("conv_wgrad");
+}
+
+// ---- batched filter gradients (see conv_wgrad_*_batched_kernel).  Variant id = kernel family of an entry:
+// 0..5 DMA form <BCO, PW> = (64|48|32) x (false|true); 8..10 halo-tile form <64|48|32>.
+extern "C" size_t hdu_wgrad_plan_entry_bytes(void) { return sizeof(WgradEntry); }
+
+extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, void* entry, int* variant,
+                                   uint32_t* nblocks) {
+  if (!d || !dw || !entry || !variant || !nblocks) return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_fill: null pointer");
+  ConvK k;
+  if (int e = fill_convk(d, &k, true)) return e;
+  if (d->dtype != HDU_BF16 || k.pro_a != nullptr || k.skip != nullptr || k.M == 0 || !d->y || (uintptr_t)d->y % 16)
+    return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_fill: only bf16 layers with materialised inputs (and a 16-byte aligned dy) can be batched");
+  WgradEntry* e = (WgradEntry*)entry;
+  const int best = choose_wgrad(k);
+  const int bi = best == 64 ? 0 : (best == 48 ? 1 : 2);
+  if (wgrad_halo_ok(k)) {
+    const int target = target_wgs > 0 ? target_wgs : (g_tuning[HDU_TUNE_HALO_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_HALO_TARGET_WGS] : 512);
+    e->per = wgrad_halo_geometry(k, best, target, &e->k);
+    *variant = 8 + bi;
+  } else {
+    const int target = target_wgs > 0 ? target_wgs : (g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768);
+    e->per = wgrad_dma_geometry(k, best, target, &e->k, 8);   // batched: other layers fill the chip, fewer atomics win (swept)
+    *variant = bi * 2 + (wgrad_pointwise(k) ? 1 : 0);
+  }
+  e->dw = dw;
+  *nblocks = wgrad_grid(e->k);
+  return 0;
+}
+
+extern "C" int hdu_wgrad_plan_run(int variant, const void* dev_entries, const uint32_t* dev_begins, int n,
+                                  uint32_t total_blocks, void* stream) {
+  if (!dev_entries || !dev_begins || n <= 0 || total_blocks == 0) return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_run: bad args");
+  const WgradEntry* tab = (const WgradEntry*)dev_entries;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(total_blocks), b(256);
+  switch (variant) {
+    case 0: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<64, false>), g, b, 0, s, tab, dev_begins, n); break;
+    case 1: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<64, true>), g, b, 0, s, tab, dev_begins, n); break;
+    case 2: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<48, false>), g, b, 0, s, tab, dev_begins, n); break;
+    case 3: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<48, true>), g, b, 0, s, tab, dev_begins, n); break;
+    case 4: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<32, false>), g, b, 0, s, tab, dev_begins, n); break;
+    case 5: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<32, true>), g, b, 0, s, tab, dev_begins, n); break;
+    case 8: HDU_LAUNCH((conv_wgrad_halo_batched_kernel<64>), g, b, 0, s, tab, dev_begins, n); break;
+    case 9: HDU_LAUNCH((conv_wgrad_halo_batched_kernel<48>), g, b, 0, s, tab, dev_begins, n); break;
+    case 10: HDU_LAUNCH((conv_wgrad_halo_batched_kernel<32>), g, b, 0, s, tab, dev_begins, n); break;
+    default: return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_run: unknown variant");
+  }
+  return hdu_check_launch("wgrad_plan_run");
 }
 
 extern "C" int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream) {

@@ -142,6 +142,10 @@ class Ctx:
         # BN fold inside the materialise launch (hdu_materialize_bn): saves 82 tiny launches per step but makes every
         # workgroup of 161 big launches derive its coefficients from six vectors -- measured 296 vs 310 slices/s: off
         self.fuse_fold = os.environ.get("HDU_FUSE_FOLD", "0") == "1"
+        # filter gradients deferred to the end of the backward pass and run as ONE launch per kernel family
+        # (ops.WgradPlan); bf16 + materialised inputs only; off under depth sharding / bucketed data parallelism
+        self.batch_wgrad = os.environ.get("HDU_BATCH_WGRAD", "1") == "1"
+        self.wgrad_plan = None
         # 0 = off, 1 = every layer, 2 = only layers with <= 16384 output pixels (latency-bound on their own)
         self.overlap_wgrad = int(os.environ.get("HDU_OVERLAP_WGRAD", "0"))
         self._side = None
@@ -202,7 +206,31 @@ class Ctx:
         for cv in self.convs:
             cv.bind()
         self._build_prep_table()
+        self._build_wgrad_plan()
         self.finalized = True
+
+    def _build_wgrad_plan(self):
+        self.wgrad_plan = None
+        for cv in self.convs:
+            cv.in_plan = False
+        if not (self.batch_wgrad and self.dtype == HDU_BF16 and self.grad_enabled and self.shard is None
+                and not self.overlap_wgrad):
+            return
+        plan = ops.WgradPlan(int(os.environ.get("HDU_BATCH_WGRAD_TARGET", "0")))
+        for cv in self.convs:
+            if cv.trainable and cv.xin is not None and cv.out.root.needs_grad:
+                plan.add(ops.conv_desc(cv.xin.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.conv_up), cv.kernel.grad)
+                cv.in_plan = True
+        if len(plan):
+            plan.finalize()
+            self.wgrad_plan = plan
+
+    def set_batch_wgrad(self, on):
+        """(re)build or drop the deferred filter-gradient plan (dropped e.g. for bucketed data parallelism, where a
+        gradient bucket must be complete when its backward segment ends)"""
+        self.batch_wgrad = on
+        if self.finalized:
+            self._build_wgrad_plan()
 
     def init_weights(self, seed):
         """Keras initialisers (K.initializers.py): glorot_uniform for convs (:332), 'normal' = RandomNormal(0.05)
@@ -314,6 +342,8 @@ class Ctx:
         order = list(reversed(self.bwd))
         for f in order[lo:hi]:
             f()
+        if hi == len(self.bwd) and self.wgrad_plan is not None:
+            self.wgrad_plan.run()
         self.join_wgrad()
 
     def grad_buckets(self, fractions):
@@ -595,7 +625,10 @@ class ConvLayer:
             return
         dy = out.grad
         x = self.x.act
-        if self.trainable:
+        if self.trainable and getattr(self, "in_plan", False):
+            if self.bias is not None:
+                ops.colsum(dy, self.bias.grad, ctx.ws)
+        elif self.trainable:
             if self.xin is not None:
                 d = ops.conv_desc(self.xin.act, self.wf_ptr, dy, self.K, self.stride, self.pad, self.conv_up)
             else:

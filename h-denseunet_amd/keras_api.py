@@ -158,6 +158,8 @@ class Model:
         self._allreduce = allreduce
         self._allreduce_async = allreduce_async
         self._buckets = self.ctx.grad_buckets(bucket_fractions) if allreduce_async is not None else None
+        if self._buckets is not None:
+            self.ctx.set_batch_wgrad(False)   # a bucket's gradients must be final when its backward segment ends
         self.loss_layer.global_scale = 1.0 / world_size
 
     def _step_head(self):

@@ -121,6 +121,53 @@ def conv_wgrad(d, dw):
     check(_l.get().hdu_conv_wgrad(ctypes.byref(d), fptr(dw), stream()), "hdu_conv_wgrad")
 
 
+class WgradPlan:
+    """Deferred, batched filter gradients (hdu_wgrad_plan_*): add(desc, dw) for every layer at build time, run() once
+    per backward pass.  One launch per kernel family; tables live in device memory (uploaded once)."""
+
+    def __init__(self, target_wgs=0):
+        self.target = target_wgs
+        self.by_variant = {}
+        self.tables = None
+        self.keep = []            # descriptors (and the tensors they point to) must outlive the plan
+
+    def add(self, d, dw):
+        lib = _l.get()
+        nb = lib.hdu_wgrad_plan_entry_bytes()
+        ent = (ctypes.c_ubyte * nb)()
+        variant, nblk = ctypes.c_int(0), ctypes.c_uint32(0)
+        check(lib.hdu_wgrad_plan_fill(ctypes.byref(d), fptr(dw), self.target, ctypes.cast(ent, ctypes.c_void_p),
+                                      ctypes.byref(variant), ctypes.byref(nblk)), "hdu_wgrad_plan_fill")
+        self.by_variant.setdefault(variant.value, []).append((bytes(ent), nblk.value))
+        self.keep.append((d, dw))
+        self.tables = None
+
+    def __len__(self):
+        return sum(len(v) for v in self.by_variant.values())
+
+    def finalize(self):
+        import numpy as np
+        self.tables = []
+        for variant, ents in sorted(self.by_variant.items()):
+            raw = np.frombuffer(b"".join(e for e, _ in ents), dtype=np.uint8).copy()
+            begins = np.zeros(len(ents), dtype=np.uint32)
+            tot = 0
+            for i, (_, nb) in enumerate(ents):
+                begins[i] = tot
+                tot += nb
+            assert tot < 2 ** 31
+            self.tables.append((variant, torch.from_numpy(raw).to(device()),
+                                torch.from_numpy(begins.view(np.int32)).to(device()), len(ents), tot))
+
+    def run(self):
+        if self.tables is None:
+            self.finalize()
+        lib = _l.get()
+        for variant, tab, begins, n, tot in self.tables:
+            check(lib.hdu_wgrad_plan_run(variant, ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(begins.data_ptr()), n,
+                                         tot, stream()), "hdu_wgrad_plan_run")
+
+
 def conv_dgrad_strided(d):
     check(_l.get().hdu_conv_dgrad_strided(ctypes.byref(d), stream()), "hdu_conv_dgrad_strided")
 

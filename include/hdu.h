@@ -101,6 +101,21 @@ int hdu_conv_fprop(const hdu_conv_desc* d, void* stream);
  * input with the same prologue as the forward (the normalised tensor is never stored). */
 int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream);
 
+/* Batched filter gradients: ONE launch per kernel family covers many layers.  Filter gradients feed nothing but the
+ * optimiser (tf.gradients order is free, K.optimizers.py:168), so a caller may defer them to the end of the backward
+ * pass; layers too small to fill the GPU on their own then run together.  bf16, materialised inputs only.
+ *   hdu_wgrad_plan_entry_bytes(): size of one opaque table entry.
+ *   hdu_wgrad_plan_fill(): fills ONE host-side entry for (desc, dw) as hdu_conv_wgrad(desc, dw) would run it;
+ *     *variant = kernel family of the entry (entries of one family go into one table), *nblocks = workgroups it needs.
+ *     target_wgs <= 0: the single-launch default split.
+ *   hdu_wgrad_plan_run(): dev_entries = the entries of ONE family copied to device memory, dev_begins[i] = first
+ *     workgroup of entry i (exclusive prefix sum of nblocks), total_blocks = their sum.  Same result as calling
+ *     hdu_conv_wgrad per layer (dw += ..., float atomics). */
+size_t hdu_wgrad_plan_entry_bytes(void);
+int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, void* entry, int* variant, uint32_t* nblocks);
+int hdu_wgrad_plan_run(int variant, const void* dev_entries, const uint32_t* dev_begins, int n, uint32_t total_blocks,
+                       void* stream);
+
 /* data-gradient of a strided conv (the 7x7x7 stride-2 stem, needed by hybridnet end2end):
  * dx[n,i,c] (+)= sum_{o,k: o*s+k-p=i} dy[n,o,co]*w[co][k][c].  d->x is the output dx, d->y is dy. */
 int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream);

@@ -174,6 +174,42 @@ def test_conv_wgrad(hdu, cs, dtype):
     assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
 
 
+def test_conv_wgrad_batched_plan(hdu):
+    """hdu_wgrad_plan_*: ONE launch per kernel family over many layers == hdu_conv_wgrad per layer (bf16,
+    materialised inputs: every CONV_CASE without prologue / skip, plus extra 1x1 and 3x3 shapes)"""
+    import ctypes
+    ops = ops_mod()
+    extra = [
+        dict(N=2, D=1, H=16, W=16, Cin=64, Cout=192, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="pw192"),
+        dict(N=1, D=1, H=12, W=33, Cin=136, Cout=192, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=160, ldout=None, id="pw_ragged"),
+        dict(N=2, D=1, H=8, W=32, Cin=64, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=96, id="halo48"),
+        dict(N=1, D=2, H=6, W=6, Cin=16, Cout=32, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="c333"),
+    ]
+    cases = [c for c in CONV_CASES if not c["pro"] and not c["skip"]] + extra
+    plan = ops.WgradPlan()
+    items = []
+    for i, cs in enumerate(cases):
+        b = build_conv_case(ops, cs, BF16, seed=300 + 7 * i)
+        N, Do, Ho, Wo, Cout = b["out_dims"]
+        dya = mkact(ops, rnd((N, Do, Ho, Wo, Cout), 900 + i, 1.0, BF16), BF16, cs["ldout"], 8 if cs["ldout"] else 0)
+        d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"])
+        ref = torch.full(b["w"].shape, 0.25, dtype=torch.float32, device=ops.device())     # dw += ...
+        got = ref.clone()
+        ops.conv_wgrad(d, ref)
+        plan.add(d, got)
+        items.append((cs["id"], ref, got, b, dya))
+    assert len(plan) == len(cases) and len(plan.by_variant) >= 3      # several kernel families in one plan
+    plan.run()
+    for name, ref, got, _, _ in items:
+        scale = float(ref.abs().max())
+        assert scale > 0.3
+        # identical tiles and splits; only the order of the float atomics differs
+        assert float((ref - got).abs().max()) <= 2e-5 * scale, name
+    plan.run()                                                          # accumulates again
+    for name, ref, got, _, _ in items:
+        assert float((got - 0.25 - 2 * (ref - 0.25)).abs().max()) <= 1e-4 * float(ref.abs().max()), name
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES if c["s"] == (1, 1, 1)])
 def test_conv_dgrad_via_fprop(hdu, cs, dtype, dma_stages):

@@ -126,3 +126,25 @@ def test_hybrid_names_and_b1(emu_lib):
     assert w["3dconv1"][0].shape == (7, 7, 7, 4, 96) and w["fianl_conv"][0].shape == (3, 3, 3, 64, 64)
     with pytest.raises(ValueError):
         U.pkg("hybridnet").dense_rnn_net(U.make_args(2, 32, 8), dtype="f32", nb_layers2d=NB2D, nb_layers3d=NB3D)
+
+
+def test_batched_filter_gradients_equal_per_layer_launches(emu_lib):
+    """bf16 training step: the deferred, batched filter gradients (ops.WgradPlan, one launch per kernel family at the
+    end of the backward pass) give the same flat gradient as one hdu_conv_wgrad launch per layer."""
+    grads = []
+    for batched in (True, False):
+        m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(2, 32), dtype="bf16", nb_layers=NB2D, seed=5)
+        m.ctx.dropout_enabled = False
+        if not batched:
+            m.ctx.set_batch_wgrad(False)
+        assert (m.ctx.wgrad_plan is not None) == batched
+        if batched:
+            assert len(m.ctx.wgrad_plan) >= 20 and sum(cv.in_plan for cv in m.ctx.convs) == len(m.ctx.wgrad_plan)
+        m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True),
+                  loss=[U.pkg("loss").weighted_crossentropy_2ddense])
+        x, y = U.synthetic_batch("2d", 2, 32, None)
+        m.train_on_batch(x, y)
+        grads.append(m.ctx.G[:m.ctx.n_trainable].clone())
+    a, b = grads
+    assert float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
