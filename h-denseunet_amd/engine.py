@@ -218,9 +218,16 @@ class Ctx:
             return
         plan = ops.WgradPlan(int(os.environ.get("HDU_BATCH_WGRAD_TARGET", "0")))
         for cv in self.convs:
-            if cv.trainable and cv.xin is not None and cv.out.root.needs_grad:
-                plan.add(ops.conv_desc(cv.xin.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.conv_up), cv.kernel.grad)
-                cv.in_plan = True
+            if not (cv.trainable and cv.out.root.needs_grad):
+                continue
+            if cv.xin is not None:          # materialised input
+                d = ops.conv_desc(cv.xin.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.conv_up)
+            elif cv.bn is None and cv.skip is None:      # the conv reads its producer directly (stems, 1x1 heads)
+                d = ops.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up)
+            else:
+                continue                    # fused prologue: per-layer launch
+            plan.add(d, cv.kernel.grad)
+            cv.in_plan = True
         if len(plan):
             plan.finalize()
             self.wgrad_plan = plan
