@@ -21,9 +21,9 @@ def main():
     par, ka = U.pkg("parallel"), U.pkg("keras_api")
     sh = par.depth_shard_info("gloo")
     rank, world = sh.rank, sh.world
-    H, D = int(os.environ.get("SHARD_TEST_H", "32")), 8 * world
+    H, D = int(os.environ.get("SHARD_TEST_H", "32")), int(os.environ.get("SHARD_TEST_DL", "8")) * world
     Dl = D // world
-    nb = (1, 1, 2, 1)
+    nb = (1, 1, 1, 1)
     rng = np.random.default_rng(5)
     vol = rng.normal(0, 50, (1, H, H, D, 4)).astype(np.float32)
     lab = rng.integers(0, 3, (1, H, H, D, 1))
