@@ -48,3 +48,52 @@ def predict_tumor_inwindow(model, imgs_test, num, mini, maxi, args):
     out = np.zeros((x, y, z, num), np.float32)
     out[:img_deps, :img_rows] = score.permute(1, 2, 0, 3).cpu().numpy()
     return out[:, :, :, num - 2], out[:, :, :, num - 1]
+
+
+def liver_window_from_mask(mask):
+    """test.py:57-62: bounding box (mini, maxi) of the dilated liver mask (labels 1 and 2 merged) that
+    `predict_tumor_inwindow` sweeps; returns (dilated mask, mini, maxi)."""
+    from scipy import ndimage
+    m = np.array(mask, copy=True)
+    m[m == 2] = 1
+    m = ndimage.binary_dilation(m, iterations=1).astype(m.dtype)
+    index = np.where(m == 1)
+    if index[0].size == 0:
+        raise ValueError("empty liver mask")
+    return m, np.min(index, axis=-1), np.max(index, axis=-1)
+
+
+def _largest_component(binary):
+    """skimage.measure.label(..., return_num=True) + regionprops areas + `box.index(max(box)) + 1` (test.py:84-92):
+    full connectivity (skimage's default for label is connectivity = ndim), first label wins a tie"""
+    from scipy import ndimage
+    lab, num = ndimage.label(binary, structure=np.ones((3,) * binary.ndim, dtype=bool))
+    if num == 0:
+        raise ValueError("no foreground component (the reference raises on max([]) here, test.py:90)")
+    areas = np.bincount(lab.ravel(), minlength=num + 1)[1:]
+    keep = int(np.argmax(areas)) + 1          # argmax returns the FIRST maximum, like list.index(max(...))
+    return (lab == keep).astype(lab.dtype)
+
+
+def segment_liver_tumor(score1, score2, mask, thres_liver=0.5, thres_tumor=0.8):
+    """Host-side post-processing of test.py:70-112: threshold the averaged scores,
+    keep the largest liver component, restrict tumours to the (dilated, largest, hole-filled) coarse liver mask, fill
+    holes, and return the uint8 label volume {0 background, 1 liver, 2 tumour} that the reference saves as NIfTI.
+    `mask` is the ALREADY dilated coarse liver mask of liver_window_from_mask (test.py dilates it a second time
+    before labelling, :95 -- reproduced).  scipy.ndimage replaces skimage.measure (same connectivity and tie rule)."""
+    from scipy import ndimage
+    result1 = np.array(score1, dtype=np.float64, copy=True)
+    result2 = np.array(score2, dtype=np.float64, copy=True)
+    result1 = (result1 >= thres_liver).astype(np.float64)
+    result2 = (result2 >= thres_tumor).astype(np.float64)
+    result1[result2 == 1] = 1
+    segmask = result2
+    liver_res = _largest_component(result1)
+    m = ndimage.binary_dilation(mask, iterations=1).astype(np.asarray(mask).dtype)
+    liver_labels = _largest_component(m)
+    liver_labels = ndimage.binary_fill_holes(liver_labels).astype(int)
+    segmask = segmask * liver_labels
+    segmask = ndimage.binary_fill_holes(segmask).astype(int).astype(np.uint8)
+    liver_res = ndimage.binary_fill_holes(liver_res.astype(np.uint8)).astype(int)
+    liver_res[segmask == 1] = 2
+    return liver_res.astype(np.uint8)
