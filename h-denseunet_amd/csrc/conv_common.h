@@ -27,6 +27,11 @@ struct ConvK {
   int wg_gx, wg_gy, wg_gz;      // filter-gradient work grid (k-column tiles, filter-row tiles, pixel splits); 1-D launch
   int debug_flags;            // developer experiments only (HDU_TUNE_DEBUG): 1 = skip operand DMA, 2 = skip MFMA
   int vec_out;                // output rows are 16-byte addressable (DMA kernels' vector epilogue)
+  // optional per-channel statistics of the OUTPUT, accumulated by the epilogue (saves the separate reduction pass over
+  // a tensor that is still in LDS): partial[slot][0][c] += sum(y - shift[c]), partial[slot][1][c] += sum((y - shift[c])^2)
+  float* stats_partial;       // [stats_slots][2][Cout] float, zeroed by the caller; NULL = off
+  const float* stats_shift;   // [Cout] shift against E[x^2]-E[x]^2 cancellation (any value near the mean)
+  int stats_slots;
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][128 B] LDS tile.

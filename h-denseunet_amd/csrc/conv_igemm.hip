@@ -688,6 +688,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
     }
 }
 
+// ---- per-channel moments of the output tile while it is still staged in LDS (ConvK::stats_partial).  Called by all
+// 256 threads after the tile stores; reads the tile only.  Thread = (16-byte column chunk, row lane): the 16 row lanes of
+// a chunk are 16 ADJACENT lanes of a wave, each sums rows rl, rl+16, ... in registers, a 4-step xor butterfly adds the 16
+// lanes, and lane 0 of the group adds the chunk's 2*CH totals to this workgroup's slot row with global float atomics
+// (no LDS scratch, no extra barrier; LDS float atomics on a shared column were measured far slower).
+template <typename T, int BM, int BN, int ROWB, typename RowValid>
+__device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n0, int tid, unsigned slot, RowValid valid) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int NCC = BN / CH;
+  float* dst = p.stats_partial + (long long)(slot % (unsigned)p.stats_slots) * 2 * p.Cout;
+  const int rl = tid & 15;
+#pragma unroll
+  for (int it = 0; it < (NCC + 15) / 16; ++it) {      // every lane takes every trip (the butterfly is wave-wide)
+    const int cc = (tid >> 4) + it * 16;
+    const int nbase = n0 + cc * CH;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (cc < NCC && nbase < p.Cout) {
+      float sh[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) sh[j] = p.stats_shift[nbase + j];
+      for (int row = rl; row < BM; row += 16) {
+        if (!valid(row)) continue;
+        float f[CH];
+        Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float d = f[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], m); s2[j] += __shfl_xor(s2[j], m); }
+    }
+    if (rl == 0 && cc < NCC && nbase < p.Cout) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        atomicAdd(dst + nbase + j, s1[j]);
+        atomicAdd(dst + p.Cout + nbase + j, s2[j]);
+      }
+    }
+  }
+}
+
 // ---- epilogue shared by the DMA kernels: bias / dropout in registers, then the tile goes through LDS so that every
 // lane writes (and, in accumulate mode, reads) one full 16-byte chunk of a row: 8 lanes cover a 128-byte line.
 template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int SMEM>
@@ -740,6 +785,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
     }
     *(u32x4*)dst = v;
   }
+  if (p.stats_partial)
+    epilogue_stats<T, BM, BN, ROWB>(p, smem, n0, tid, blockIdx.x, [&](int row) { return m0 + row < p.M; });
 }
 
 // =====================================================================================
@@ -1701,6 +1748,9 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
     }
     *(u32x4*)dst = v;
   }
+  if (p.stats_partial)
+    epilogue_stats<T, BM, BN, ROWB>(p, smem, n0, tid, blockIdx.x,
+                                    [&](int row) { return y0 + (row >> 5) < H && x0 + (row & 31) < W; });
 }
 
 // =====================================================================================
@@ -1883,6 +1933,11 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   }
   k->drop_seed = d->drop_seed;
   k->drop_seed_dev = d->drop_seed_dev;
+  k->stats_partial = wgrad ? nullptr : d->stats_partial;
+  k->stats_shift = d->stats_shift;
+  k->stats_slots = d->stats_slots;
+  if (k->stats_partial && (!k->stats_shift || k->stats_slots <= 0 || d->accumulate))
+    return hdu_set_error(HDU_ERR_ARG, "conv: epilogue statistics need stats_shift, stats_slots > 0 and accumulate == 0");
   k->xcd_swizzle = g_tuning[HDU_TUNE_XCD_SWIZZLE];
   k->vec_out = 1;
   k->debug_flags = g_tuning[HDU_TUNE_DEBUG];

@@ -12,6 +12,7 @@ enum { ROW_UNROLL = 4 };   // rows of loads each thread of a row kernel keeps in
 // optional per-channel epilogue of the finalize kernel (saves the separate bn_fold / bn_bwd_coef launches)
 struct FinK {
   int kind;                 // 0 none, 1 BN fold (after RED_STATS), 2 BN backward coefficients (after RED_BNBWD)
+  const float* shift_f32;   // RED_STATS: float shift array used by a conv epilogue (else the shift is row 0 of x)
   const float* gamma; const float* beta; const float* sgamma; const float* sbeta;
   float eps, momentum, invM;
   int batch_stats;
@@ -70,7 +71,7 @@ template <typename T, int MODE>
 __device__ __forceinline__ void finalize_channel(int c, double a1, double a2, long long M, const void* x, float* o1,
                                                  float* o2, const FinK& fin) {
   if (MODE == 0) {   // RED_STATS
-    const double shift = (double)Chunk<T>::load1((const T*)x + c);
+    const double shift = fin.shift_f32 ? (double)fin.shift_f32[c] : (double)Chunk<T>::load1((const T*)x + c);
     const double m1 = a1 / (double)M;
     double var = a2 / (double)M - m1 * m1;
     if (var < 0.0) var = 0.0;
@@ -388,6 +389,23 @@ extern "C" int hdu_bn_stats_fold(int dtype, const void* x, int64_t ldx, int64_t 
   f.kind = 1; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.sbeta = sbeta; f.eps = eps; f.momentum = momentum;
   f.a = a; f.b = b; f.rstd = rstd; f.mov_mean = mov_mean; f.mov_var = mov_var;
   return reduce_entry<RED_STATS>(dtype, k, mean, var, ws, ws_bytes, (hipStream_t)stream, "bn_stats_fold", f);
+}
+
+extern "C" int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M, int C, const float* shift, float* mean,
+                                     float* var, const float* gamma, const float* beta, float eps, const float* sgamma,
+                                     const float* sbeta, float* a, float* b, float* rstd, float* mov_mean, float* mov_var,
+                                     float momentum, void* stream) {
+  if (!partial || slots <= 0 || M <= 0 || C <= 0 || !shift || !mean || !var || ((a == nullptr) != (b == nullptr)))
+    return hdu_set_error(HDU_ERR_ARG, "bn_stats_finalize: bad args");
+  FinK f{};
+  f.shift_f32 = shift;
+  if (a) {
+    f.kind = 1; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.sbeta = sbeta; f.eps = eps; f.momentum = momentum;
+    f.a = a; f.b = b; f.rstd = rstd; f.mov_mean = mov_mean; f.mov_var = mov_var;
+  }
+  HDU_LAUNCH((reduce_finalize_kernel<float, RED_STATS>), dim3((unsigned)((C + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+             partial, slots, C, (long long)M, (const void*)nullptr, mean, var, f);
+  return hdu_check_launch("bn_stats_finalize");
 }
 
 extern "C" int hdu_bn_bwd_reduce_coef(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,

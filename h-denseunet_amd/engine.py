@@ -146,6 +146,11 @@ class Ctx:
         # (ops.WgradPlan); bf16 + materialised inputs only; off under depth sharding / bucketed data parallelism
         self.batch_wgrad = os.environ.get("HDU_BATCH_WGRAD", "1") == "1"
         self.wgrad_plan = None
+        # batch statistics of a conv output taken in the conv's epilogue (hdu_conv_desc.stats_*) instead of a separate
+        # reduction pass; the StatsOp then only runs hdu_bn_stats_finalize over the 32 slot rows
+        self.epilogue_stats = os.environ.get("HDU_EPILOGUE_STATS", "1") == "1"
+        self.stats_sinks = []
+        self.stats_acc = None
         # 0 = off, 1 = every layer, 2 = only layers with <= 16384 output pixels (latency-bound on their own)
         self.overlap_wgrad = int(os.environ.get("HDU_OVERLAP_WGRAD", "0"))
         self._side = None
@@ -203,6 +208,11 @@ class Ctx:
                 tot += cv.kernel.numel
         self.Wc = torch.zeros(max(tot, 8), dtype=tdt, device=self.dev)
         self.init_weights(seed)
+        tot = 0
+        for st in self.stats_sinks:
+            st.acc_off = tot
+            tot += st.SLOTS * 2 * st.var.C
+        self.stats_acc = torch.zeros(tot, dtype=torch.float32, device=self.dev) if tot else None
         for cv in self.convs:
             cv.bind()
         self._build_prep_table()
@@ -231,6 +241,11 @@ class Ctx:
         if len(plan):
             plan.finalize()
             self.wgrad_plan = plan
+
+    def unprime_stats(self):
+        """new weights: the stored means are no longer a good shift for the one-pass epilogue moments"""
+        for st in self.stats_sinks:
+            st.primed = False
 
     def set_batch_wgrad(self, on):
         """(re)build or drop the deferred filter-gradient plan (dropped e.g. for bucketed data parallelism, where a
@@ -336,6 +351,8 @@ class Ctx:
 
     def run_forward(self):
         self.pass_id += 1
+        if self.learning_phase == 1 and self.stats_acc is not None:
+            self.stats_acc.zero_()          # ONE memset for the epilogue-statistics accumulators of every layer
         for f in self.fwd:
             f()
 
@@ -594,6 +611,21 @@ class ConvLayer:
         if self.dropout > 0:
             self.d_f_drop = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu,
                                           bias, False, 1.0 - self.dropout, self.drop_seed, ctx.seed_dev)
+        # training-phase variants that also accumulate the output's moments for the StatsOp that follows this conv
+        self.d_f_st = self.d_f_drop_st = None
+        sink = getattr(self, "stats_sink", None)
+        if sink is not None:
+            mean, _ = sink.var.stats()
+            part = ctypes.c_void_p(ctx.stats_acc.data_ptr() + 4 * sink.acc_off)
+
+            def with_stats(d):
+                if d is None:
+                    return None
+                c = type(d)()
+                ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(d))
+                c.stats_partial, c.stats_shift, c.stats_slots = part, ctypes.c_void_p(mean.data_ptr()), sink.SLOTS
+                return c
+            self.d_f_st, self.d_f_drop_st = with_stats(self.d_f), with_stats(self.d_f_drop)
 
     def prep(self):
         ctx = self.ctx
@@ -620,10 +652,13 @@ class ConvLayer:
                                 skip, dst)
             if self.halo:
                 _sh.halo_exchange(ctx.shard, self.xin.act, self.halo)
+        # epilogue statistics once the sink has a usable shift (the previous pass's mean); the first training pass
+        # after build / after new weights uses the two-pass reduction (shift = a sample of the tensor itself)
+        st = ctx.learning_phase == 1 and self.d_f_st is not None and self.stats_sink.primed
         if self.d_f_drop is not None and ctx.learning_phase == 1 and ctx.dropout_enabled:
-            ops.conv_fprop(self.d_f_drop)
+            ops.conv_fprop(self.d_f_drop_st if st else self.d_f_drop)
         else:
-            ops.conv_fprop(self.d_f)
+            ops.conv_fprop(self.d_f_st if st else self.d_f)
 
     def backward(self):
         ctx = self.ctx
@@ -727,12 +762,26 @@ class StatsOp:
     """tf.nn.moments of a freshly written tensor / slab, once, shared by every consumer BN.  When the tensor has a
     single batch-stat consumer BN over exactly these channels, `fuse(bn)` folds it in the same two launches."""
 
+    SLOTS = 32     # slot rows a conv epilogue spreads its float atomics over (workgroup % SLOTS)
+
     def __init__(self, ctx, var):
         self.ctx, self.var = ctx, var
         self.fused = None
         self.sync_buf = ctx.fvec(2 * var.C)
         ctx.need_ws(var.act.M, var.C)
         var.stats()
+        # produced by the conv that was just built?  then its epilogue takes the moments (no reduction pass)
+        self.producer = None
+        prod = ctx.convs[-1] if ctx.convs else None
+        sharded = ctx.shard is not None and ctx.shard.world > 1
+        if (ctx.epilogue_stats and not sharded and prod is not None and ctx.fwd and ctx.fwd[-1] == prod.forward
+                and prod.out.root is var.root and prod.out.c0 == var.c0 and prod.out.C == var.C
+                and getattr(prod, "stats_sink", None) is None):
+            self.producer = prod
+            prod.stats_sink = self
+            self.acc_off = None
+            self.primed = False
+            ctx.stats_sinks.append(self)
         ctx.fwd.append(self.forward)
 
     def fuse(self, bn):
@@ -751,14 +800,29 @@ class StatsOp:
             ops.bn_stats(self.var.act, mean, var, ctx.ws)
             _sh.sync_stats(ctx.shard, mean, var, self.var.act.M, self.var.act.M * ctx.shard.world, self.sync_buf)
             return
-        if bn is None:
+        fold = None
+        if bn is not None:
+            fold = (bn.gamma.data, bn.beta.data, bn.eps, bn.sg.data if bn.sg else None, bn.sb.data if bn.sb else None,
+                    bn.a, bn.b, bn.rstd, bn.mm.data, bn.mv.data, bn.momentum)
+        if self.producer is not None and not self.primed:
+            self.primed = True              # this pass: ordinary reduction below; its mean is the next pass's shift
+            if bn is None:
+                ops.bn_stats(self.var.act, mean, var, ctx.ws)
+                return
+            ops.bn_stats_fold(self.var.act, mean, var, *fold, ctx.ws)
+        elif self.producer is not None:
+            # the conv epilogue left sum(y - shift), sum((y - shift)^2) in the slot rows; shift = last step's mean
+            n = self.SLOTS * 2 * self.var.C
+            ops.bn_stats_finalize(ctx.stats_acc[self.acc_off:self.acc_off + n], self.SLOTS, self.var.act.M, self.var.C,
+                                  mean, mean, var, fold)
+        elif bn is None:
             ops.bn_stats(self.var.act, mean, var, ctx.ws)
             return
-        ops.bn_stats_fold(self.var.act, mean, var, bn.gamma.data, bn.beta.data, bn.eps,
-                          bn.sg.data if bn.sg else None, bn.sb.data if bn.sb else None, bn.a, bn.b, bn.rstd,
-                          bn.mm.data, bn.mv.data, bn.momentum, ctx.ws)
-        bn.mean_used = mean
-        bn.folded_pass = ctx.pass_id
+        else:
+            ops.bn_stats_fold(self.var.act, mean, var, *fold, ctx.ws)
+        if bn is not None:
+            bn.mean_used = mean
+            bn.folded_pass = ctx.pass_id
 
 
 class MaterializeLayer:

@@ -338,6 +338,9 @@ class Model:
                     raise ValueError("no layer named %r in model %s" % (n, self.name))
                 continue
             self.ctx.set_layer_weights(n, arrs)
+        self.ctx.unprime_stats()
+        if self._graph is not None:
+            self._graph = None      # a captured step contains the primed (epilogue-statistics) launch list
 
     def get_grads_dict(self):
         return OrderedDict((n, self.ctx.get_layer_grads(n)) for n in self.ctx.by_layer)

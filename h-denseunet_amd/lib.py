@@ -38,6 +38,9 @@ class ConvDesc(ctypes.Structure):
         ("drop_keep", c_f),
         ("drop_seed", c_u32),
         ("drop_seed_dev", c_p),
+        ("stats_partial", c_p),
+        ("stats_shift", c_p),
+        ("stats_slots", c_int),
     ]
 
 
@@ -76,6 +79,8 @@ _SIGS = {
     "hdu_wgrad_plan_entry_bytes": (c_sz, []),
     "hdu_wgrad_plan_fill": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_int, c_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_uint32)]),
     "hdu_wgrad_plan_run": (c_int, [c_int, c_p, c_p, c_int, ctypes.c_uint32, c_p]),
+    "hdu_bn_stats_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      c_f, c_p]),
     "hdu_materialize_bn": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
                                    c_p, c_p, c_p, c_p, c_p, c_f, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),

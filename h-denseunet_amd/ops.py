@@ -265,6 +265,15 @@ def materialize(x, a, b, relu, up, skip, out):
                                    skip.ld if skip is not None else 0, out.ptr, out.ld, stream()), "hdu_materialize")
 
 
+def bn_stats_finalize(partial, slots, M, C, shift, mean, var, fold=None):
+    """fold = (gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum) or None"""
+    g, be, eps, sg, sb, a, b, r, mm, mv, mom = fold if fold is not None else (None, None, 0.0, None, None, None, None,
+                                                                                 None, None, None, 0.0)
+    check(_l.get().hdu_bn_stats_finalize(fptr(partial), slots, M, C, fptr(shift), fptr(mean), fptr(var), fptr(g), fptr(be),
+                                         eps, fptr(sg), fptr(sb), fptr(a), fptr(b), fptr(r), fptr(mm), fptr(mv), mom,
+                                         stream()), "hdu_bn_stats_finalize")
+
+
 def materialize_bn(x, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum, relu, up,
                    skip, out):
     check(_l.get().hdu_materialize_bn(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, fptr(mean), fptr(var), fptr(gamma),

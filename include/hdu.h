@@ -90,6 +90,13 @@ typedef struct hdu_conv_desc {
   uint32_t drop_seed;
   const uint32_t* drop_seed_dev;   /* optional device word added to drop_seed (lets a captured hipGraph
                                       draw a fresh mask per replay) */
+  /* optional (hdu_conv_fprop only): per-channel moments of the stored output, taken in the epilogue while the tile is
+   * still in LDS -- tf.nn.moments of the conv output (TFB:1635) without a second pass over it.
+   * stats_partial[slot][0][c] += sum_m (y[m][c] - stats_shift[c]); [slot][1][c] += sum_m (y - shift)^2, float atomics,
+   * slot = workgroup % stats_slots.  The caller zeroes stats_partial and finishes with hdu_bn_stats_finalize. */
+  float* stats_partial;
+  const float* stats_shift;
+  int stats_slots;
 } hdu_conv_desc;
 
 /* forward conv; also the data-gradient of every stride-1 conv (caller passes dy as x and the
@@ -200,6 +207,14 @@ int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, cons
 int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
                     const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip, void* out,
                     int64_t ldout, void* stream);
+
+/* second half of hdu_bn_stats / hdu_bn_stats_fold when the first half ran in a conv epilogue (stats_partial of
+ * hdu_conv_desc): sums the `slots` partial rows, mean = shift + S1/M, var = S2/M - (S1/M)^2 (biased, as tf.nn.moments),
+ * and -- when a/b are given -- folds the BN(+Scale) and updates the moving statistics exactly like hdu_bn_stats_fold.
+ * `shift` must be the array the epilogue used; it may alias `mean` (each channel is read before it is written). */
+int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M, int C, const float* shift, float* mean, float* var,
+                          const float* gamma, const float* beta, float eps, const float* sgamma, const float* sbeta,
+                          float* a, float* b, float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream);
 
 /* hdu_materialize with the BN(+Scale) fold of hdu_bn_fold done inside the same launch: a/b are derived per thread from
  * (mean, var, gamma, beta, Scale); a, b, rstd and the moving statistics are ALSO written (first row block) exactly as

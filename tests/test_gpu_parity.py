@@ -18,14 +18,16 @@ def _pair(kind, variant, b, size, cols, dtype):
     return m, P, fwd
 
 
-@pytest.mark.parametrize("kind,variant,b,size,cols", [
-    ("2d", "denseunet", 1, 512, None),          # BASELINE configs[0]: single 512x512 slice
-    ("2d", "densenet", 2, 224, None),
-    ("hybrid", "3dpart", 1, 224, 12),           # configs[2]
-    ("hybrid", "end2end", 1, 224, 12),          # configs[3]
-    ("3d", "3dpart", 1, 224, 12),               # the per-shard network of configs[4] (unsharded)
+@pytest.mark.parametrize("kind,variant,b,size,cols,primed", [
+    ("2d", "denseunet", 1, 512, None, False),          # BASELINE configs[0]: single 512x512 slice
+    ("2d", "denseunet", 1, 512, None, True),           # same, batch statistics taken in the conv epilogues
+    ("2d", "densenet", 2, 224, None, False),
+    ("hybrid", "3dpart", 1, 224, 12, False),           # configs[2]
+    ("hybrid", "end2end", 1, 224, 12, False),          # configs[3]
+    ("hybrid", "end2end", 1, 224, 12, True),
+    ("3d", "3dpart", 1, 224, 12, False),               # the per-shard network of configs[4] (unsharded)
 ])
-def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
+def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols, primed):
     m, P, fwd = _pair(kind, variant, b, size, cols, "f32")
     x, y = U.synthetic_batch(kind, b, size, cols)
     xt = torch.tensor(x)
@@ -40,6 +42,15 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols):
     m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy])
     ref_loss, ref_grads, ref_logits = U.R.train_step(P, fwd, U.loss_fn_for(kind), xt, torch.tensor(y), {})
     w_before = m.get_weights_dict()
+    if primed:
+        # steady-state path: a training-phase forward leaves every layer's batch mean behind (the shift of the one-pass
+        # epilogue moments); weights and moving statistics are put back, so the step below starts from the same state
+        # as the oracle's but runs the primed launch list (what every step after the first runs)
+        assert len(m.ctx.stats_sinks) > 5
+        P0 = m.ctx.P.clone()
+        m.forward_train_mode(x)
+        m.ctx.P.copy_(P0)
+        assert all(s.primed for s in m.ctx.stats_sinks)
     loss = m.train_on_batch(x, y)
     got_l = m._download_logits().cpu().numpy()
     rl = ref_logits.numpy()

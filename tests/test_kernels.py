@@ -174,6 +174,54 @@ def test_conv_wgrad(hdu, cs, dtype):
     assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES
+                                if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "stem7x7s2", "wide_bn128",
+                                               "tile128x128_ragged_m", "halo_tile_ragged_slab", "halo_tile_exact")])
+def test_conv_epilogue_statistics(hdu, cs, dtype):
+    """moments taken in the conv epilogue (hdu_conv_desc.stats_*) + hdu_bn_stats_finalize == hdu_bn_stats_fold on the
+    stored output: same mean / variance / folded a,b / moving statistics, for every kernel family that has the epilogue
+    (VALU prologue form, DMA form, halo-tile form; ragged M / N tiles; slab output)."""
+    import ctypes
+    ops = ops_mod()
+    b = build_conv_case(ops, cs, dtype, seed=40)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    if cs["ldout"]:
+        big = ops.Act.alloc(N, Do, Ho, Wo, cs["ldout"], dtype, zero=True)
+        ya = big.slab(8, Cout)
+    else:
+        ya = ops.Act.alloc(N, Do, Ho, Wo, Cout, dtype)
+    pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+    bias = dev(ops, b["bias"]) if b["bias"] is not None else None
+    slots = 5
+    z = lambda n, v=0.0: torch.full((n,), v, dtype=torch.float32, device=ops.device())
+    partial = z(slots * 2 * Cout)
+    shift = dev(ops, rnd((Cout,), 11, 0.3).float().double())        # any value near the mean works
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), ya, cs["K"], cs["s"], cs["p"], cs["up"], b["sa"], pro,
+                      True, bias, drop_keep=0.8, drop_seed=77)
+    d.stats_partial, d.stats_shift, d.stats_slots = ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(shift.data_ptr()), slots
+    ops.conv_fprop(d)
+    gamma, beta, sg, sb = (dev(ops, (rnd((Cout,), 20 + i, 0.2) + 1.0).float().double()) for i in range(4))
+    outs = []
+    for fused in (True, False):
+        mean, var, a, bb, r = z(Cout), z(Cout), z(Cout), z(Cout), z(Cout)
+        mm, mv = z(Cout, 0.5), z(Cout, 2.0)
+        if fused:
+            mean.copy_(shift)                                           # shift may alias mean
+            ops.bn_stats_finalize(partial, slots, ya.M, Cout, mean, mean, var,
+                                  (gamma, beta, 1.1e-5, sg, sb, a, bb, r, mm, mv, 0.99))
+        else:
+            ws = ops.Workspace(ops.reduce_ws_bytes(ya.M, Cout))
+            ops.bn_stats_fold(ya, mean, var, gamma, beta, 1.1e-5, sg, sb, a, bb, r, mm, mv, 0.99, ws)
+        outs.append([t.cpu().double() for t in (mean, var, a, bb, r, mm, mv)])
+    y = ya.to_torch().cpu()
+    assert float(y.abs().max()) > 0 and float((y == 0).double().mean()) > 0.1      # dropout is part of what is measured
+    names = ("mean", "var", "a", "b", "rstd", "mov_mean", "mov_var")
+    for nme, u, v in zip(names, *outs):
+        tol = 2e-5 * max(1.0, float(v.abs().max()))
+        assert float((u - v).abs().max()) <= tol, (nme, float((u - v).abs().max()))
+
+
 def test_conv_wgrad_batched_plan(hdu):
     """hdu_wgrad_plan_*: ONE launch per kernel family over many layers == hdu_conv_wgrad per layer (bf16,
     materialised inputs: every CONV_CASE without prologue / skip, plus extra 1x1 and 3x3 shapes)"""
