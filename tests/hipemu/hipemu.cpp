@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -138,6 +139,29 @@ const char* wave_exchange(const void* mine, size_t nbytes, size_t* slot_stride) 
 
 void wave_release() { wave_barrier(); }
 
+// fiber stacks are recycled through a process-wide free list: a fresh 256 KB malloc per emulated thread per workgroup is
+// an mmap + page faults + munmap each (measured: more system time than user time for the whole CPU test tier)
+static std::mutex g_stack_mu;
+static std::vector<char*> g_stack_free;
+
+static void acquire_stacks(std::vector<char*>& out, size_t n) {
+  out.clear();
+  {
+    std::lock_guard<std::mutex> lk(g_stack_mu);
+    while (out.size() < n && !g_stack_free.empty()) {
+      out.push_back(g_stack_free.back());
+      g_stack_free.pop_back();
+    }
+  }
+  while (out.size() < n) out.push_back((char*)malloc(kStack));
+}
+
+static void release_stacks(std::vector<char*>& v) {
+  std::lock_guard<std::mutex> lk(g_stack_mu);
+  for (char* p : v) g_stack_free.push_back(p);
+  v.clear();
+}
+
 static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, unsigned bx, unsigned by,
                       unsigned bz, size_t dyn_smem_bytes) {
   const unsigned nthreads = block.x * block.y * block.z;
@@ -149,9 +173,11 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
   std::vector<char> smem(dyn_smem_bytes + 64);
   char* smem_aligned = (char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
   t_run = &run;
+  std::vector<char*> stacks;
+  acquire_stacks(stacks, nthreads);
   for (unsigned t = 0; t < nthreads; ++t) {
     Fiber& f = run.fibers[t];
-    f.stack = (char*)malloc(kStack);
+    f.stack = stacks[t];
     f.ctx.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
     f.ctx.bid = {bx, by, bz};
     f.ctx.bdim = {block.x, block.y, block.z};
@@ -185,7 +211,7 @@ static void run_block(const std::function<void()>& body, dim3 grid, dim3 block, 
       abort();
     }
   }
-  for (auto& f : run.fibers) free(f.stack);
+  release_stacks(stacks);
   t_run = nullptr;
   g_cur = nullptr;
 }

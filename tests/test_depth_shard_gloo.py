@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_depth_shard_world2_gloo(emu_lib):
-    env = dict(os.environ, HIPEMU_THREADS="2", OMP_NUM_THREADS="2")
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)

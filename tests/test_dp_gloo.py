@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_data_parallel_world2_gloo(emu_lib):
-    env = dict(os.environ, HIPEMU_THREADS="2", OMP_NUM_THREADS="2", HDU_DP_BUCKETS="0.3,0.6,0.9")
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", HDU_DP_BUCKETS="0.3,0.6,0.9")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "dp_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
