@@ -317,6 +317,13 @@ class Model:
             hist.history["loss"].append(logs["loss"])
             if verbose:
                 print("Epoch %d/%d - loss: %.4f" % (epoch + 1, epochs, logs["loss"]))
+                # the author's patch to ProgbarLogger.on_epoch_end (K.callbacks.py:28,311-314): the epoch loss is
+                # appended to ./Experiments/history/lossepoch.txt (the scripts create that directory,
+                # train_2ddense.py:190-200); skipped when it does not exist instead of raising
+                hist_dir = os.path.join("Experiments", "history")
+                if os.path.isdir(hist_dir):
+                    with open(os.path.join(hist_dir, "lossepoch.txt"), "a") as f:
+                        f.write("%.4f\n" % logs["loss"])
             for cb in callbacks:
                 if hasattr(cb, "on_epoch_end"):
                     cb.on_epoch_end(epoch, logs)
@@ -407,7 +414,7 @@ class ModelCheckpoint:
         if self.save_best_only and not cur < self.best:
             return
         self.best = min(self.best, cur)
-        path = self.filepath.format(epoch=epoch + 1, **logs)
+        path = self.filepath.format(epoch=epoch, **logs)      # Keras 2.0.8 formats the 0-based epoch (K.callbacks.py:404)
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         self.model.save(path)
 

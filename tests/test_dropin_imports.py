@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_reference_import_lines_and_call_pattern(emu_lib, tmp_path):
+def test_reference_import_lines_and_call_pattern(emu_lib, tmp_path, monkeypatch):
     sys.path.insert(0, os.path.join(ROOT, "compat"))
     try:
         from keras.optimizers import SGD
@@ -34,11 +34,18 @@ def test_reference_import_lines_and_call_pattern(emu_lib, tmp_path):
             while True:
                 yield x, y
 
-        ck = ModelCheckpoint(str(tmp_path / "weights.{epoch:02d}-{loss:.2f}.npz"), monitor="loss", period=1)
-        hist = model.fit_generator(gen(), steps_per_epoch=2, epochs=2, verbose=0, callbacks=[ck], workers=3,
+        # train_2ddense.py:190-210: Experiments/{model,history}, checkpoint name pattern, verbose=1
+        monkeypatch.chdir(tmp_path)
+        os.makedirs("Experiments/model"); os.makedirs("Experiments/history")
+        ck = ModelCheckpoint("Experiments/model/weights.{epoch:02d}-{loss:.2f}.npz", monitor="loss", verbose=1,
+                             save_best_only=False, save_weights_only=False, mode="min", period=1)
+        hist = model.fit_generator(gen(), steps_per_epoch=2, epochs=2, verbose=1, callbacks=[ck], workers=3,
                                    use_multiprocessing=True, max_queue_size=10)
         assert len(hist.history["loss"]) == 2 and hist.history["loss"][1] < hist.history["loss"][0] * 1.5
-        assert len(list(tmp_path.iterdir())) == 2
+        saved = sorted(os.listdir("Experiments/model"))
+        assert len(saved) == 2 and saved[0].startswith("weights.00-") and saved[1].startswith("weights.01-")   # 0-based epoch
+        lines = open("Experiments/history/lossepoch.txt").read().split()       # K.callbacks.py:311-314 (author's patch)
+        assert lines == ["%.4f" % v for v in hist.history["loss"]]
         p = model.predict(x, batch_size=1, verbose=1)
         assert p.shape == (1, 32, 32, 3) and np.isfinite(p).all()
         s = Scale(axis=3, name="conv1_scale")
