@@ -366,15 +366,26 @@ class Model:
     def load_weights(self, filepath, by_name=False, by_gpu=False, two_model=False, by_flag=False):
         """topology.py:2590-2640.  by_name (and the author's by_gpu / two_model loaders, which select an HDF5 group
         and then match by layer name) skip layers absent from the file; the default requires every layer."""
-        z = np.load(filepath, allow_pickle=False)
-        groups = OrderedDict()
-        for k in z.files:
-            if k == "__model_name__":
-                continue
-            n, i = k.rsplit("/", 1)
-            groups.setdefault(n, {})[int(i)] = z[k]
-        d = OrderedDict((n, [g[i] for i in sorted(g)]) for n, g in groups.items())
+        with open(filepath, "rb") as fh:
+            magic = fh.read(8)
         lenient = by_name or by_gpu or two_model
+        if magic == b"\x89HDF\r\n\x1a\n":
+            # a Keras HDF5 file (save_weights / save of the reference, e.g. densenet161_weights_tf.h5, model_best.hdf5):
+            # decoded by the pure-Python reader, same Keras weight shapes / per-layer order as the npz container
+            from . import h5lite
+            d = OrderedDict((n, arrs) for n, arrs in h5lite.read_keras_weights(filepath).items() if arrs)
+            extra = [n for n in d if n not in self.ctx.by_layer]
+            if extra and not lenient:
+                raise ValueError("weights file has layers the model lacks: %s... (use by_name=True)" % extra[:5])
+        else:
+            z = np.load(filepath, allow_pickle=False)
+            groups = OrderedDict()
+            for k in z.files:
+                if k == "__model_name__":
+                    continue
+                n, i = k.rsplit("/", 1)
+                groups.setdefault(n, {})[int(i)] = z[k]
+            d = OrderedDict((n, [g[i] for i in sorted(g)]) for n, g in groups.items())
         if not lenient:
             missing = [n for n in self.ctx.by_layer if n not in d]
             if missing:
