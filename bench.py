@@ -27,11 +27,34 @@ TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 
 
+# HDU_BENCH_DRYRUN=1 (tests/test_bench_flow_gloo.py only): the same control flow on CPU -- x86 emulator build of the
+# kernels, gloo instead of RCCL, a reduced-depth net -- so that the multi-rank sequence of collectives of this script is
+# checked without a multi-GPU node.  Never a measurement; the JSON line says so.
+DRYRUN = os.environ.get("HDU_BENCH_DRYRUN") == "1"
+
+
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class _HostEvent:
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 def build(config, dtype, b, size, cols):
     args = argparse.Namespace(b=b, input_size=size, input_cols=cols)
     ka = importlib.import_module("h-denseunet_amd.keras_api")
     if config == "2d":
-        m = importlib.import_module("h-denseunet_amd.denseunet").DenseUNet(reduction=0.5, args=args, dtype=dtype)
+        kw = {"nb_layers": (2, 2, 2, 2)} if DRYRUN else {}
+        m = importlib.import_module("h-denseunet_amd.denseunet").DenseUNet(reduction=0.5, args=args, dtype=dtype, **kw)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy_2ddense
     elif config == "3dpart":
         m = importlib.import_module("h-denseunet_amd.denseunet3d").denseunet_3d(args, dtype=dtype)
@@ -71,7 +94,8 @@ def instrumented_step(m):
 
     def wrap(fn, op):
         def f(d, *a):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
+            e0, e1 = Ev(enable_timing=True), Ev(enable_timing=True)
             e0.record()
             fn(d, *a)
             e1.record()
@@ -85,13 +109,18 @@ def instrumented_step(m):
         m._graph = None
         if batched:
             ctx.set_batch_wgrad(False)     # per-layer filter-gradient launches so that each one can be timed
+        # this extra step runs on rank 0 ONLY: it must not enter the gradient all-reduce (the other ranks are already
+        # waiting in the final barrier)
+        dp = (m._allreduce, m._allreduce_async, m._buckets)
+        m._allreduce = m._allreduce_async = m._buckets = None
         try:
             m.train_step_resident()
         finally:
             m._graph = g
+            m._allreduce, m._allreduce_async, m._buckets = dp
             if batched:
                 ctx.set_batch_wgrad(True)
-        torch.cuda.synchronize()
+        _sync()
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w
     agg = {}
@@ -171,13 +200,17 @@ def main():
     a = ap.parse_args()
 
     pkg = importlib.import_module("h-denseunet_amd")
-    pkg.lib.load()   # gfx950 library or a loud failure: there is no CPU fallback
+    if DRYRUN:
+        pkg.lib.use_emulator_for_tests()
+        a.no_graph, a.no_cpu_baseline = True, True
+    else:
+        pkg.lib.load()   # gfx950 library or a loud failure: there is no CPU fallback
     par = importlib.import_module("h-denseunet_amd.parallel")
-    rank, world = par.init_process_group_from_env("nccl")
+    rank, world = par.init_process_group_from_env("gloo" if DRYRUN else "nccl")
     if world != a.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
-    if world == 1:
+    if world == 1 and not DRYRUN:
         torch.cuda.set_device(0)
     b = a.batch or (8 if a.config == "2d" else 1)
     size = a.size or (512 if a.config == "2d" else 224)
@@ -203,7 +236,7 @@ def main():
         x, y = synth.synthetic_batch(kind, b, size, cols, seed=1234 + rank)
     m._upload_x(x)
     m.loss_layer.set_labels(m._labels_internal(y))
-    torch.cuda.synchronize()
+    _sync()
 
     if not a.no_graph:
         m.capture_graph(warmup=1)
@@ -215,7 +248,7 @@ def main():
     def barrier():
         if dist_on:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     barrier()
     t0 = time.perf_counter()
@@ -224,7 +257,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cpu" if DRYRUN else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / a.steps * 1e3
@@ -239,7 +272,7 @@ def main():
         "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "strong" if a.config == "shard3d" else "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on",
+        "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on" + (" -- CPU DRY RUN, not a measurement" if DRYRUN else ""),
         "config": {"workload": {"2d": "2D DenseUNet-161 train step, batch %d x %dx%d per GPU (BASELINE configs[1])" % (b, size, size),
                                 "3dpart": "denseunet_3d train step, %dx%dx%d (BASELINE configs[2])" % (size, size, cols or 0),
                                 "end2end": "dense_rnn_net end2end train step, %dx%dx%d (BASELINE configs[3])" % (size, size, cols or 0),

@@ -1,0 +1,30 @@
+"""bench.py's multi-rank control flow on 2 CPU ranks (HDU_BENCH_DRYRUN=1: emulator kernels, gloo, reduced-depth net): the
+sequence of collectives -- broadcast, per-step gradient all-reduce, barriers, MAX-reduce of the time, the loss reduce, and
+the rank-0-ONLY instrumented roofline step that must not enter a collective -- completes, and rank 0 prints ONE JSON line
+with the contract's keys.  (What the driver launches at round end with --gpus 2/4/8 over RCCL.)"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_world2_control_flow(emu_lib):
+    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "1", "--size", "32", "--dtype", "bf16"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 only
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["global_batch_slices"] == 2 and rec["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in rec                                # rank 0 at N=1 only
+    assert "DRY RUN" in rec["data"]
+    assert rec["roofline"]["launches_per_step"] > 0
