@@ -61,7 +61,7 @@ def build(config, dtype, b, size, cols):
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
     elif config == "shard3d":
         par = importlib.import_module("h-denseunet_amd.parallel")
-        sh = par.depth_shard_info("nccl")
+        sh = par.depth_shard_info("gloo" if DRYRUN else "nccl")
         m = importlib.import_module("h-denseunet_amd.densenet3d_sharded").dense_net3d(args, dtype=dtype, shard=sh)
         par.attach_depth_shard(m)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
