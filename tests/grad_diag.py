@@ -1,8 +1,9 @@
-"""Diagnostic (test infrastructure, imports oracle/): per-tensor gradient error of one f32 training step vs the oracle.
-usage: python tools/grad_diag.py <kind> <variant> <b> <size> <cols|0> [emu]"""
+"""Diagnostic, TEST INFRASTRUCTURE (lives under tests/ because it imports oracle/): per-tensor gradient error of one f32
+training step vs the oracle.  usage: python tests/grad_diag.py <kind> <variant> <b> <size> <cols|0> [emu]"""
 import sys, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import parity_utils as U
 kind, variant, b, size, cols = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]) or None
 if len(sys.argv) > 6:
