@@ -1,15 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- CT slices/s of one fwd+bwd+SGD step of the H-DenseUNet hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2d|3dpart|end2end] [--dtype bf16|f32]
+    python bench.py --gpus N --steps K --warmup W [--config 2d|3dpart|end2end|shard3d] [--dtype bf16|f32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N=1 workload (BASELINE.json configs[1], the configuration the metric is quoted on): 2D DenseUNet-161 training step,
-batch 8 x 512 x 512, bf16 storage / f32 accumulate, synthetic CT phantom, random-init weights, dropout ON.  Under
-N>1 every rank runs the same per-GPU batch (weak scaling) and gradients are summed with one flat RCCL all-reduce.
-Inputs and labels are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+BASELINE.json's metric is "CT slices/sec fwd+bwd (2D 512^2 & 3D 224x224x12)".  The JSON line's top-level `value` is the
+2D half on the configuration the metric is quoted on (configs[1]: 2D DenseUNet-161 training step, batch 8 x 512 x 512,
+bf16 storage / f32 accumulate, dropout ON, one hipGraph per step); the 3D half -- `denseunet_3d` (configs[2]) and
+`dense_rnn_net` end2end (configs[3]) at 224 x 224 x 12 -- and the float32 parity-mode 2D step are timed by the SAME
+function in the same process and reported under `config.extra_workloads`, each with its own value / ms_per_step /
+roofline.  Under N>1 every rank runs the same per-GPU batch (weak scaling) and gradients are summed with one flat RCCL
+all-reduce.  Inputs and labels are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -25,10 +29,10 @@ sys.path.insert(0, ROOT)
 # conv FLOPs (2*MAC) per slice, fwd + dgrad + wgrad (stem dgrad skipped)
 TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3d": 121.3}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
-
+PROFILE_ROUND = "r02"
 
 # HDU_BENCH_DRYRUN=1 (tests/test_bench_flow_gloo.py only): the same control flow on CPU -- x86 emulator build of the
-# kernels, gloo instead of RCCL, a reduced-depth net -- so that the multi-rank sequence of collectives of this script is
+# kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
 # checked without a multi-GPU node.  Never a measurement; the JSON line says so.
 DRYRUN = os.environ.get("HDU_BENCH_DRYRUN") == "1"
 
@@ -49,24 +53,56 @@ class _HostEvent:
         return (other.t - self.t) * 1e3
 
 
+def physical_cores():
+    """physical core count of the host (north_star: 'core count stated'); falls back to the logical count"""
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    try:
+        seen = set()
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
 def build(config, dtype, b, size, cols):
     args = argparse.Namespace(b=b, input_size=size, input_cols=cols)
     ka = importlib.import_module("h-denseunet_amd.keras_api")
+    small2d, small3d = (2, 2, 2, 2), (1, 1, 2, 1)
     if config == "2d":
-        kw = {"nb_layers": (2, 2, 2, 2)} if DRYRUN else {}
+        kw = {"nb_layers": small2d} if DRYRUN else {}
         m = importlib.import_module("h-denseunet_amd.denseunet").DenseUNet(reduction=0.5, args=args, dtype=dtype, **kw)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy_2ddense
     elif config == "3dpart":
-        m = importlib.import_module("h-denseunet_amd.denseunet3d").denseunet_3d(args, dtype=dtype)
+        kw = {"nb_layers2d": small2d, "nb_layers3d": small3d} if DRYRUN else {}
+        m = importlib.import_module("h-denseunet_amd.denseunet3d").denseunet_3d(args, dtype=dtype, **kw)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
     elif config == "shard3d":
         par = importlib.import_module("h-denseunet_amd.parallel")
         sh = par.depth_shard_info("gloo" if DRYRUN else "nccl")
-        m = importlib.import_module("h-denseunet_amd.densenet3d_sharded").dense_net3d(args, dtype=dtype, shard=sh)
+        kw = {"nb_layers3d": small3d} if DRYRUN else {}
+        m = importlib.import_module("h-denseunet_amd.densenet3d_sharded").dense_net3d(args, dtype=dtype, shard=sh, **kw)
         par.attach_depth_shard(m)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
     else:
-        m = importlib.import_module("h-denseunet_amd.hybridnet").dense_rnn_net(args, dtype=dtype)
+        kw = {"nb_layers2d": small2d, "nb_layers3d": small3d} if DRYRUN else {}
+        m = importlib.import_module("h-denseunet_amd.hybridnet").dense_rnn_net(args, dtype=dtype, **kw)
         loss = importlib.import_module("h-denseunet_amd.loss").weighted_crossentropy
     m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[loss])
     return m
@@ -76,7 +112,6 @@ def instrumented_step(m):
     """one eager step with a HIP-event pair around every conv launch (events on the launch stream = torch's current
     stream); returns {kernel_name: [n_launches, total_ms, total_algorithmic_flops]}"""
     ops = importlib.import_module("h-denseunet_amd.ops")
-    eng = importlib.import_module("h-denseunet_amd.engine")
     ctx = m.ctx
     scale = {}
     for cv in ctx.convs:
@@ -142,46 +177,151 @@ def instrumented_step(m):
     return agg
 
 
-def cpu_baseline(config, size, cols):
+def cpu_baseline(config, size, cols, samples=2):
     """the reference's Keras/TF CPU path cannot run here; stand-in = the float32 torch-CPU
-    restatement of the same graph (oracle/torch_ref.py), ONE training step on ONE slice / ONE volume."""
+    restatement of the same graph (oracle/torch_ref.py), training steps on ONE slice / ONE volume, on the host's
+    PHYSICAL cores (torch threads pinned to that count)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import torch_ref as R
     import parity_utils as U
     kind = "2d" if config == "2d" else "hybrid"
     variant = {"2d": "denseunet", "3dpart": "3dpart", "end2end": "end2end"}[config]
     b = 1
-    x, y = U.synthetic_batch(kind, b, size, cols)
-    P = R.ParamStore(seed=4321, dtype=torch.float32, perturb=False)
-    fwd = U.oracle_forward_fn(kind, variant, (6, 12, 36, 24), (3, 4, 12, 8))
-    t0 = time.time()
-    R.train_step(P, fwd, U.loss_fn_for(kind), torch.tensor(x), torch.tensor(y), {})
-    t1 = time.time()   # includes parameter creation + one plain forward
-    R.train_step(P, fwd, U.loss_fn_for(kind), torch.tensor(x), torch.tensor(y), {})
-    t2 = time.time()
+    cores = physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        x, y = U.synthetic_batch(kind, b, size, cols)
+        P = R.ParamStore(seed=4321, dtype=torch.float32, perturb=False)
+        fwd = U.oracle_forward_fn(kind, variant, (6, 12, 36, 24), (3, 4, 12, 8))
+        with torch.no_grad():
+            fwd(P, torch.tensor(x))      # creates the parameters (not timed)
+        P.bn_batch_means = {}
+        vel = {}
+        times = []
+        for _ in range(samples):
+            t1 = time.time()
+            R.train_step(P, fwd, U.loss_fn_for(kind), torch.tensor(x), torch.tensor(y), vel)
+            times.append(time.time() - t1)
+    finally:
+        torch.set_num_threads(prev)
     slices = b if kind == "2d" else cols
-    return {"value": round(slices / (t2 - t1), 4), "unit": "slices/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 training step (fwd+bwd+SGD) of the float32 torch-CPU restatement of the reference graph "
-                      "(not TensorFlow) on %s, %.1f s" % ("1x%dx%d" % (size, size) if kind == "2d" else
-                                                        "one %dx%dx%d volume" % (size, size, cols), t2 - t1)}
+    best = min(times)
+    return {"value": round(slices / best, 4), "unit": "slices/s", "cores": cores, "logical_cpus": os.cpu_count(),
+            "kind": "port",
+            "sample": "%d training steps (fwd+bwd+SGD) of the float32 torch-CPU restatement of the reference graph "
+                      "(not TensorFlow) on %s, torch threads = physical cores; per-step seconds %s, best used" %
+                      (samples, "1x%dx%d" % (size, size) if kind == "2d" else "one %dx%dx%d volume" % (size, size, cols),
+                       [round(t, 1) for t in times])}
 
 
 def pmc_traffic(kernel, config, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC summaries (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     passes over this same bench command, profiles/): FETCH_SIZE [KB] x2 (gfx950 counts a 128-B request as 64 B,
     MI355X_MICROARCH.md "HBM") + WRITE_SIZE [KB].  None when no summary of this config / kernel is committed."""
-    vals = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_%s_%s_%s.txt" % (ctr, config, dtype))
-        if not os.path.exists(path):
-            return None
-        lines = open(path).read().split("\n")
-        for i, ln in enumerate(lines):
-            if ln.startswith("void " + kernel + "(") and i + 1 < len(lines) and ctr in lines[i + 1]:
-                vals[ctr] = float(lines[i + 1].split()[-1])
-    if len(vals) != 2:
-        return None
-    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    for rnd in (PROFILE_ROUND, "r01"):
+        vals = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            path = os.path.join(ROOT, "profiles", "%s_pmc_%s_%s_%s.txt" % (rnd, ctr, config, dtype))
+            if not os.path.exists(path):
+                break
+            lines = open(path).read().split("\n")
+            for i, ln in enumerate(lines):
+                if ln.startswith("void " + kernel + "(") and i + 1 < len(lines) and ctr in lines[i + 1]:
+                    vals[ctr] = float(lines[i + 1].split()[-1])
+        if len(vals) == 2:
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), rnd
+    return None, None
+
+
+WORKLOAD_TEXT = {
+    "2d": "2D DenseUNet-161 train step, batch %(b)d x %(size)dx%(size)d per GPU (BASELINE configs[1])",
+    "3dpart": "denseunet_3d train step, %(size)dx%(size)dx%(cols)d (BASELINE configs[2])",
+    "end2end": "dense_rnn_net end2end train step, %(size)dx%(size)dx%(cols)d (BASELINE configs[3])",
+    "shard3d": "3D DenseNet train step on ONE %(size)dx%(size)dx%(gcols)d volume, depth-sharded (BASELINE configs[4] shape family)",
+}
+
+
+def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline):
+    """build, make resident, (capture,) warm up, time `steps` steps between barriers, MAX over ranks.  Returns the
+    record of this workload (rank 0 adds the roofline of its dominant conv kernel)."""
+    par = importlib.import_module("h-denseunet_amd.parallel")
+    synth = importlib.import_module("h-denseunet_amd.synth")
+    gcols = cols
+    if config == "shard3d":
+        # ONE volume of `cols` depth planes split over the ranks (strong scaling); every rank builds the same phantom
+        # and keeps its own planes.  No hipGraph: the step contains the neighbour exchanges.
+        assert cols % (4 * world) == 0, "--cols must be a multiple of 4*world"
+        gcols, cols = cols, cols // world
+        use_graph = False
+    m = build(config, dtype, b, size, cols)
+    if (world > 1 or os.environ.get("HDU_FORCE_DP") == "1") and config != "shard3d":
+        par.attach_data_parallel(m)
+    kind = "2d" if config == "2d" else "hybrid"
+    if config == "shard3d":
+        xv, yv = synth.synthetic_batch("hybrid", 1, size, gcols, seed=1234)
+        rng = np.random.default_rng(99)
+        xv = np.concatenate([xv, rng.normal(0, 60, xv.shape[:4] + (3,)).astype(np.float32)], -1)
+        x, y = xv[:, :, :, rank * cols:(rank + 1) * cols], yv[:, :, :, rank * cols:(rank + 1) * cols]
+    else:
+        x, y = synth.synthetic_batch(kind, b, size, cols, seed=1234 + rank)
+    m._upload_x(x)
+    m.loss_layer.set_labels(m._labels_internal(y))
+    _sync()
+
+    if use_graph:
+        m.capture_graph(warmup=1)
+    for _ in range(warmup):
+        m.train_step_resident()
+
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    def barrier():
+        if dist_on:
+            torch.distributed.barrier()
+        _sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_step_resident()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device="cpu" if DRYRUN else "cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / steps * 1e3
+    slices_per_step = (b if kind == "2d" else cols) * world   # shard3d: cols is per rank -> the whole volume
+    loss = m.loss_value()
+    rec = {
+        "workload": WORKLOAD_TEXT[config] % dict(b=b, size=size, cols=cols or 0, gcols=gcols or 0),
+        "value": round(slices_per_step / (ms / 1e3), 2), "unit": "slices/s", "ms_per_step": round(ms, 3),
+        "steps": steps, "warmup": warmup, "dtype": dtype, "global_batch_slices": slices_per_step,
+        "hipgraph": bool(use_graph), "loss": round(loss, 5),
+        "step_conv_tflops": round(TRAIN_GFLOP_PER_SLICE[config] * slices_per_step / world / ms, 2),
+        "step_frac_of_mfma_peak": round(TRAIN_GFLOP_PER_SLICE[config] * slices_per_step / world / ms / PEAK_TFLOPS[dtype], 4),
+    }
+    # the instrumented step is rank-0-only and must not enter a collective: the depth-sharded step always does
+    # (halo exchange, sync-BN), so it is skipped there when world > 1
+    if rank == 0 and roofline and not (config == "shard3d" and world > 1):
+        agg = instrumented_step(m)
+        name, (n, tms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+        ach = fl / (tms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[dtype]
+        traffic, rnd = pmc_traffic(name, config, dtype)
+        rec["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 4), "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch, PMC (profiles/%s_pmc_*), avg over the layer shapes" % (rnd or PROFILE_ROUND),
+                           "kernel": name, "launches_per_step": n, "avg_launch_ms": round(tms / n, 4),
+                           "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1], 3),
+                                                    "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+    del m
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -197,6 +337,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--extras", default=None,
+                    help="comma list of extra workloads timed after the main one (config[:dtype]); default for the "
+                         "default 2d/bf16 run: 3dpart,end2end,2d:f32; 'none' disables")
     a = ap.parse_args()
 
     pkg = importlib.import_module("h-denseunet_amd")
@@ -216,88 +359,49 @@ def main():
     size = a.size or (512 if a.config == "2d" else 224)
     cols = a.cols if a.config != "2d" else None
 
-    if a.config == "shard3d":
-        # ONE volume of --cols depth planes split over the ranks (strong scaling); every rank builds the same phantom
-        # and keeps its own planes.  No hipGraph: the step contains the neighbour exchanges.
-        assert cols % (4 * world) == 0, "--cols must be a multiple of 4*world"
-        gcols, cols = cols, cols // world
-        a.no_graph = True
-    m = build(a.config, a.dtype, b, size, cols)
-    if (world > 1 or os.environ.get("HDU_FORCE_DP") == "1") and a.config != "shard3d":
-        par.attach_data_parallel(m)
-    synth = importlib.import_module("h-denseunet_amd.synth")
-    kind = "2d" if a.config == "2d" else "hybrid"
-    if a.config == "shard3d":
-        xv, yv = synth.synthetic_batch("hybrid", 1, size, gcols, seed=1234)
-        rng = np.random.default_rng(99)
-        xv = np.concatenate([xv, rng.normal(0, 60, xv.shape[:4] + (3,)).astype(np.float32)], -1)
-        x, y = xv[:, :, :, rank * cols:(rank + 1) * cols], yv[:, :, :, rank * cols:(rank + 1) * cols]
-    else:
-        x, y = synth.synthetic_batch(kind, b, size, cols, seed=1234 + rank)
-    m._upload_x(x)
-    m.loss_layer.set_labels(m._labels_internal(y))
-    _sync()
-
-    if not a.no_graph:
-        m.capture_graph(warmup=1)
-    for _ in range(a.warmup):
-        m.train_step_resident()
-
-    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-
-    def barrier():
-        if dist_on:
-            torch.distributed.barrier()
-        _sync()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        m.train_step_resident()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], device="cpu" if DRYRUN else "cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    ms = dt / a.steps * 1e3
-    slices_per_step = (b if kind == "2d" else cols) * world   # shard3d: cols is per rank -> the whole volume
-    value = slices_per_step / (ms / 1e3)
-    loss = m.loss_value()
+    main_rec = run_workload(a.config, a.dtype, b, size, cols, a.steps, a.warmup, rank, world, not a.no_graph,
+                            not a.no_roofline)
+    extras = a.extras
+    if extras is None:
+        default_run = a.config == "2d" and a.dtype == "bf16" and a.batch is None and a.size is None
+        extras = "3dpart,end2end,2d:f32" if (default_run and not DRYRUN) else "none"
+    extra_recs = []
+    if extras != "none":
+        for spec in extras.split(","):
+            cfg, _, dt = spec.partition(":")
+            dt = dt or "bf16"
+            # the 3D half of the metric at the shape BASELINE names; fewer steps for the slow float32 parity mode
+            e_b, e_size, e_cols = (b, size, None) if cfg == "2d" else (1, 32 if DRYRUN else 224, 8 if DRYRUN else 12)
+            e_steps = max(2, min(a.steps, 10 if dt == "bf16" else 3))
+            e_warm = max(1, min(a.warmup, 3 if dt == "bf16" else 1))
+            extra_recs.append(run_workload(cfg, dt, e_b, e_size, e_cols, e_steps, e_warm, rank, world, not a.no_graph,
+                                           not a.no_roofline))
 
     out = {
         "metric": "CT slices/sec fwd+bwd (%s)" % ("2D 512^2" if a.config == "2d" else
-                                                   ("3D %dx%dx%d depth-sharded" % (size, size, cols * world) if a.config == "shard3d"
+                                                   ("3D %dx%dx%d depth-sharded" % (size, size, cols) if a.config == "shard3d"
                                                     else "3D 224x224x12")),
-        "value": round(value, 2), "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "value": main_rec["value"], "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True,
         "scaling": "strong" if a.config == "shard3d" else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on" + (" -- CPU DRY RUN, not a measurement" if DRYRUN else ""),
-        "config": {"workload": {"2d": "2D DenseUNet-161 train step, batch %d x %dx%d per GPU (BASELINE configs[1])" % (b, size, size),
-                                "3dpart": "denseunet_3d train step, %dx%dx%d (BASELINE configs[2])" % (size, size, cols or 0),
-                                "end2end": "dense_rnn_net end2end train step, %dx%dx%d (BASELINE configs[3])" % (size, size, cols or 0),
-                                "shard3d": "3D DenseNet train step on ONE %dx%dx%d volume, depth-sharded (BASELINE configs[4] shape family)" % (size, size, (cols or 0) * world)}[a.config],
-                   "global_batch_slices": slices_per_step, "parallelism": "dp%d" % world, "hipgraph": not a.no_graph,
-                   "loss": round(loss, 5),
-                   "step_conv_tflops": round(TRAIN_GFLOP_PER_SLICE[a.config] * slices_per_step / world / ms, 2)},
+        "config": {"workload": main_rec["workload"], "global_batch_slices": main_rec["global_batch_slices"],
+                   "parallelism": "dp%d" % world, "hipgraph": main_rec["hipgraph"], "loss": main_rec["loss"],
+                   "step_conv_tflops": main_rec["step_conv_tflops"],
+                   "step_frac_of_mfma_peak": main_rec["step_frac_of_mfma_peak"]},
     }
+    if extra_recs:
+        out["config"]["extra_workloads"] = extra_recs
     if rank == 0:
-        if not a.no_roofline:
-            agg = instrumented_step(m)
-            name, (n, tms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
-            ach = fl / (tms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[a.dtype]
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(name, a.config, a.dtype),
-                               "traffic_unit": "HBM bytes per launch, PMC (profiles/r01_pmc_*), avg over the layer shapes",
-                               "kernel": name, "launches_per_step": n,
-                               "avg_launch_ms": round(tms / n, 4),
-                               "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1], 3),
-                                                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
-                                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        if "roofline" in main_rec:
+            out["roofline"] = main_rec["roofline"]
         if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
             out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
+            for r in extra_recs:
+                if r["workload"].startswith("denseunet_3d"):      # the 3D half beside its own CPU baseline
+                    r["cpu_baseline"] = cpu_baseline("3dpart", 224, 12, samples=1)
         print(json.dumps(out))
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

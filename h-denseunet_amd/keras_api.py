@@ -38,6 +38,13 @@ def weighted_crossentropy_2ddense(y_true, y_pred):  # loss.py:27
     raise RuntimeError("marker function: pass it to Model.compile(loss=[...]); the HIP loss kernel computes it")
 
 
+def _is_io_rank():
+    """one process per GPU under data parallelism / depth sharding: checkpoints, the loss history and progress lines
+    are written by rank 0 only (the reference's single-process make_parallel wrote each file once)"""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 class History:
     def __init__(self):
         self.history = {"loss": []}
@@ -98,6 +105,7 @@ class Model:
         self.optimizer = None
         self.world_size = 1
         self._graph = None
+        self._graph_hparams = None
         self._allreduce = None
         self._allreduce_async = None
         self._buckets = None
@@ -191,6 +199,10 @@ class Model:
         """one fwd+bwd+SGD step on the inputs / labels already resident in HBM (what bench.py times)."""
         if self.optimizer is None:
             raise RuntimeError("compile() the model first")
+        if self._graph is not None and self._graph_hparams != (self.optimizer.lr, self.optimizer.momentum):
+            # the captured SGD launch carries lr / momentum as kernel arguments: an LR-schedule callback that assigns
+            # optimizer.lr would otherwise be ignored silently.  All buffers are static, so re-capturing needs no warm-up.
+            self.capture_graph(warmup=0)
         if self._graph is not None:
             g_fb, g_upd = self._graph
             if isinstance(g_fb, list):               # bucketed data parallel: one graph per backward segment
@@ -263,6 +275,7 @@ class Model:
                 self._step_update()
         self.optimizer.iterations = it0
         self._graph = (g_fb, g_upd)
+        self._graph_hparams = (self.optimizer.lr, self.optimizer.momentum)
 
     def train_on_batch(self, x, y, **kw):
         self._upload_x(x)
@@ -315,7 +328,7 @@ class Model:
                 losses.append(self.train_on_batch(x, y))
             logs = {"loss": float(np.mean(losses))}
             hist.history["loss"].append(logs["loss"])
-            if verbose:
+            if verbose and _is_io_rank():
                 print("Epoch %d/%d - loss: %.4f" % (epoch + 1, epochs, logs["loss"]))
                 # the author's patch to ProgbarLogger.on_epoch_end (K.callbacks.py:28,311-314): the epoch loss is
                 # appended to ./Experiments/history/lossepoch.txt (the scripts create that directory,
@@ -426,6 +439,8 @@ class ModelCheckpoint:
             return
         self.best = min(self.best, cur)
         path = self.filepath.format(epoch=epoch, **logs)      # Keras 2.0.8 formats the 0-based epoch (K.callbacks.py:404)
+        if not _is_io_rank():
+            return            # every rank holds the same weights after the all-reduced step; rank 0 writes the file
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         self.model.save(path)
 

@@ -71,8 +71,12 @@ def broadcast_parameters(model, src=0):
 
 def shard_depth(D, world, rank):
     """[begin, end) of the depth planes owned by `rank` when one volume is sharded on the depth axis"""
+    if D % (4 * world) != 0:
+        # sync-BN and the loss normalisation assume equal shards (n_global = n_local * world), and every shard must
+        # satisfy the 3D net's depth rule (local depth a multiple of 4, SURVEY.md A.2)
+        raise ValueError("depth %d cannot be split evenly over %d ranks in multiples of 4 planes" % (D, world))
     per = D // world
-    return rank * per, (rank + 1) * per if rank < world - 1 else D
+    return rank * per, (rank + 1) * per
 
 
 def depth_shard_info(backend=None):

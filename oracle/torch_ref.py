@@ -109,6 +109,19 @@ def weighted_crossentropy(y_true, y_pred):
     return weighted_crossentropy_rows(y_pred[:, :, :, 1:7, :].reshape(-1, 3), y_true[:, :, :, 1:7, :].reshape(-1).long())
 
 
+class _RoundBF16(torch.autograd.Function):
+    """value AND gradient rounded to bfloat16 (round-to-nearest-even) and widened back: what storing a tensor and its
+    gradient in bf16 does.  Used only by the calibration runs of the bf16 parity tests (ParamStore.store_bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 # --------------------------------------------------------------------------- parameters
 class ParamStore:
     """Keras-ordered, Keras-shaped weights keyed by layer name.
@@ -125,6 +138,11 @@ class ParamStore:
         self.bn_batch_means = {}
         self.learning_phase = 1
         self.dropout_off = True
+        # calibration mode of the bf16 parity tests: every conv reads a bf16-stored input and bf16 filter copy and
+        # writes a bf16-stored output (and the same for the gradients flowing back), accumulation stays float32 --
+        # the storage precision of the product's throughput mode applied to the ORACLE's arithmetic.  The distance
+        # between this run and the plain float32 run is the noise floor a bf16 implementation cannot beat.
+        self.store_bf16 = False
 
     # -- creation helpers
     def _t(self, a):
@@ -152,6 +170,10 @@ class ParamStore:
             self.kind[name] = "conv"
         self.trainable[name] = trainable
         ws = self.w[name]
+        if self.store_bf16:
+            w = ws[0] + (ws[0].detach().to(torch.bfloat16).to(ws[0].dtype) - ws[0].detach())   # bf16 copy, f32 gradient
+            y = conv_nd(_RoundBF16.apply(x), w, strides, padding, ws[1] if use_bias else None)
+            return _RoundBF16.apply(y)
         return conv_nd(x, ws[0], strides, padding, ws[1] if use_bias else None)
 
     def bn(self, name, x, eps=1e-3, momentum=0.99, mode="batch", trainable=True):

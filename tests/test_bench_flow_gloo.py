@@ -14,7 +14,7 @@ def test_bench_world2_control_flow(emu_lib):
     env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "1", "--size", "32", "--dtype", "bf16"]
+           "--warmup", "1", "--batch", "1", "--size", "32", "--dtype", "bf16", "--extras", "3dpart"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -28,3 +28,24 @@ def test_bench_world2_control_flow(emu_lib):
     assert "cpu_baseline" not in rec                                # rank 0 at N=1 only
     assert "DRY RUN" in rec["data"]
     assert rec["roofline"]["launches_per_step"] > 0
+    # the 3D half of the metric rides in the same line: timed by the same function, data parallel as well
+    ex = rec["config"]["extra_workloads"]
+    assert len(ex) == 1 and ex[0]["workload"].startswith("denseunet_3d") and ex[0]["value"] > 0
+    assert ex[0]["global_batch_slices"] == 16 and ex[0]["roofline"]["launches_per_step"] > 0
+
+
+def test_bench_world2_shard3d_control_flow(emu_lib):
+    """--config shard3d with 2 ranks: the depth-sharded step always contains collectives (halo exchange, sync-BN), so
+    the rank-0-only instrumented roofline step must be skipped -- otherwise rank 0 blocks on sends that the other
+    rank, already in the final barrier, never matches."""
+    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--config", "shard3d", "--size", "32", "--cols", "16", "--dtype", "f32"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["global_batch_slices"] == 16 and "roofline" not in rec

@@ -1,0 +1,229 @@
+"""GPU tier, throughput mode: ONE bf16 training step of every full-size net -- the launch list bench.py times (deferred
+batched filter gradients, batch statistics from the conv epilogues, bf16 DMA / halo-tile kernels) -- against the float32
+oracle, from WELL-CONDITIONED weights.
+
+Weights: random-init logits are nearly tied between the classes (a 1e-4 relative error flips arg-max labels), so the
+nets are first trained here, in the product's float32 parity mode, on the seeded phantom, following the reference's own
+recipe: the 2D DenseUNet alone (train_2ddense.py), then the hybrid with the 2D weights loaded by name
+(train_hybrid.py:152-153).  The recipe is deterministic (seeds below); the trained weights are an INPUT of the
+comparison, fed identically to the oracle and to the bf16 product.
+
+Gates (per configuration):
+  * predict logits: absolute error reported with max|logit|; Dice of arg-max labels vs the oracle's on ALL voxels
+    >= 1 - 1e-3 (relaxed only to BF16_SLACK x the disagreement of the bf16-storage oracle itself, see below), and the
+    Dice against the ground-truth labels within 1e-3 of the oracle's (north_star: "Dice within 1e-3 of reference");
+  * training step: loss, every parameter gradient (relative L2 and cosine per tensor, mean |got|/|ref| norm ratio).
+    The bound on the gradients is calibrated, in the same test, against the ORACLE run with bf16-stored activations /
+    filter copies / activation gradients (oracle/torch_ref.py ParamStore.store_bf16): the distance of that run from the
+    float32 oracle is the noise floor of bf16 storage; the product must stay within BF16_SLACK x of it (or an absolute
+    floor for tensors whose noise is tiny).
+Match: loss.py:5-46, K.optimizers.py:155-186, K.engine/training.py:948-967.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as U
+
+pytestmark = pytest.mark.gpu
+
+FULL2D, FULL3D = (6, 12, 36, 24), (3, 4, 12, 8)
+BF16_SLACK = 2.5          # product error <= BF16_SLACK x (bf16-storage oracle error) per tensor ...
+REL_FLOOR = 0.02          # ... or this relative L2, whichever is larger
+COS_MIN = 0.999
+
+
+def _sgd():
+    return U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True)
+
+
+def _train(m, x, y, steps):
+    m.compile(optimizer=_sgd(), loss=[U.pkg("loss").weighted_crossentropy])
+    l0 = m.train_on_batch(x, y)
+    for _ in range(steps - 1):
+        m.train_step_resident()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return l0, m.loss_value()
+
+
+def trained_weights(kind, variant, b, size, cols, nb2d=FULL2D, nb3d=FULL3D, steps2d=80, steps3d=50):
+    """the recipe described in the module docstring; returns an OrderedDict layer -> Keras-shaped arrays"""
+    if kind == "2d":
+        mod = U.pkg("denseunet" if variant == "denseunet" else "densenet")
+        m = mod.DenseUNet(reduction=0.5, args=U.make_args(b, size), dtype="f32", nb_layers=nb2d, seed=4321)
+        x, y = U.synthetic_batch("2d", b, size, None, seed=77)
+        l0, l1 = _train(m, x, y, steps2d)
+        print("recipe 2d/%s: loss %.4f -> %.4f in %d steps" % (variant, l0, l1, steps2d))
+        return m.get_weights_dict()
+    if kind == "3d":
+        m = U.pkg("densenet3d_sharded").dense_net3d(U.make_args(1, size, cols), dtype="f32", nb_layers3d=nb3d, seed=4321)
+        x, y = U.synthetic_batch("3d", 1, size, cols, seed=77)
+        l0, l1 = _train(m, x, y, steps3d)
+        print("recipe 3d: loss %.4f -> %.4f in %d steps" % (l0, l1, steps3d))
+        return m.get_weights_dict()
+    # hybrid: pre-train the 2D net (densenet.py variant: the hybrid's 2D branch has no skips), load by name, train
+    m2 = U.pkg("densenet").DenseUNet(reduction=0.5, args=U.make_args(6, size), dtype="f32", nb_layers=nb2d, seed=4321)
+    x2, y2 = U.synthetic_batch("2d", 6, size, None, seed=77)
+    l0, l1 = _train(m2, x2, y2, steps2d)
+    print("recipe hybrid stage 1 (2D): loss %.4f -> %.4f in %d steps" % (l0, l1, steps2d))
+    w2 = m2.get_weights_dict()
+    del m2
+    mod, fn = ("denseunet3d", "denseunet_3d") if variant == "3dpart" else ("hybridnet", "dense_rnn_net")
+    m = getattr(U.pkg(mod), fn)(U.make_args(1, size, cols), dtype="f32", nb_layers2d=nb2d, nb_layers3d=nb3d, seed=4321)
+    m.set_weights_dict(w2, strict=False)
+    x, y = U.synthetic_batch("hybrid", 1, size, cols, seed=77)
+    l0, l1 = _train(m, x, y, steps3d)
+    print("recipe hybrid stage 2 (%s): loss %.4f -> %.4f in %d steps" % (variant, l0, l1, steps3d))
+    return m.get_weights_dict()
+
+
+def oracle_with(weights, kind, variant, b, size, cols, nb2d=FULL2D, nb3d=FULL3D):
+    P = U.R.ParamStore(seed=1, dtype=torch.float32, perturb=False)
+    fwd = U.oracle_forward_fn(kind, variant, nb2d, nb3d)
+    x, _ = U.synthetic_batch(kind, b, size, cols)
+    with torch.no_grad():
+        fwd(P, torch.tensor(x))            # creates the parameter inventory
+    P.bn_batch_means = {}
+    assert set(P.w.keys()) == set(weights.keys()), set(P.w.keys()) ^ set(weights.keys())
+    for name in P.w:
+        assert len(P.w[name]) == len(weights[name]), name
+        P.w[name] = [torch.tensor(np.asarray(a, np.float32)) for a in weights[name]]
+    return P, fwd
+
+
+def product_with(weights, kind, variant, b, size, cols, dtype, nb2d=FULL2D, nb3d=FULL3D):
+    if kind == "2d":
+        mod = U.pkg("denseunet" if variant == "denseunet" else "densenet")
+        m = mod.DenseUNet(reduction=0.5, args=U.make_args(b, size), dtype=dtype, nb_layers=nb2d)
+    elif kind == "3d":
+        m = U.pkg("densenet3d_sharded").dense_net3d(U.make_args(b, size, cols), dtype=dtype, nb_layers3d=nb3d)
+    elif variant == "3dpart":
+        m = U.pkg("denseunet3d").denseunet_3d(U.make_args(b, size, cols), dtype=dtype, nb_layers2d=nb2d, nb_layers3d=nb3d)
+    else:
+        m = U.pkg("hybridnet").dense_rnn_net(U.make_args(b, size, cols), dtype=dtype, nb_layers2d=nb2d, nb_layers3d=nb3d)
+    m.set_weights_dict(weights)
+    m.ctx.dropout_enabled = False
+    return m
+
+
+def grad_table(got, ref, noise=None):
+    """per tensor: relative L2 (floored denominators), cosine and norm ratio for tensors that carry signal"""
+    rms_max = max(float(np.sqrt((g.astype(np.float64) ** 2).mean())) for g in ref.values())
+    rows = []
+    for key, r in ref.items():
+        r = r.astype(np.float64)
+        a = got[key].astype(np.float64)
+        floor = 1e-3 * rms_max * np.sqrt(r.size)
+        nr = np.linalg.norm(r)
+        rel = np.linalg.norm(a - r) / max(nr, floor)
+        sig = nr > 1e-2 * rms_max * np.sqrt(r.size)
+        cos = float((a * r).sum() / (np.linalg.norm(a) * nr + 1e-300)) if sig else None
+        ratio = float(np.linalg.norm(a) / nr) if sig else None
+        rows.append((key, rel, cos, ratio, None if noise is None else noise[key]))
+    return rows
+
+
+def flat_grads(gd_product):
+    return {(n, i): g for n, gs in gd_product.items() for i, g in enumerate(gs)}
+
+
+CASES = [
+    ("2d", "denseunet", 2, 512, None),            # BASELINE configs[1] shape family (2 x 512 x 512)
+    ("hybrid", "3dpart", 1, 224, 12),             # configs[2]
+    ("hybrid", "end2end", 1, 224, 12),            # configs[3]
+    ("3d", "3dpart", 1, 224, 12),                 # the per-shard network of configs[4]
+]
+
+
+@pytest.mark.parametrize("kind,variant,b,size,cols", CASES, ids=["2d-2x512", "3dpart", "end2end", "3d"])
+def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols):
+    small = os.environ.get("HDU_PARITY_SMALL") == "1"       # developer switch: same flow at reduced depth / size
+    nb2d, nb3d = ((2, 2, 2, 2), (1, 1, 2, 1)) if small else (FULL2D, FULL3D)
+    if small:
+        size, cols = (64, None) if kind == "2d" else (32, 8)
+    torch.manual_seed(0)
+    W = trained_weights(kind, variant, b, size, cols, nb2d, nb3d, *((8, 6) if small else (80, 50)))
+    x, y = U.synthetic_batch(kind, b, size, cols)
+    xt, yt = torch.tensor(x), torch.tensor(y)
+
+    # ---- oracle: predict, float32 step, bf16-storage step (calibration)
+    P, fwd = oracle_with(W, kind, variant, b, size, cols, nb2d, nb3d)
+    ref_pred = U.R.predict(P, fwd, xt).numpy()
+    ref_loss, ref_grads, ref_logits = U.R.train_step(P, fwd, U.loss_fn_for(kind), xt, yt, {})
+    Pb, _ = oracle_with(W, kind, variant, b, size, cols, nb2d, nb3d)
+    Pb.store_bf16 = True
+    cal_pred = U.R.predict(Pb, fwd, xt).numpy()
+    cal_loss, cal_grads, cal_logits = U.R.train_step(Pb, fwd, U.loss_fn_for(kind), xt, yt, {})
+    ref_g = {k: g.numpy() for k, g in ref_grads.items()}
+    cal_g = {k: g.numpy() for k, g in cal_grads.items()}
+    noise = {k: r[1] for k, r in zip(ref_g, grad_table(cal_g, ref_g))}
+    cal_rows = grad_table(cal_g, ref_g)
+
+    # ---- product, bf16, the launch list of the benchmark
+    m = product_with(W, kind, variant, b, size, cols, "bf16", nb2d, nb3d)
+    got_pred = m.predict(x)
+    scale = float(np.abs(ref_pred).max())
+    e_pred = float(np.abs(got_pred - ref_pred).max())
+    dice = U.dice_vs_oracle(got_pred, ref_pred)
+    dice_cal = U.dice_vs_oracle(cal_pred, ref_pred)
+    lab = np.asarray(y)[..., 0]
+    dice_gt_got = U.R.dice_per_class(np.argmax(got_pred, -1), lab)
+    dice_gt_ref = U.R.dice_per_class(np.argmax(ref_pred, -1), lab)
+    agree = float((np.argmax(got_pred, -1) == np.argmax(ref_pred, -1)).mean())
+    srt = np.sort(ref_pred, -1)
+    margin = srt[..., -1] - srt[..., -2]
+    print("[%s/%s] predict: max|logit| %.3f, max abs err %.3e (%.2e relative), median top-2 margin %.3f, label agreement "
+          "%.5f, Dice vs oracle %s (bf16-storage oracle vs oracle %s); Dice vs ground truth %s (oracle %s)" %
+          (kind, variant, scale, e_pred, e_pred / scale, float(np.median(margin)), agree, ["%.5f" % d for d in dice],
+           ["%.5f" % d for d in dice_cal], ["%.4f" % d for d in dice_gt_got], ["%.4f" % d for d in dice_gt_ref]))
+    m.compile(optimizer=_sgd(), loss=[U.pkg("loss").weighted_crossentropy])
+    assert m.ctx.wgrad_plan is not None and len(m.ctx.wgrad_plan) > 10, "deferred batched filter gradients must be on"
+    assert len(m.ctx.stats_sinks) > 5, "conv-epilogue statistics must be on"
+    P0 = m.ctx.P.clone()
+    m.forward_train_mode(x)                 # primes the epilogue-statistics shift; weights / moving stats restored
+    m.ctx.P.copy_(P0)
+    assert all(s.primed for s in m.ctx.stats_sinks)
+    loss = m.train_on_batch(x, y)
+    got_l = m._download_logits().cpu().numpy()
+    rl = ref_logits.numpy()
+    e_train = float(np.abs(got_l - rl).max())
+    e_cal = float(np.abs(cal_logits.numpy() - rl).max())
+    rows = grad_table(flat_grads(m.get_grads_dict()), ref_g, noise)
+    rels = np.array([r[1] for r in rows])
+    cal_rels = np.array([r[1] for r in cal_rows])
+    coss = np.array([r[2] for r in rows if r[2] is not None])
+    cal_coss = np.array([r[2] for r in cal_rows if r[2] is not None])
+    ratios = np.array([r[3] for r in rows if r[3] is not None])
+    worst = max(rows, key=lambda r: r[1] / max(BF16_SLACK * r[4], REL_FLOOR))
+    print("[%s/%s] train step: loss %.6f (oracle %.6f, bf16-storage oracle %.6f); train-mode logits max abs err %.3e "
+          "(bf16-storage oracle %.3e, max|logit| %.3f)" % (kind, variant, loss, ref_loss, cal_loss, e_train, e_cal,
+                                                          float(np.abs(rl).max())))
+    print("[%s/%s] gradients over %d tensors: rel-L2 worst %.4f / median %.4f (bf16-storage oracle: %.4f / %.4f); cosine "
+          "min %.5f / median %.6f (oracle-bf16: %.5f / %.6f); mean norm ratio %.4f; worst vs its bound: %s rel %.4f "
+          "noise %.4f" % (kind, variant, len(rows), rels.max(), float(np.median(rels)), cal_rels.max(),
+                          float(np.median(cal_rels)), coss.min(), float(np.median(coss)), cal_coss.min(),
+                          float(np.median(cal_coss)), float(ratios.mean()), worst[0], worst[1], worst[4]))
+
+    # ---- gates
+    for c in range(3):
+        assert 1.0 - dice[c] <= max(1e-3, BF16_SLACK * (1.0 - dice_cal[c])), \
+            "predict Dice vs the float32 oracle on ALL voxels: %s (bf16-storage oracle %s)" % (dice, dice_cal)
+        assert abs(dice_gt_got[c] - dice_gt_ref[c]) <= 1e-3, "Dice vs ground truth: %s, oracle %s" % (dice_gt_got, dice_gt_ref)
+    assert abs(loss - ref_loss) <= max(2.5 * abs(cal_loss - ref_loss), 2e-3 * abs(ref_loss)), (loss, ref_loss, cal_loss)
+    assert e_train <= max(2.5 * e_cal, 0.02 * float(np.abs(rl).max())), (e_train, e_cal)
+    for key, rel, cos, ratio, nz in rows:
+        assert rel <= max(BF16_SLACK * nz, REL_FLOOR), "gradient of %s: rel-L2 %.4f, bf16-storage noise %.4f" % (key, rel, nz)
+    # direction: cosine >= 0.999, relaxed only where the bf16-storage oracle itself cannot reach it
+    for (key, rel, cos, ratio, nz), crow in zip(rows, cal_rows):
+        if cos is not None:
+            lim = min(COS_MIN, 1.0 - BF16_SLACK * (1.0 - crow[2]))
+            assert cos >= lim, "gradient of %s: cosine %.5f < %.5f (bf16-storage oracle %.5f)" % (key, cos, lim, crow[2])
+    assert abs(float(ratios.mean()) - 1.0) < 1e-2, "mean |got|/|ref| = %.4f" % float(ratios.mean())
+    # SGD-Nesterov update of the head from the bf16 gradients (K.optimizers.py:168-185): delta = -lr*(1+momentum)*g
+    last = {"2d": "dense167classifer", "hybrid": "2d3dclassifer", "3d": "3dclassifer"}[kind]
+    d_got = m.get_weights_dict()[last][0] - W[last][0]
+    d_ref = P.numpy()[last][0] - W[last][0]
+    assert np.linalg.norm(d_got - d_ref) <= 5e-2 * np.linalg.norm(d_ref) + 1e-9
