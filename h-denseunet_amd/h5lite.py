@@ -371,3 +371,228 @@ def read_keras_weights(path):
         names = [text(n) for n in np.asarray(lg.attrs["weight_names"]).reshape(-1)] if "weight_names" in lg.attrs else []
         out[lname] = [np.asarray(lg[w]) for w in names]
     return out
+
+
+# =====================================================================================================================
+# Writer: the same HDF5 subset, emitted natively (no h5py in this image), so that ModelCheckpoint / Model.save /
+# save_weights hand the reference real Keras-layout files (K.engine/topology.py:2847-2873, K.models.py:31-170):
+# superblock v0, old-style groups (local heap + symbol nodes + v1 B-tree of any depth), v1 object headers, contiguous
+# little-endian datasets, v1 attribute messages with fixed-length (null-padded) strings -- what h5py 2.x wrote in the
+# Keras 2.0.8 era.  tests/test_h5_export.py reads the files back with the reader above and, where the conda
+# interpreter with the real HDF5 library exists, with h5py.
+_UNDEF = 0xFFFFFFFFFFFFFFFF
+_LEAF_K, _NODE_K = 4, 16            # HDF5 defaults: symbol nodes hold <= 2*4 entries, B-tree nodes <= 2*16 children
+
+
+class WGroup:
+    """in-memory group: .attrs (name -> bytes | str | list of str | numpy array), .children (name -> WGroup | ndarray)"""
+
+    def __init__(self):
+        self.attrs = OrderedDict()
+        self.children = OrderedDict()
+
+    def group(self, path):
+        node = self
+        for part in [p for p in path.split("/") if p]:
+            nxt = node.children.get(part)
+            if nxt is None:
+                nxt = node.children[part] = WGroup()
+            if not isinstance(nxt, WGroup):
+                raise H5Error("%s is a dataset" % part)
+            node = nxt
+        return node
+
+    def dataset(self, path, arr):
+        """create_dataset(name) with '/' in the name lands in nested groups, exactly as h5py resolves it"""
+        parts = [p for p in path.split("/") if p]
+        g = self.group("/".join(parts[:-1])) if len(parts) > 1 else self
+        arr = np.asarray(arr)
+        g.children[parts[-1]] = arr if arr.flags.c_contiguous else arr.copy(order="C")
+
+
+def _pad8(b):
+    return b + b"\0" * (-len(b) % 8)
+
+
+def _dtype_msg(dt):
+    dt = np.dtype(dt)
+    if dt.kind == "f" and dt.itemsize in (4, 8):
+        exp_bits, man_bits = (8, 23) if dt.itemsize == 4 else (11, 52)
+        bias = (1 << (exp_bits - 1)) - 1
+        return (bytes([0x11, 0x20, dt.itemsize * 8 - 1, 0]) + struct.pack("<I", dt.itemsize) +
+                struct.pack("<HHBBBBI", 0, dt.itemsize * 8, man_bits, exp_bits, 0, man_bits, bias))
+    if dt.kind in "iu":
+        return (bytes([0x10, 0x08 if dt.kind == "i" else 0x00, 0, 0]) + struct.pack("<I", dt.itemsize) +
+                struct.pack("<HH", 0, dt.itemsize * 8))
+    if dt.kind == "S":
+        return bytes([0x13, 0x01, 0, 0]) + struct.pack("<I", dt.itemsize)      # null-padded ASCII
+    raise H5Error("cannot write dtype %s" % dt)
+
+
+def _space_msg(shape):
+    return bytes([1, len(shape), 0, 0, 0, 0, 0, 0]) + b"".join(struct.pack("<Q", int(d)) for d in shape)
+
+
+def _attr_value(v):
+    if isinstance(v, str):
+        v = v.encode("utf8")
+    if isinstance(v, bytes):
+        return np.array(v, dtype="S%d" % max(len(v), 1))
+    if isinstance(v, (list, tuple)):
+        bs = [s.encode("utf8") if isinstance(s, str) else bytes(s) for s in v]
+        return np.array(bs, dtype="S%d" % max([len(b) for b in bs] + [1]))
+    v = np.asarray(v)
+    return v if v.flags.c_contiguous else v.copy(order="C")
+
+
+class _Emitter:
+    def __init__(self):
+        self.buf = bytearray(96)               # superblock placeholder
+
+    def put(self, data):
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        addr = len(self.buf)
+        self.buf += data
+        return addr
+
+    def header(self, msgs):
+        """v1 object header from [(type, body bytes)]"""
+        body = b""
+        for mtype, data in msgs:
+            data = _pad8(data)
+            if len(data) > 0xFFF8:
+                raise H5Error("object header message of %d bytes exceeds the 64 KB limit of HDF5 (the same limit "
+                              "h5py / Keras hit for very long attribute lists)" % len(data))
+            body += struct.pack("<HHB3x", mtype, len(data), 0) + data
+        return self.put(struct.pack("<BBHII4x", 1, 0, len(msgs), 1, len(body)) + body)
+
+    def attr_msgs(self, attrs):
+        out = []
+        for name, v in attrs.items():
+            a = _attr_value(v)
+            nm = name.encode("utf8") + b"\0"
+            dt, sp = _dtype_msg(a.dtype), _space_msg(a.shape)
+            out.append((0x000C, struct.pack("<BBHHH", 1, 0, len(nm), len(dt), len(sp)) + _pad8(nm) + _pad8(dt) +
+                        _pad8(sp) + a.tobytes()))
+        return out
+
+    def dataset(self, arr):
+        arr = np.asarray(arr)
+        if not arr.flags.c_contiguous:
+            arr = arr.copy(order="C")
+        if arr.dtype.byteorder == ">":
+            arr = arr.astype(arr.dtype.newbyteorder("<"))
+        raw = arr.tobytes()
+        data = self.put(raw) if raw else _UNDEF
+        msgs = [(0x0001, _space_msg(arr.shape)), (0x0003, _dtype_msg(arr.dtype)),
+                (0x0005, bytes([2, 2, 2, 0])),                                   # fill value v2: late alloc, undefined
+                (0x0008, bytes([3, 1]) + struct.pack("<QQ", data, len(raw)))]
+        return self.header(msgs)
+
+    def group(self, g):
+        """returns (object header address, B-tree address, local heap address)"""
+        names = sorted(g.children, key=lambda s: s.encode("utf8"))
+        addrs = {}
+        for n in names:
+            c = g.children[n]
+            addrs[n] = self.group(c)[0] if isinstance(c, WGroup) else self.dataset(c)
+        # local heap: offset 0 holds the empty string (the leftmost B-tree key)
+        heap = bytearray(8)
+        off = {}
+        for n in names:
+            off[n] = len(heap)
+            heap += _pad8(n.encode("utf8") + b"\0")
+        free_at = len(heap)
+        heap += struct.pack("<QQ", 1, 32) + b"\0" * 16          # one free block (next = H5HL_FREE_NULL, size 32)
+        hdata = self.put(bytes(heap))
+        haddr = self.put(b"HEAP" + bytes(4) + struct.pack("<QQQ", len(heap), free_at, hdata))
+        # symbol nodes
+        snods = []                                               # (address, largest name offset)
+        per = 2 * _LEAF_K
+        for i in range(0, max(len(names), 1), per):
+            chunk = names[i:i + per]
+            ents = b"".join(struct.pack("<QQII16x", off[n], addrs[n], 0, 0) for n in chunk)
+            ents += bytes(40 * (per - len(chunk)))
+            a = self.put(b"SNOD" + struct.pack("<BBH", 1, 0, len(chunk)) + ents)
+            snods.append((a, off[chunk[-1]] if chunk else 0))
+        # B-tree levels
+        level, nodes = 0, snods
+        while True:
+            cap = 2 * _NODE_K
+            groups = [nodes[i:i + cap] for i in range(0, len(nodes), cap)]
+            size = 24 + (2 * cap + 1) * 8
+            base = self.put(bytes(size * len(groups)))
+            nxt = []
+            left_key = 0
+            for gi, grp in enumerate(groups):
+                a = base + gi * size
+                left = a - size if gi > 0 else _UNDEF
+                right = a + size if gi + 1 < len(groups) else _UNDEF
+                body = b"TREE" + struct.pack("<BBHQQ", 0, level, len(grp), left, right) + struct.pack("<Q", left_key)
+                for child, key in grp:
+                    body += struct.pack("<QQ", child, key)
+                    left_key = key
+                self.buf[a:a + len(body)] = body
+                nxt.append((a, grp[-1][1]))
+            if len(nxt) == 1:
+                btree = nxt[0][0]
+                break
+            level, nodes = level + 1, nxt
+        ohdr = self.header([(0x0011, struct.pack("<QQ", btree, haddr))] + self.attr_msgs(g.attrs))
+        return ohdr, btree, haddr
+
+    def finish(self, root):
+        ohdr, btree, haddr = self.group(root)
+        self.buf += b"\0" * (-len(self.buf) % 8)
+        sb = (SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + struct.pack("<HHI", _LEAF_K, _NODE_K, 0) +
+              struct.pack("<QQQQ", 0, _UNDEF, len(self.buf), _UNDEF) +
+              struct.pack("<QQII", 0, ohdr, 1, 0) + struct.pack("<QQ", btree, haddr))
+        assert len(sb) == 96
+        self.buf[0:96] = sb
+        return bytes(self.buf)
+
+
+def write_file(path, root):
+    """serialise the in-memory tree `root` (WGroup) to `path` atomically (temp file + rename)"""
+    import os
+    data = _Emitter().finish(root)
+    tmp = "%s.tmp%d" % (path, os.getpid())
+    with open(tmp, "wb") as fh:
+        fh.write(data)
+    os.replace(tmp, path)
+
+
+def keras_weights_group(g, layers, keras_version="2.0.8", backend="tensorflow"):
+    """K.engine/topology.py:2847-2873 save_weights_to_hdf5_group: `layers` = [(layer name, [(weight name, array)])]"""
+    g.attrs["layer_names"] = [n for n, _ in layers]
+    g.attrs["backend"] = backend
+    g.attrs["keras_version"] = keras_version
+    for lname, ws in layers:
+        lg = g.group(lname)
+        lg.attrs["weight_names"] = [wn for wn, _ in ws] if ws else np.zeros((0,), "S1")
+        for wn, arr in ws:
+            lg.dataset(wn, arr)
+    return g
+
+
+def read_nested_model_weights(path, model_group, swap="always"):
+    """The author's multi-GPU loaders (K.engine/topology.py:3171-3247 `..._by_name_mulgpu`, :3250-3330
+    `..._mulgpu_twomodelcombine`): the checkpoint was written from a `make_parallel` wrapper, so the real layers sit
+    one level down, under the group of the wrapped model (`model_1`, `denseu161`, `auto3d_residual_conv`), and carry
+    no weight_names attribute: the loaders list the HDF5 links (name order) and swap the first two, which turns
+    (bias, kernel) / (beta, gamma, moving_mean, moving_variance) / (.._beta, .._gamma) into Keras' weight order.
+    swap: 'always' (:3214, the mulgpu loader) or 'len2or4' (:3292-3293, the two-model loader).
+    Returns {layer name: [arrays]}; raises KeyError when `model_group` is absent, as f[...] does there."""
+    f = File(path)
+    g = f["model_weights"] if "layer_names" not in f.attrs and "model_weights" in f else f
+    mg = g[model_group]
+    out = OrderedDict()
+    for lname in mg.keys():
+        lg = mg[lname]
+        if not isinstance(lg, Group):
+            continue
+        names = lg.keys()
+        if len(names) >= 2 and (swap == "always" or len(names) in (2, 4)):
+            names[0], names[1] = names[1], names[0]
+        out[lname] = [np.asarray(lg[w]) for w in names]
+    return out

@@ -365,28 +365,153 @@ class Model:
     def get_grads_dict(self):
         return OrderedDict((n, self.ctx.get_layer_grads(n)) for n in self.ctx.by_layer)
 
-    def save_weights(self, filepath, overwrite=True):
+    # Keras 2.0.8 weight names inside a layer's HDF5 group (K.layers/convolutional.py:128-143, normalization.py:97-123,
+    # lib/custom_layers.py:53-57: the Scale layer names its variables '<layer>_gamma' / '<layer>_beta')
+    def _weight_names(self, layer):
+        kind = self.ctx.layer_kind[layer]
+        n = len(self.ctx.by_layer[layer])
+        if kind == "conv":
+            return ["%s/kernel:0" % layer, "%s/bias:0" % layer][:n]
+        if kind == "bn":
+            return ["%s/%s:0" % (layer, w) for w in ("gamma", "beta", "moving_mean", "moving_variance")]
+        if kind == "scale":
+            return ["%s/%s_gamma:0" % (layer, layer), "%s/%s_beta:0" % (layer, layer)]
+        raise ValueError(kind)
+
+    def _keras_layers(self):
+        return [(n, list(zip(self._weight_names(n), arrs))) for n, arrs in self.get_weights_dict().items()]
+
+    def _optimizer_state(self):
+        """SGD.weights (K.optimizers.py:173-174): [iterations] + one moment per trainable weight, in parameter order"""
+        ctx = self.ctx
+        out = [("SGD/iterations:0", np.array(self.optimizer.iterations if self.optimizer else 0, dtype=np.int64))]
+        k = 0
+        for p in ctx.params:
+            if not p.trainable:
+                continue
+            v = ctx._to_keras(p, ctx.V[p.offset:p.offset + p.numel])
+            out.append(("training/SGD/Variable%s:0" % ("_%d" % k if k else ""), v))
+            k += 1
+        return out
+
+    def _set_optimizer_state(self, arrays):
+        """inverse of _optimizer_state: [iterations, moment...] (names are TensorFlow's auto-numbering; order decides)"""
+        ctx = self.ctx
+        tr = [p for p in ctx.params if p.trainable]
+        if len(arrays) != len(tr) + 1:
+            raise ValueError("optimizer state has %d arrays, the model needs %d" % (len(arrays), len(tr) + 1))
+        if self.optimizer is not None:
+            self.optimizer.iterations = int(np.asarray(arrays[0]).reshape(-1)[0])
+        for p, a in zip(tr, arrays[1:]):
+            t = torch.from_numpy(ctx._to_internal(p, a).reshape(-1)).to(ctx.dev)
+            ctx.V[p.offset:p.offset + p.numel] = t
+
+    @staticmethod
+    def _is_hdf5_name(filepath):
+        return str(filepath).lower().endswith((".h5", ".hdf5", ".hdf"))
+
+    def save_weights(self, filepath, overwrite=True, nested_under=None):
+        """K.engine/topology.py:2555-2588.  `.h5` / `.hdf5` names get a real Keras-layout HDF5 file (written natively by
+        h5lite: the image has no h5py); other names the `.npz` container of round 1.  `nested_under='model_1'` writes
+        the layout a `make_parallel` wrapper produced in the reference (every layer one level down, under the wrapped
+        model's group), which is what its `by_gpu` loaders expect (topology.py:3171-3330)."""
+        if not overwrite and os.path.isfile(filepath):
+            raise IOError("%s exists and overwrite=False" % filepath)
+        if not self._is_hdf5_name(filepath):
+            return self._save_npz(filepath, with_optimizer=False)
+        from . import h5lite
+        root = h5lite.WGroup()
+        self._fill_weights_group(root, nested_under)
+        h5lite.write_file(filepath, root)
+
+    def _fill_weights_group(self, g, nested_under=None):
+        from . import h5lite
+        layers = self._keras_layers()
+        if nested_under:
+            layers = [(nested_under, [w for _, ws in layers for w in ws])]
+        h5lite.keras_weights_group(g, layers)
+
+    def save(self, filepath, overwrite=True, include_optimizer=True):
+        """K.models.py:31-170 `save_model`: model_weights group + optimizer state + training_config.  The graph topology
+        is NOT serialised (model_config carries the constructor identity only): the drop-in rebuilds a model from its
+        constructor, as every reference script does before load_weights."""
+        if not overwrite and os.path.isfile(filepath):
+            raise IOError("%s exists and overwrite=False" % filepath)
+        if not self._is_hdf5_name(filepath):
+            return self._save_npz(filepath, with_optimizer=include_optimizer)
+        import json
+        from . import h5lite
+        root = h5lite.WGroup()
+        root.attrs["keras_version"] = "2.0.8"
+        root.attrs["backend"] = "tensorflow"
+        root.attrs["model_config"] = json.dumps({"class_name": "Model", "config": {
+            "name": self.name, "constructor": {"kind": self.kind, "variant": self.variant,
+                                               "input_shape": list(self.input_shape)}, "layers": []}})
+        self._fill_weights_group(root.group("model_weights"))
+        if include_optimizer and self.optimizer is not None:
+            opt = self.optimizer
+            root.attrs["training_config"] = json.dumps({
+                "optimizer_config": {"class_name": "SGD", "config": {"lr": opt.lr, "momentum": opt.momentum,
+                                                                     "decay": opt.decay, "nesterov": True}},
+                "loss": ["weighted_crossentropy"], "metrics": None, "sample_weight_mode": None, "loss_weights": None})
+            og = root.group("optimizer_weights")
+            st = self._optimizer_state()
+            og.attrs["weight_names"] = [n for n, _ in st]
+            for n, a in st:
+                og.dataset(n, a)
+        h5lite.write_file(filepath, root)
+
+    def _save_npz(self, filepath, with_optimizer):
         flat = {}
         for n, arrs in self.get_weights_dict().items():
             for i, a in enumerate(arrs):
                 flat["%s/%d" % (n, i)] = a
         flat["__model_name__"] = np.array(self.name or "")
-        with open(filepath, "wb") as f:
+        if with_optimizer and self.optimizer is not None:
+            for i, (_, a) in enumerate(self._optimizer_state()):
+                flat["__optimizer__/%d" % i] = a
+        tmp = "%s.tmp%d" % (filepath, os.getpid())
+        with open(tmp, "wb") as f:
             np.savez(f, **flat)
+        os.replace(tmp, filepath)       # atomic: a reader never sees a torn file
 
-    save = save_weights
-
-    def load_weights(self, filepath, by_name=False, by_gpu=False, two_model=False, by_flag=False):
-        """topology.py:2590-2640.  by_name (and the author's by_gpu / two_model loaders, which select an HDF5 group
-        and then match by layer name) skip layers absent from the file; the default requires every layer."""
+    def load_optimizer_weights(self, filepath):
+        """restore SGD iterations + momentum buffers saved by `save` (Keras does this in load_model, K.models.py:249-272)"""
         with open(filepath, "rb") as fh:
             magic = fh.read(8)
-        lenient = by_name or by_gpu or two_model
         if magic == b"\x89HDF\r\n\x1a\n":
-            # a Keras HDF5 file (save_weights / save of the reference, e.g. densenet161_weights_tf.h5, model_best.hdf5):
-            # decoded by the pure-Python reader, same Keras weight shapes / per-layer order as the npz container
             from . import h5lite
-            d = OrderedDict((n, arrs) for n, arrs in h5lite.read_keras_weights(filepath).items() if arrs)
+            f = h5lite.File(filepath)
+            if "optimizer_weights" not in f:
+                raise ValueError("%s holds no optimizer_weights group" % filepath)
+            og = f["optimizer_weights"]
+            names = [(n if isinstance(n, bytes) else bytes(n)).rstrip(b"\0").decode("utf8")
+                     for n in np.asarray(og.attrs["weight_names"]).reshape(-1)]
+            arrays = [np.asarray(og[n]) for n in names]
+        else:
+            z = np.load(filepath, allow_pickle=False)
+            keys = sorted([k for k in z.files if k.startswith("__optimizer__/")], key=lambda k: int(k.split("/")[1]))
+            if not keys:
+                raise ValueError("%s holds no optimizer state" % filepath)
+            arrays = [z[k] for k in keys]
+        self._set_optimizer_state(arrays)
+
+    def load_weights(self, filepath, by_name=False, by_gpu=False, two_model=False, by_flag=False):
+        """K.engine/topology.py:2590-2640 incl. the author's loaders: `by_name` skips layers absent from the file;
+        `by_name + by_gpu` reads the layers under the wrapped model's group `model_1` (:3171-3247); `+ two_model`
+        under `denseu161` (by_flag) or `auto3d_residual_conv` (:3250-3330) -- the 2D DenseUNet of a multi-GPU
+        pre-training run loaded into the hybrid (train_hybrid.py:146).  The default requires every layer of the model.
+        A name-based load that matches NO layer raises instead of silently keeping the initial weights."""
+        with open(filepath, "rb") as fh:
+            magic = fh.read(8)
+        lenient = bool(by_name)
+        if magic == b"\x89HDF\r\n\x1a\n":
+            from . import h5lite
+            if by_name and by_gpu:
+                grp = ("denseu161" if by_flag else "auto3d_residual_conv") if two_model else "model_1"
+                d = h5lite.read_nested_model_weights(filepath, grp, swap="len2or4" if two_model else "always")
+            else:
+                d = OrderedDict((n, arrs) for n, arrs in h5lite.read_keras_weights(filepath).items() if arrs)
             extra = [n for n in d if n not in self.ctx.by_layer]
             if extra and not lenient:
                 raise ValueError("weights file has layers the model lacks: %s... (use by_name=True)" % extra[:5])
@@ -394,7 +519,7 @@ class Model:
             z = np.load(filepath, allow_pickle=False)
             groups = OrderedDict()
             for k in z.files:
-                if k == "__model_name__":
+                if k.startswith("__"):
                     continue
                 n, i = k.rsplit("/", 1)
                 groups.setdefault(n, {})[int(i)] = z[k]
@@ -403,6 +528,10 @@ class Model:
             missing = [n for n in self.ctx.by_layer if n not in d]
             if missing:
                 raise ValueError("weights file lacks layers: %s..." % missing[:5])
+        elif not any(n in self.ctx.by_layer for n in d):
+            raise ValueError("%s: none of its %d layers (%s...) matches a layer of model %s -- nothing would be loaded; for "
+                             "a checkpoint written from a make_parallel wrapper pass by_name=True, by_gpu=True"
+                             % (filepath, len(d), list(d)[:3], self.name))
         self.set_weights_dict(d, strict=not lenient)
 
     def count_params(self):
@@ -421,6 +550,7 @@ class ModelCheckpoint:
     def __init__(self, filepath, monitor="loss", verbose=0, save_best_only=False, save_weights_only=False, mode="min",
                  period=1):
         self.filepath, self.monitor, self.verbose, self.save_best_only, self.period = filepath, monitor, verbose, save_best_only, period
+        self.save_weights_only = save_weights_only
         self.best = np.inf
         self.model = None
         self.epochs_since = 0
@@ -442,7 +572,10 @@ class ModelCheckpoint:
         if not _is_io_rank():
             return            # every rank holds the same weights after the all-reduced step; rank 0 writes the file
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        self.model.save(path)
+        if self.save_weights_only:
+            self.model.save_weights(path)      # K.callbacks.py:425-428
+        else:
+            self.model.save(path)
 
 
 def make_parallel(model, gpu_count, mini_batch=None):
