@@ -32,6 +32,9 @@ struct ConvK {
   float* stats_partial;       // [stats_slots][2][Cout] float, zeroed by the caller; NULL = off
   const float* stats_shift;   // [Cout] shift against E[x^2]-E[x]^2 cancellation (any value near the mean)
   int stats_slots;
+  // split-K (ring kernel): gridDim.z workgroups share one output tile; partial accumulators meet in sk_ws
+  float* sk_ws;               // [tile][split][wave][fragment][lane] f32x4, write-through stores
+  unsigned* sk_cnt;           // [tile] arrival tickets, zero between launches
 };
 
 // byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][128 B] LDS tile.

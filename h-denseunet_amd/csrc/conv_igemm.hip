@@ -978,6 +978,49 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 // slot about to be refilled) -> issue tile t+NS-1 -> MFMAs on tile t.  Every wave issues exactly A_IT + B_IT DMAs
 // per tile (invalid rows fetch the zero page) so the vmcnt immediate is uniform.  Used for small grids (< 1
 // workgroup per CU), where latency rather than occupancy limits the K loop and one workgroup may take the LDS.
+// split-K meeting point of the ring kernel (hdu_platform.h: hdu_store_wt16 / hdu_acquire_agent).  Every split stores its
+// accumulator fragments lane-linear ([wave][fragment][lane] x 16 B: one coalesced 1 KiB store per fragment and wave),
+// drains, and takes a ticket; the last arriver sums all splits' fragments (same lane mapping, plain 16-byte loads after
+// ONE agent-scope acquire) and returns true: it alone runs the ordinary epilogue.
+template <int TM, int TN>
+__device__ __forceinline__ bool splitk_combine(const ConvK& p, f32x4 (&acc)[TM][TN], char* smem, unsigned tile, int z, int S,
+                                               int wave, int lane, int tid) {
+  constexpr int FR = TM * TN;
+  constexpr size_t SPLIT_FLOATS = (size_t)4 * FR * 64 * 4;
+  float* base = p.sk_ws + (size_t)tile * (size_t)S * SPLIT_FLOATS;
+  float* mine = base + (size_t)z * SPLIT_FLOATS + ((size_t)wave * FR) * 256 + lane * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) hdu_store_wt16(mine + (i * TN + j) * 256, acc[i][j]);
+  HDU_WAIT_STORES();                                  // every storing wave drains its write-through stores ...
+  __syncthreads();                                    // ... before ONE lane announces the workgroup's arrival
+  int* flag = (int*)smem;                             // the operand stages are dead: all MFMA reads are behind the barrier
+  if (tid == 0) *flag = hdu_ticket(p.sk_cnt + tile) == (unsigned)(S - 1) ? 1 : 0;
+  __syncthreads();
+  if (*flag == 0) return false;
+  if (tid == 0) hdu_acquire_agent();
+  __syncthreads();
+  // fixed summation order 0..S-1 whichever split arrives last (its own fragments are re-read too): the result does not
+  // depend on the arrival order, so a layer is reproducible run to run
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) {
+    const float* o = base + (size_t)s * SPLIT_FLOATS + ((size_t)wave * FR) * 256 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 v = *(const f32x4*)(o + (i * TN + j) * 256);
+        acc[i][j] += v;
+      }
+  }
+  if (tid == 0) hdu_store_agent_u32(p.sk_cnt + tile, 0u);     // the counter is zero again for the next launch
+  return true;
+}
+
 template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_n() {
   if constexpr (N == 0) { HDU_WAIT_VMCNT(0); }
   else if constexpr (N == 1) { HDU_WAIT_VMCNT(1); }
@@ -1094,7 +1137,12 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
       rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
     }
   }
-  int k = kcl * CH;
+  // split-K: gridDim.z workgroups share this output tile, each takes a contiguous range of K steps
+  const int nk_all = (p.Ktot + BK - 1) / BK;
+  const int nsplit = (int)gridDim.z, split = (int)blockIdx.z;
+  const int kt_begin = nsplit > 1 ? (int)((long long)nk_all * split / nsplit) : 0;
+  const int kt_end = nsplit > 1 ? (int)((long long)nk_all * (split + 1) / nsplit) : nk_all;
+  int k = kt_begin * BK + kcl * CH;
   int c, kd, kh, kw, tap_i;
   {
     const int tap = k / p.Cin;
@@ -1164,7 +1212,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.Ktot + BK - 1) / BK;
+  const int nk = kt_end - kt_begin;
 #pragma unroll
   for (int pre = 0; pre < NS - 1; ++pre)
     if (pre < nk) issue_tile(pre);
@@ -1199,6 +1247,10 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
+  if (nsplit > 1) {
+    HDU_WAIT_VMCNT(0);
+    if (!splitk_combine<TM, TN>(p, acc, smem, blockIdx.y * gridDim.x + blockIdx.x, split, nsplit, wave, lane, tid)) return;
+  }
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NS * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
 }
 
@@ -1938,6 +1990,10 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   k->stats_slots = d->stats_slots;
   if (k->stats_partial && (!k->stats_shift || k->stats_slots <= 0 || d->accumulate))
     return hdu_set_error(HDU_ERR_ARG, "conv: epilogue statistics need stats_shift, stats_slots > 0 and accumulate == 0");
+  k->sk_ws = wgrad ? nullptr : (float*)d->splitk_ws;
+  k->sk_cnt = wgrad ? nullptr : d->splitk_counters;
+  if (k->sk_ws && ((uintptr_t)k->sk_ws % 16 || !k->sk_cnt))
+    return hdu_set_error(HDU_ERR_ARG, "conv: splitk_ws must be 16-byte aligned and come with splitk_counters");
   k->xcd_swizzle = g_tuning[HDU_TUNE_XCD_SWIZZLE];
   k->vec_out = 1;
   k->debug_flags = g_tuning[HDU_TUNE_DEBUG];
@@ -1954,8 +2010,29 @@ static bool igemm_fast_ok(const ConvK& k) {
   return span < (1ll << 31);
 }
 
+// Split-K factor of a small-grid launch (ring kernel).  A grid of <= 128 workgroups leaves half the chip idle and each
+// busy compute unit is bound by what it alone can pull from L2 (measured: 14-20 KB per K step at ~1 us per step whatever
+// the MFMA work), so the K steps are dealt to S workgroups per tile until ~256 workgroups run, keeping >= 3 K steps per
+// split and S <= 16 (the last arriver reads S-1 partial tiles).  `bytes`: scratch the launch needs.
+static int choose_splitk(long long nblk, int nk, int bm, int bn, size_t* bytes) {
+  *bytes = 0;
+  const int mode = g_tuning[HDU_TUNE_SPLITK];
+  if (mode == 1 || nblk > 128) return 1;
+  int S = mode >= 2 ? mode : (int)((256 + nblk - 1) / nblk);
+  if (S > nk / 3) S = nk / 3;
+  if (S > 16) S = 16;
+  if (S < 2) return 1;
+  *bytes = (size_t)nblk * (size_t)S * (size_t)bm * (size_t)bn * sizeof(float);
+  return S;
+}
+
+static bool igemm_ring_ok(long long nblk, int Ktot, int stage_bytes, int nsd) {
+  const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
+  return stage_bytes * nsd <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && Ktot > g_tuning[HDU_TUNE_RING_MIN_K]));
+}
+
 template <typename T, int BM, int BN, int WMv, int WNv>
-static void launch_igemm(const ConvK& k, hipStream_t s) {
+static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
   dim3 grid((unsigned)((k.M + BM - 1) / BM), (unsigned)((k.Cout + BN - 1) / BN), 1);
   if (k.pro_a == nullptr && k.skip == nullptr && k.vec_out) {
     // deep ring when the grid cannot fill the chip (latency-bound K loop, LDS is free); else 2 stages x 3 blocks/CU
@@ -1964,7 +2041,11 @@ static void launch_igemm(const ConvK& k, hipStream_t s) {
     const long long nblk = (long long)grid.x * grid.y;
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
     const bool fast = igemm_fast_ok(k);
-    if (STAGE * NSD <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128))) {
+    if (igemm_ring_ok(nblk, k.Ktot, STAGE, NSD)) {
+      constexpr int BK = 8 * Chunk<T>::CH;
+      size_t need;
+      const int S = choose_splitk(nblk, (k.Ktot + BK - 1) / BK, BM, BN, &need);
+      if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) grid.z = (unsigned)S;
       if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, k);
     } else if (mode == 3) {
@@ -2002,22 +2083,22 @@ template <int BM, int BN> struct WaveLayout {           // (waves along M, waves
 };
 
 template <typename T, int BM>
-static void dispatch_igemm_bn(const ConvK& k, int bn, hipStream_t s) {
+static void dispatch_igemm_bn(const ConvK& k, int bn, size_t skb, hipStream_t s) {
   switch (bn) {
-    case 128: launch_igemm<T, BM, 128, WaveLayout<BM, 128>::WM, WaveLayout<BM, 128>::WN>(k, s); return;
-    case 96: launch_igemm<T, BM, 96, WaveLayout<BM, 96>::WM, WaveLayout<BM, 96>::WN>(k, s); return;
-    case 64: launch_igemm<T, BM, 64, WaveLayout<BM, 64>::WM, WaveLayout<BM, 64>::WN>(k, s); return;
-    case 48: launch_igemm<T, BM, 48, WaveLayout<BM, 48>::WM, WaveLayout<BM, 48>::WN>(k, s); return;
-    default: launch_igemm<T, BM, 32, WaveLayout<BM, 32>::WM, WaveLayout<BM, 32>::WN>(k, s); return;
+    case 128: launch_igemm<T, BM, 128, WaveLayout<BM, 128>::WM, WaveLayout<BM, 128>::WN>(k, skb, s); return;
+    case 96: launch_igemm<T, BM, 96, WaveLayout<BM, 96>::WM, WaveLayout<BM, 96>::WN>(k, skb, s); return;
+    case 64: launch_igemm<T, BM, 64, WaveLayout<BM, 64>::WM, WaveLayout<BM, 64>::WN>(k, skb, s); return;
+    case 48: launch_igemm<T, BM, 48, WaveLayout<BM, 48>::WM, WaveLayout<BM, 48>::WN>(k, skb, s); return;
+    default: launch_igemm<T, BM, 32, WaveLayout<BM, 32>::WM, WaveLayout<BM, 32>::WN>(k, skb, s); return;
   }
 }
 
 template <typename T>
-static void dispatch_igemm(const ConvK& k, hipStream_t s) {
+static void dispatch_igemm(const ConvK& k, size_t skb, hipStream_t s) {
   int bm, bn;
   choose_igemm(k, &bm, &bn);
-  if (bm == 64) dispatch_igemm_bn<T, 64>(k, bn, s);
-  else dispatch_igemm_bn<T, 128>(k, bn, s);
+  if (bm == 64) dispatch_igemm_bn<T, 64>(k, bn, skb, s);
+  else dispatch_igemm_bn<T, 128>(k, bn, skb, s);
 }
 
 static bool fprop_halo_ok(const ConvK& k, int dtype) {
@@ -2025,7 +2106,10 @@ static bool fprop_halo_ok(const ConvK& k, int dtype) {
          k.KH == 3 && k.KW == 3 && k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 &&
          (k.ud | k.uh | k.uw) == 0 && k.Di == 1 && k.Cin % 8 == 0 && k.We >= 32 && k.He >= 4 &&
          // measured: pays when the K loop is long (>= 4 chunks of 32 channels) and one N tile covers Cout
-         k.Cin >= 128 && k.Cout <= 96;
+         k.Cin >= 128 && k.Cout <= 96 &&
+         // ... and when its 4x32-pixel tiles fill the chip: below that the im2col ring kernel with split-K spreads the
+         // layer over more compute units (each halo workgroup has to pull the whole 9-tap filter tile)
+         (long long)k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32) >= (g_tuning[HDU_TUNE_HALO_MIN_TILES] > 0 ? g_tuning[HDU_TUNE_HALO_MIN_TILES] : 128);
 }
 
 static int choose_halo_bn(const ConvK& k) {
@@ -2060,9 +2144,25 @@ extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
     }
     return hdu_check_launch("conv_fprop(halo)");
   }
-  if (d->dtype == HDU_BF16) dispatch_igemm<bf16_t>(k, (hipStream_t)stream);
-  else dispatch_igemm<float>(k, (hipStream_t)stream);
+  if (d->dtype == HDU_BF16) dispatch_igemm<bf16_t>(k, d->splitk_ws_bytes, (hipStream_t)stream);
+  else dispatch_igemm<float>(k, d->splitk_ws_bytes, (hipStream_t)stream);
   return hdu_check_launch("conv_fprop");
+}
+
+extern "C" size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d) {
+  ConvK k;
+  if (fill_convk(d, &k, false)) return 0;
+  if (k.M == 0 || fprop_halo_ok(k, d->dtype) || k.pro_a != nullptr || k.skip != nullptr) return 0;
+  int bm, bn;
+  choose_igemm(k, &bm, &bn);
+  const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
+  const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
+  const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;
+  if (!igemm_ring_ok(nblk, k.Ktot, stage, nsd)) return 0;
+  const int bk = d->dtype == HDU_BF16 ? 64 : 32;
+  size_t need;
+  choose_splitk(nblk, (k.Ktot + bk - 1) / bk, bm, bn, &need);
+  return need;
 }
 
 template <typename T, int BCO>
@@ -2307,7 +2407,7 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
     const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
     const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;
-    const bool ring = dma && stage * nsd <= 160 * 1024 && (mode == 6 || (mode == 2 && nblk <= 256 && k.Ktot > 8 * 128));
+    const bool ring = dma && igemm_ring_ok(nblk, k.Ktot, stage, nsd);
     const char* fast = igemm_fast_ok(k) ? "true" : "false";
     if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, nsd, fast);
     else if (dma && mode == 3) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, 3, false>", t, bm, bn, wm, 4 / wm);

@@ -209,6 +209,22 @@ __device__ __forceinline__ void hdu_store_agent_u32(unsigned* p, unsigned v) {
 #define HDU_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// split-K hand-off (cdna_hip_programming.md Guideline 16, recipe R1): the partial tile is stored WRITE-THROUGH (sc1: the
+// bytes leave the XCD's L2, no release fence -- a release would write back every dirty line the previous kernel left
+// there), every storing wave drains its stores, the workgroup meets at a barrier and ONE lane takes a ticket with a
+// relaxed agent-scope atomic; the tile's last arriver issues ONE agent-scope acquire (drops its CU's L1) and reads the
+// other partial tiles with plain loads.  Placement-independent: no assumption on which XCD runs which split.
+#ifdef HDU_EMU
+__device__ __forceinline__ void hdu_store_wt16(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void hdu_acquire_agent() {}
+#else
+__device__ __forceinline__ void hdu_store_wt16(float* p, f32x4 v) {
+  // 16-byte global store with sc1 (write-through); the s_nop keeps the data registers alive until the store has read them
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void hdu_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+#endif
+
 // counter-based hash RNG for dropout masks (stateless; fwd and bwd regenerate the same mask)
 __host__ __device__ __forceinline__ unsigned hdu_hash32(unsigned long long idx, unsigned seed) {
   unsigned h = (unsigned)idx * 0x9E3779B1u;

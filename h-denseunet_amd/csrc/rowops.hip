@@ -463,6 +463,28 @@ extern "C" int hdu_bn_fold(int C, const float* mean, const float* var, const flo
   return hdu_check_launch("bn_fold");
 }
 
+// all inference-mode folds of a pass in one launch: block -> (entry, 256-channel block) by binary search over begins[]
+__global__ __launch_bounds__(256) void bn_fold_batched_kernel(const hdu_fold_entry* __restrict__ table,
+                                                              const unsigned* __restrict__ begins, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (begins[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hdu_fold_entry e = table[lo];
+  const int c = (int)(blockIdx.x - begins[lo]) * 256 + (int)threadIdx.x;
+  if (c >= e.C) return;
+  bn_fold_channel(c, e.mean[c], e.var[c], e.gamma, e.beta, e.eps, e.sgamma, e.sbeta, e.a, e.b, e.rstd, nullptr, nullptr,
+                  0.f);
+}
+
+extern "C" int hdu_bn_fold_batched(const hdu_fold_entry* table, const uint32_t* begins, int n, uint32_t total_blocks,
+                                   void* stream) {
+  if (!table || !begins || n <= 0 || total_blocks == 0) return hdu_set_error(HDU_ERR_ARG, "bn_fold_batched: bad args");
+  HDU_LAUNCH(bn_fold_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, begins, n);
+  return hdu_check_launch("bn_fold_batched");
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(int C, float invM, int batch_stats, const float* s1,
                                                           const float* s2, const float* gamma, const float* beta,
                                                           const float* sgamma, const float* rstd, float* k1,

@@ -129,6 +129,12 @@ class Ctx:
         self.P = self.G = self.V = None
         self.n_trainable = 0
         self.convs = []
+        self.bns = []
+        self._fold_plans = {}
+        self.prefolded_pass = -1
+        # inference-mode BN folds depend on parameters only: all of them (every BN in a predict pass, the frozen ones in
+        # a training pass) run as ONE launch at the head of the forward instead of one launch per layer
+        self.batch_fold = os.environ.get("HDU_BATCH_FOLD", "1") == "1"
         self._scratch = {}
         self.ws_bytes = 1 << 16
         self.ws = None
@@ -349,8 +355,24 @@ class Ctx:
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
             self._prep_table = torch.from_numpy(raw).to(self.dev)
 
+    def _fold_plan(self, phase):
+        if phase not in self._fold_plans:
+            ents = []
+            for bn in self.bns:
+                if bn.mode == "batch" and phase == 1:
+                    continue
+                ents.append((bn.C, bn.eps, bn.mm.data, bn.mv.data, bn.gamma.data, bn.beta.data,
+                             bn.sg.data if bn.sg else None, bn.sb.data if bn.sb else None, bn.a, bn.b, bn.rstd))
+            self._fold_plans[phase] = ops.FoldPlan(ents) if ents else None
+        return self._fold_plans[phase]
+
     def run_forward(self):
         self.pass_id += 1
+        if self.batch_fold and self.finalized:
+            plan = self._fold_plan(self.learning_phase)
+            if plan is not None:
+                plan.run()
+                self.prefolded_pass = self.pass_id
         if self.learning_phase == 1 and self.stats_acc is not None:
             self.stats_acc.zero_()          # ONE memset for the epilogue-statistics accumulators of every layer
         for f in self.fwd:
@@ -442,6 +464,7 @@ class BNLayer:
         self.mean_used = None
         self.batch_now = False
         self.folded_pass = -1
+        ctx.bns.append(self)
         self.s12 = v(2 * C)
 
     def any_trainable(self):
@@ -459,6 +482,9 @@ class BNLayer:
         self.batch_now = self.mode == "batch" and ctx.learning_phase == 1
         if self.batch_now and self.folded_pass == ctx.pass_id:
             return None  # the statistics reduction of this pass already folded this BN (StatsOp.fused)
+        if not self.batch_now and ctx.prefolded_pass == ctx.pass_id:
+            self.mean_used = self.mm.data
+            return None  # folded with every other inference-mode BN by the batched launch at the head of this pass
         if self.batch_now:
             mean, var = xvar.stats()
             self.mean_used = mean

@@ -41,6 +41,9 @@ class ConvDesc(ctypes.Structure):
         ("stats_partial", c_p),
         ("stats_shift", c_p),
         ("stats_slots", c_int),
+        ("splitk_ws", c_p),
+        ("splitk_ws_bytes", c_sz),
+        ("splitk_counters", c_p),
     ]
 
 
@@ -49,12 +52,18 @@ class PrepEntry(ctypes.Structure):
                 ("Cout", ctypes.c_int32), ("T", ctypes.c_int32), ("Cin", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
+class FoldEntry(ctypes.Structure):
+    _fields_ = [("mean", c_p), ("var", c_p), ("gamma", c_p), ("beta", c_p), ("sgamma", c_p), ("sbeta", c_p),
+                ("a", c_p), ("b", c_p), ("rstd", c_p), ("C", ctypes.c_int32), ("eps", c_f)]
+
+
 _SIGS = {
     "hdu_last_error": (ctypes.c_char_p, []),
     "hdu_backend": (ctypes.c_char_p, []),
     "hdu_abi_version": (c_int, []),
     "hdu_set_tuning": (c_int, [c_int, c_int]),
     "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
+    "hdu_conv_splitk_ws_bytes": (c_sz, [ctypes.POINTER(ConvDesc)]),
     "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
@@ -63,6 +72,7 @@ _SIGS = {
     "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
     "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),
     "hdu_bn_fold": (c_int, [c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "hdu_bn_fold_batched": (c_int, [c_p, c_p, c_int, ctypes.c_uint32, c_p]),
     "hdu_bn_stats_fold": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p,
                                   c_p, c_f, c_p, c_sz, c_p]),
     "hdu_bn_bwd_reduce_coef": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_int,
@@ -130,6 +140,42 @@ def _bind(path):
     return lib
 
 
+def _apply_env_tuning(lib):
+    """developer knobs (A/B runs): HDU_* environment variables -> hdu_set_tuning"""
+    if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
+        lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
+    if "HDU_SPLITK" in os.environ:
+        lib.hdu_set_tuning(13, int(os.environ["HDU_SPLITK"]))
+    if "HDU_HALO_MIN_TILES" in os.environ:
+        lib.hdu_set_tuning(15, int(os.environ["HDU_HALO_MIN_TILES"]))
+    if "HDU_RING_MIN_K" in os.environ:
+        lib.hdu_set_tuning(14, int(os.environ["HDU_RING_MIN_K"]))
+    if "HDU_RED_WGS" in os.environ:
+        lib.hdu_set_tuning(11, int(os.environ["HDU_RED_WGS"]))
+    if "HDU_ROW_WGS" in os.environ:
+        lib.hdu_set_tuning(12, int(os.environ["HDU_ROW_WGS"]))
+    if "HDU_FUSED_FINALIZE" in os.environ:
+        lib.hdu_set_tuning(10, int(os.environ["HDU_FUSED_FINALIZE"]))
+    if "HDU_NO_HALO_FPROP" in os.environ:
+        lib.hdu_set_tuning(9, int(os.environ["HDU_NO_HALO_FPROP"]))
+    if "HDU_NO_HALO" in os.environ:
+        lib.hdu_set_tuning(8, int(os.environ["HDU_NO_HALO"]))
+    if "HDU_HALO_TARGET" in os.environ:
+        lib.hdu_set_tuning(7, int(os.environ["HDU_HALO_TARGET"]))
+    if "HDU_MAX_BN" in os.environ:
+        lib.hdu_set_tuning(6, int(os.environ["HDU_MAX_BN"]))
+    if "HDU_NO_FAST" in os.environ:
+        lib.hdu_set_tuning(5, int(os.environ["HDU_NO_FAST"]))
+    if "HDU_DEBUG_FLAGS" in os.environ:
+        lib.hdu_set_tuning(4, int(os.environ["HDU_DEBUG_FLAGS"]))
+    if "HDU_XCD_SWIZZLE" in os.environ:
+        lib.hdu_set_tuning(3, int(os.environ["HDU_XCD_SWIZZLE"]))
+    if "HDU_WGRAD_TARGET" in os.environ:
+        lib.hdu_set_tuning(2, int(os.environ["HDU_WGRAD_TARGET"]))
+    if "HDU_WGRAD_MIN_STEPS" in os.environ:
+        lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
+
+
 def load(path=None):
     """Bind the product library (gfx950).  Raises if it has not been built."""
     global _lib, _backend
@@ -140,32 +186,7 @@ def load(path=None):
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
     _lib = _bind(path)
     _backend = _lib.hdu_backend().decode()
-    if "HDU_DMA_STAGES" in os.environ:      # developer knobs (A/B runs)
-        _lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
-    if "HDU_RED_WGS" in os.environ:
-        _lib.hdu_set_tuning(11, int(os.environ["HDU_RED_WGS"]))
-    if "HDU_ROW_WGS" in os.environ:
-        _lib.hdu_set_tuning(12, int(os.environ["HDU_ROW_WGS"]))
-    if "HDU_FUSED_FINALIZE" in os.environ:
-        _lib.hdu_set_tuning(10, int(os.environ["HDU_FUSED_FINALIZE"]))
-    if "HDU_NO_HALO_FPROP" in os.environ:
-        _lib.hdu_set_tuning(9, int(os.environ["HDU_NO_HALO_FPROP"]))
-    if "HDU_NO_HALO" in os.environ:
-        _lib.hdu_set_tuning(8, int(os.environ["HDU_NO_HALO"]))
-    if "HDU_HALO_TARGET" in os.environ:
-        _lib.hdu_set_tuning(7, int(os.environ["HDU_HALO_TARGET"]))
-    if "HDU_MAX_BN" in os.environ:
-        _lib.hdu_set_tuning(6, int(os.environ["HDU_MAX_BN"]))
-    if "HDU_NO_FAST" in os.environ:
-        _lib.hdu_set_tuning(5, int(os.environ["HDU_NO_FAST"]))
-    if "HDU_DEBUG_FLAGS" in os.environ:
-        _lib.hdu_set_tuning(4, int(os.environ["HDU_DEBUG_FLAGS"]))
-    if "HDU_XCD_SWIZZLE" in os.environ:
-        _lib.hdu_set_tuning(3, int(os.environ["HDU_XCD_SWIZZLE"]))
-    if "HDU_WGRAD_TARGET" in os.environ:
-        _lib.hdu_set_tuning(2, int(os.environ["HDU_WGRAD_TARGET"]))
-    if "HDU_WGRAD_MIN_STEPS" in os.environ:
-        _lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
+    _apply_env_tuning(_lib)
     return _lib
 
 
@@ -178,6 +199,7 @@ def use_emulator_for_tests():
     _lib = _bind(path)
     _backend = _lib.hdu_backend().decode()
     assert _backend == "emu-x86"
+    _apply_env_tuning(_lib)
     return _lib
 
 

@@ -86,10 +86,27 @@ class Act:
         return self
 
 
+# split-K scratch of hdu_conv_fprop (include/hdu.h): one float32 buffer + ticket counters per process, shared by every
+# launch (launches of one stream are ordered; the filter gradients on the side stream never use it).  Sized for the
+# library's worst case: 128 tiles x 16 splits x 64x128 outputs.
+_SPLITK = None
+SPLITK_BYTES = 128 * 16 * 64 * 128 * 4
+
+
+def splitk_scratch():
+    global _SPLITK
+    if _SPLITK is None:
+        _SPLITK = (torch.empty(SPLITK_BYTES // 4, dtype=torch.float32, device=device()),
+                   torch.zeros(512, dtype=torch.int32, device=device()))
+    return _SPLITK
+
+
 def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
               bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None):
     """x: Act (stored input), y: Act (output), K=(KD,KH,KW)."""
     d = ConvDesc()
+    ws, cnt = splitk_scratch()
+    d.splitk_ws, d.splitk_ws_bytes, d.splitk_counters = ws.data_ptr(), SPLITK_BYTES, cnt.data_ptr()
     d.dtype = x.dtype
     d.x, d.ldx = x.ptr, x.ld
     d.N, d.Di, d.Hi, d.Wi, d.Cin = x.N, x.D, x.H, x.W, x.C
@@ -115,6 +132,10 @@ def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), ski
 
 def conv_fprop(d):
     check(_l.get().hdu_conv_fprop(ctypes.byref(d), stream()), "hdu_conv_fprop")
+
+
+def conv_splitk_ws_bytes(d):
+    return _l.get().hdu_conv_splitk_ws_bytes(ctypes.byref(d))
 
 
 def conv_wgrad(d, dw):
@@ -215,6 +236,31 @@ def bn_fold(C, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean=
     check(_l.get().hdu_bn_fold(C, fptr(mean), fptr(var), fptr(gamma), fptr(beta), eps, fptr(sgamma), fptr(sbeta),
                                fptr(a), fptr(b), fptr(rstd), fptr(mov_mean), fptr(mov_var), momentum, stream()),
           "hdu_bn_fold")
+
+
+class FoldPlan:
+    """inference-mode BN(+Scale) folds of many layers as ONE launch (hdu_bn_fold_batched); built once, tables on device"""
+
+    def __init__(self, entries):
+        """entries: [(C, eps, mean, var, gamma, beta, sgamma|None, sbeta|None, a, b, rstd)] of float32 tensors"""
+        import numpy as np
+        self.keep = entries
+        n = len(entries)
+        tab = (_l.FoldEntry * n)()
+        begins = np.zeros(n, dtype=np.uint32)
+        tot = 0
+        for i, (C, eps, mean, var, g, be, sg, sb, a, b, r) in enumerate(entries):
+            p = lambda t: t.data_ptr() if t is not None else None
+            tab[i] = _l.FoldEntry(p(mean), p(var), p(g), p(be), p(sg), p(sb), p(a), p(b), p(r), C, eps)
+            begins[i] = tot
+            tot += (C + 255) // 256
+        self.n, self.total = n, tot
+        self.table = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(device())
+        self.begins = torch.from_numpy(begins.view(np.int32)).to(device())
+
+    def run(self):
+        check(_l.get().hdu_bn_fold_batched(ctypes.c_void_p(self.table.data_ptr()), ctypes.c_void_p(self.begins.data_ptr()),
+                                           self.n, self.total, stream()), "hdu_bn_fold_batched")
 
 
 def bn_stats_fold(x, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum, ws):

@@ -54,6 +54,9 @@ int hdu_abi_version(void);
 #define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
 #define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
+#define HDU_TUNE_SPLITK 13           /* 0 = library default (split small grids), 1 = never split, N >= 2 = force N splits where possible (tests) */
+#define HDU_TUNE_HALO_MIN_TILES 15   /* the halo-tile forward kernel needs this many 4x32-pixel tiles (default 128) */
+#define HDU_TUNE_RING_MIN_K 14       /* small grids use the deep LDS ring when Ktot > this (default 0: always) */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
 int hdu_set_tuning(int key, int value);
 
@@ -97,7 +100,19 @@ typedef struct hdu_conv_desc {
   float* stats_partial;
   const float* stats_shift;
   int stats_slots;
+  /* optional split-K scratch of hdu_conv_fprop.  Layers whose output grid cannot fill the chip (dense blocks at 1/16 and
+   * 1/32 resolution, every 3D dense block: M = 147..9408 pixels) are bound by what ONE compute unit can pull from L2;
+   * with scratch the K loop is split over `S` workgroups per output tile (S chosen by the library,
+   * hdu_conv_splitk_ws_bytes says how much it wants), partial tiles meet in `splitk_ws` (float32, write-through) and the
+   * tile's last-arriving workgroup sums them and runs the ordinary epilogue.  `splitk_counters`: >= 512 zeroed uint32
+   * (every launch returns them to zero).  Both may be shared by all launches of one stream.  NULL = never split. */
+  void* splitk_ws;
+  size_t splitk_ws_bytes;
+  uint32_t* splitk_counters;
 } hdu_conv_desc;
+
+/* bytes of split-K scratch hdu_conv_fprop would use for this descriptor (0 = it would not split) */
+size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d);
 
 /* forward conv; also the data-gradient of every stride-1 conv (caller passes dy as x and the
  * flipped/transposed filter from hdu_weight_prep; replaces tf.gradients of TFB:3158/3307). */
@@ -152,6 +167,18 @@ int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, int64
  * Scale: lib/custom_layers.py:63-69.
  */
 size_t hdu_reduce_ws_bytes(int64_t M, int C);
+
+/* Inference-mode folds of MANY BatchNormalization(+Scale) layers in ONE launch (K.layers/normalization.py:173-190 with
+ * training=False -> TFB:1667-1684: the moving statistics, no update).  Such folds depend on parameters only, never on
+ * activations, so a frozen sub-network (denseunet3d.py:222-224, hybridnet.py:211) or a whole predict pass needs one
+ * launch instead of one per layer.  `table`: device array of n entries; `begins`: device array, begins[i] = first
+ * 256-channel block of entry i (exclusive prefix sum of ceil(C/256)); total_blocks = the grand total. */
+typedef struct hdu_fold_entry {
+  const float* mean; const float* var; const float* gamma; const float* beta; const float* sgamma; const float* sbeta;
+  float* a; float* b; float* rstd;
+  int32_t C; float eps;
+} hdu_fold_entry;
+int hdu_bn_fold_batched(const hdu_fold_entry* table, const uint32_t* begins, int n, uint32_t total_blocks, void* stream);
 
 /* per-channel mean and biased variance over M pixels (tf.nn.moments, TFB:1635) */
 int hdu_bn_stats(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* mean, float* var, void* ws,

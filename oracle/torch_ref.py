@@ -122,6 +122,18 @@ class _RoundBF16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
+class _RoundGradBF16(torch.autograd.Function):
+    """identity forward, gradient rounded to bfloat16: one consumer's contribution to a bf16-stored gradient tensor"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 # --------------------------------------------------------------------------- parameters
 class ParamStore:
     """Keras-ordered, Keras-shaped weights keyed by layer name.
@@ -210,6 +222,14 @@ class ParamStore:
         g, b = self.w[name]
         return x * g + b
 
+    def q(self, x):
+        """calibration mode: a tensor the product STORES (value and its gradient in bf16); identity otherwise"""
+        return _RoundBF16.apply(x) if self.store_bf16 else x
+
+    def qg(self, x):
+        """calibration mode: a consumer's gradient contribution to a stored (bf16) gradient tensor; identity otherwise"""
+        return _RoundGradBF16.apply(x) if self.store_bf16 else x
+
     def dropout(self, x, rate):
         # parity runs: rate 0 (TF's RNG cannot be reproduced, SURVEY.md section 7); predict: identity
         return x
@@ -259,7 +279,7 @@ def _dense_block2d(P, x, stage, nb_layers, nb_filter, growth, *flags):
     """denseunet.py:295-319"""
     concat = x
     for i in range(nb_layers):
-        y = _conv_block2d(P, concat, stage, i + 1, growth, *flags)
+        y = _conv_block2d(P, P.qg(concat), stage, i + 1, growth, *flags)
         concat = torch.cat([concat, y], -1)
         nb_filter += growth
     return concat, nb_filter
@@ -269,11 +289,11 @@ def _transition2d(P, x, stage, nb_filter, compression, bn_mode, tr_conv, tr_bn, 
     """denseunet.py:266-292"""
     eps = 1.1e-5
     base = "conv%d_blk" % stage
-    x = P.bn(base + "_bn", x, eps=eps, mode=bn_mode, trainable=tr_bn)
+    x = P.bn(base + "_bn", P.qg(x), eps=eps, mode=bn_mode, trainable=tr_bn)
     x = P.scale(base + "_scale", x, trainable=tr_scale)
     x = torch.relu(x)
     x = P.conv(base, x, int(nb_filter * compression), (1, 1), use_bias=False, trainable=tr_conv)
-    return avg_pool_valid(x, (2, 2))
+    return P.q(avg_pool_valid(x, (2, 2)))
 
 
 def dense_unet_2d(P, img, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 36, 24), growth_rate=48):
@@ -295,7 +315,7 @@ def dense_unet_2d(P, img, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 
     x = P.conv("conv1", x, nb_filter, (7, 7), strides=(2, 2), use_bias=False, trainable=tr_conv)
     x = P.bn("conv1_bn", x, eps=eps, mode=bn_mode, trainable=tr_bn)
     x = P.scale("conv1_scale", x, trainable=tr_scale)
-    x = torch.relu(x)
+    x = P.q(torch.relu(x))
     box.append(x)
     x = zero_pad(x, 1)
     x = max_pool_valid(x, 3, 2)
@@ -307,9 +327,8 @@ def dense_unet_2d(P, img, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 
         x = _transition2d(P, x, stage, nb_filter, compression, *flags)
         nb_filter = int(nb_filter * compression)
     final_stage = stage + 1
-    x, nb_filter = _dense_block2d(P, x, final_stage, nb_layers[-1], nb_filter, growth_rate, *flags)
-    x = P.bn("conv%d_blk_bn" % final_stage, x, eps=eps, mode=bn_mode, trainable=tr_bn)
-    x = P.scale("conv%d_blk_scale" % final_stage, x, trainable=tr_scale)
+    xb, nb_filter = _dense_block2d(P, x, final_stage, nb_layers[-1], nb_filter, growth_rate, *flags)
+    x = P.scale("conv%d_blk_scale" % final_stage, P.bn("conv%d_blk_bn" % final_stage, P.qg(xb), eps=eps, mode=bn_mode, trainable=tr_bn), trainable=tr_scale)
     x = torch.relu(x)
     box.append(x)
 
@@ -363,7 +382,7 @@ def dense_net_3d(P, img, variant="3dpart", reduction=0.5, nb_layers=(3, 4, 12, 8
     x = P.conv("3dconv1", x, nb_filter, (7, 7, 7), strides=(2, 2, 2), use_bias=False)
     x = P.bn("3dconv1_bn", x, eps=eps)
     x = P.scale("3dconv1_scale", x)
-    x = torch.relu(x)
+    x = P.q(torch.relu(x))
     x = zero_pad(x, 1)
     x = max_pool_valid(x, 3, 2)
     stage = 1
@@ -371,24 +390,24 @@ def dense_net_3d(P, img, variant="3dpart", reduction=0.5, nb_layers=(3, 4, 12, 8
         stage = bi + 2
         concat = x
         for i in range(nb_layers[bi]):
-            y = _conv_block3d(P, concat, stage, i + 1, growth_rate, blk_mode, blk_tr)
+            y = _conv_block3d(P, P.qg(concat), stage, i + 1, growth_rate, blk_mode, blk_tr)
             concat = torch.cat([concat, y], -1)
             nb_filter += growth_rate
         x = concat
         base = "3dconv%d_blk" % stage
-        x = P.bn(base + "_bn", x, eps=eps, mode=blk_mode, trainable=True)
+        x = P.bn(base + "_bn", P.qg(x), eps=eps, mode=blk_mode, trainable=True)
         x = P.scale(base + "_scale", x)
         x = torch.relu(x)
         x = P.conv(base, x, int(nb_filter * compression), (1, 1, 1), use_bias=False)
-        x = avg_pool_valid(x, (2, 2, 1))
+        x = P.q(avg_pool_valid(x, (2, 2, 1)))
         nb_filter = int(nb_filter * compression)
     final_stage = stage + 1
     concat = x
     for i in range(nb_layers[-1]):
-        y = _conv_block3d(P, concat, final_stage, i + 1, growth_rate, blk_mode, blk_tr)
+        y = _conv_block3d(P, P.qg(concat), final_stage, i + 1, growth_rate, blk_mode, blk_tr)
         concat = torch.cat([concat, y], -1)
         nb_filter += growth_rate
-    x = concat
+    x = P.qg(concat)
     x = P.bn("3dconv%d_blk_bn" % final_stage, x, eps=eps)
     x = P.scale("3dconv%d_blk_scale" % final_stage, x)
     x = torch.relu(x)
@@ -424,7 +443,7 @@ def hybrid_net(P, img, variant="3dpart", nb_layers2d=(6, 12, 36, 24), nb_layers3
     input2d = torch.stack(slabs, 0)  # (D,H,W,3)
     feature2d, classifer2d = dense_unet_2d(P, input2d, variant=variant, nb_layers=nb_layers2d)
     res2d = classifer2d.permute(1, 2, 0, 3)[None]  # slice2d + concat: (1,H,W,D,3)
-    fea2d = feature2d.permute(1, 2, 0, 3)[None]
+    fea2d = P.q(feature2d).permute(1, 2, 0, 3)[None]
     input3d = torch.cat([img, res2d * 250], 4)
     feature3d = dense_net_3d(P, input3d, variant=variant, nb_layers=nb_layers3d)
     final = feature3d + fea2d

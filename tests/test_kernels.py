@@ -289,6 +289,73 @@ def test_conv_dgrad_via_fprop(hdu, cs, dtype, dma_stages):
     assert_close(dxe.to_torch().cpu(), xe.grad, dtype, what="dgrad")
 
 
+SPLITK_CASES = [
+    # dense-block shapes whose output grid cannot fill the chip (include/hdu.h, hdu_conv_desc.splitk_ws)
+    dict(N=2, D=1, H=16, W=15, Cin=192, Cout=48, K=(1, 3, 3), p=(0, 1, 1), bias=False, ldout=96, id="block5_3x3_192to48"),
+    dict(N=1, D=3, H=7, W=7, Cin=128, Cout=32, K=(3, 3, 3), p=(1, 1, 1), bias=True, ldout=None, id="3d_block5_3x3x3_128to32"),
+    dict(N=1, D=1, H=10, W=20, Cin=1056, Cout=192, K=(1, 1, 1), p=(0, 0, 0), bias=False, ldout=None, id="block5_1x1_1056to192"),
+    dict(N=1, D=1, H=9, W=12, Cin=96, Cout=128, K=(1, 3, 3), p=(0, 1, 1), bias=True, ldout=None, id="n128_waves2x2"),
+    dict(N=1, D=1, H=8, W=8, Cin=160, Cout=64, K=(1, 3, 3), p=(0, 1, 1), bias=True, ldout=None, id="n64_waves2x2"),
+    dict(N=1, D=2, H=4, W=4, Cin=64, Cout=40, K=(3, 3, 3), p=(1, 1, 1), bias=True, ldout=None, up=(1, 1, 1), id="upsampled_3d_decoder"),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in SPLITK_CASES])
+def test_conv_splitk(hdu, cs, dtype):
+    """K loop dealt to S workgroups per output tile, partial tiles summed by the tile's last arriver: same result as the
+    unsplit launch for forced S = 2, 5, the library's own choice, with bias / ragged M / slab output / accumulate and
+    the conv-epilogue statistics; the ticket counters are back at zero after every launch."""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    N, D, H, W, Cin, Cout, K, p = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cin"], cs["Cout"], cs["K"], cs["p"]
+    up = cs.get("up", (0, 0, 0))
+    x = rnd((N, D, H, W, Cin), 1, 1.0, dtype)
+    w = rnd((Cout,) + K + (Cin,), 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cin), dtype)
+    bias = rnd((Cout,), 6, 0.5).float().double() if cs["bias"] else None
+    xa = mkact(ops, x, dtype)
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    ref = ref_conv(ref_xeff(x, up, None, None, False, dtype), w, (1, 1, 1), p, bias)
+    D, H, W = D << up[0], H << up[1], W << up[2]
+    slots = 4
+    shift = dev(ops, rnd((Cout,), 11, 0.3).float().double())
+    outs, stats = {}, {}
+    ws, cnt = ops.splitk_scratch()
+    for S in (1, 2, 5, 0):
+        lib.hdu_set_tuning(13, S)
+        try:
+            if cs["ldout"]:
+                big = ops.Act.alloc(N, D, H, W, cs["ldout"], dtype, zero=True)
+                ya = big.slab(8, Cout)
+            else:
+                ya = ops.Act.alloc(N, D, H, W, Cout, dtype)
+            bias_d = dev(ops, bias) if bias is not None else None       # must outlive the launches
+            d = ops.conv_desc(xa, ctypes.c_void_p(wt.data_ptr()), ya, K, (1, 1, 1), p, up, None, None, True, bias_d)
+            if S == 0:
+                assert ops.conv_splitk_ws_bytes(d) > 0, "the library's default should split this shape"
+            elif S == 1:
+                assert ops.conv_splitk_ws_bytes(d) == 0
+            partial = torch.zeros(slots * 2 * Cout, dtype=torch.float32, device=ops.device())
+            d.stats_partial, d.stats_shift, d.stats_slots = partial.data_ptr(), shift.data_ptr(), slots
+            ops.conv_fprop(d)
+            outs[S] = ya.to_torch().cpu()
+            stats[S] = partial.cpu().reshape(slots, 2, Cout).sum(0)
+            assert int(cnt.abs().sum()) == 0, "split-K tickets must return to zero"
+            assert_close(outs[S], ref, dtype, what="fprop S=%d" % S)
+            d.stats_partial = None
+            d.accumulate = 1
+            ops.conv_fprop(d)
+            assert_close(ya.to_torch().cpu(), q(ref, dtype) * 2, dtype, scale=2 * float(ref.abs().max()), what="accumulate S=%d" % S)
+        finally:
+            lib.hdu_set_tuning(13, 0)
+    for S in (2, 5, 0):
+        # same products, different summation order: float32 roundoff only (one storage ulp in bf16)
+        tol = 2e-5 if dtype == F32 else 8e-3
+        assert float((outs[S] - outs[1]).abs().max()) <= tol * float(ref.abs().max()), S
+        assert float((stats[S] - stats[1]).abs().max()) <= 1e-2 * float(stats[1].abs().max()) + 1e-3, S
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_conv_dgrad_strided(hdu, dtype):
     ops = ops_mod()
