@@ -550,7 +550,8 @@ class ConvLayer:
         self.K, self.stride = K, stride
         self.halo = halo
         if halo:
-            assert skip is None and not ctx.fuse_prologue, "halo mode materialises the conv input"
+            assert not ctx.fuse_prologue, "halo mode materialises the conv input"
+            assert skip is None or up == (0, 0, 0), "a skip add in halo mode must be at the stored resolution"
             pad = (pad[0] - (halo << up[0]), pad[1], pad[2])
         self.pad = pad
         self.trainable = trainable
@@ -762,12 +763,16 @@ def _conv_backward_halo(self, dy):
     ctx = self.ctx
     x = self.x.act
     K, pad, h = self.K, self.pad, self.halo
-    assert not self.strided, "the stride-2 stem needs no data gradient in the depth-sharded 3D net"
     De, He, We = (x.D + 2 * h) << self.up[0], x.H << self.up[1], x.W << self.up[2]
     tgt = self._dxe()
-    d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
-                      (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]))
-    ops.conv_fprop(d)
+    if self.strided:      # the 7x7x7 stride-2 stem of a depth-sharded end-to-end hybrid: gradient w.r.t. (CT, 250*logits2d)
+        d = ops.conv_desc(ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), self.wf_ptr, dy, K,
+                          self.stride, pad)
+        ops.conv_dgrad_strided(d)
+    else:
+        d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
+                          (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]))
+        ops.conv_fprop(d)
     dz = tgt
     if self.up != (0, 0, 0):
         dz = self._dz()
@@ -775,6 +780,8 @@ def _conv_backward_halo(self, dy):
     _sh.halo_reduce(ctx.shard, dz, h, self._halo_tmp().buf)
     plane = x.H * x.W * dz.ld
     interior = ops.Act(dz.buf, dz.off + h * plane, x.N, x.D, x.H, x.W, x.C, dz.ld, dz.dtype)
+    if self.skip is not None and self.skip.root.needs_grad:      # d(x_eff) is also the gradient of the added skip
+        ops.upsample_bwd(interior, self.skip.grad, (0, 0, 0), accumulate=self.skip.grad_mode())
     if self.bn is not None:
         self.bn.backward(self.x, interior)
     else:

@@ -75,13 +75,28 @@ class Model:
                                  "(hybridnet.py:359-364,400-406)")
             H = W = input_size
             D = input_cols
+            ctx.shard = shard
+            sharded = shard is not None and shard.world > 1
             self.input_shape = (1, H, W, D, 1)
-            self.vol = torch.zeros(D * H * W, dtype=torch.float32, device=ctx.dev)
-            self.logits = _m.build_hybrid(ctx, self.vol, D, H, W, variant=variant, nb_layers2d=nb_layers2d,
-                                          nb_layers3d=nb_layers3d)
-            # loss.py:6-7 hard-codes depth slices 1:7
-            hi = min(7, D)
-            self.loss_layer = LossLayer(ctx, self.logits, [(1 * H * W, (hi - 1) * H * W)])
+            if sharded:
+                # input_cols = depth planes held by THIS rank; one raw CT plane of each depth neighbour rides along for
+                # the 2.5D slabs (denseunet3d.py:399-409): vol_h = [halo][D planes][halo], vol = its interior
+                self.vol_h = torch.zeros((D + 2) * H * W, dtype=torch.float32, device=ctx.dev)
+                self.vol = self.vol_h[H * W:(D + 1) * H * W]
+                self.logits = _m.build_hybrid(ctx, self.vol_h, D, H, W, variant=variant, nb_layers2d=nb_layers2d,
+                                              nb_layers3d=nb_layers3d)
+            else:
+                self.vol = torch.zeros(D * H * W, dtype=torch.float32, device=ctx.dev)
+                self.logits = _m.build_hybrid(ctx, self.vol, D, H, W, variant=variant, nb_layers2d=nb_layers2d,
+                                              nb_layers3d=nb_layers3d)
+            # loss.py:6-7 hard-codes depth slices 1:7 (of the WHOLE volume: a shard takes its part of that range)
+            g0 = shard.rank * D if sharded else 0
+            world = shard.world if sharded else 1
+            lo, hi = max(1, g0), min(7, D * world, g0 + D)
+            ranges = [((lo - g0) * H * W, (hi - lo) * H * W)] if hi > lo else []
+            self.loss_layer = LossLayer(ctx, self.logits, ranges)
+            if sharded:   # normalised by the global voxel count: count * world == (min(7, D_global) - 1) * H * W
+                self.loss_layer.count = (min(7, D * world) - 1) * H * W / float(world)
             self.output_shape = (1, H, W, D, 3)
         elif kind == "3d":
             # stand-alone DenseNet3D on a 4-channel volume; with `shard` this rank holds input_cols LOCAL depth planes
@@ -124,6 +139,10 @@ class Model:
             self.x_stage.copy_(x[0].permute(2, 0, 1, 3).contiguous().reshape(-1).to(self.ctx.dev))
         else:  # (1,H,W,D,1) -> depth-major [D][H][W]
             self.vol.copy_(x[0, :, :, :, 0].permute(2, 0, 1).contiguous().reshape(-1).to(self.ctx.dev))
+            if getattr(self, "vol_h", None) is not None:
+                from . import shard as _sh
+                H, D = self.input_shape[1], self.input_shape[3]
+                _sh.exchange_ct_planes(self.ctx.shard, self.vol_h, D, H * H)
 
     def _labels_internal(self, y):
         y = np.asarray(y)

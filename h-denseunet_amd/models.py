@@ -235,8 +235,23 @@ def as3d(ctx, v2d):
 def build_hybrid(ctx, vol, D, H, W, variant="3dpart", nb_layers2d=(6, 12, 36, 24), nb_layers3d=(3, 4, 12, 8)):
     """vol: float32 device tensor [D][H][W].  Returns logits Var [1][D][H][W][cpad(3)]."""
     dt = ctx.dtype
-    x2d = ctx.new_var(D, 1, H, W, ops.cpad(3, dt))
-    Slab25DLayer(ctx, vol, x2d)
+    sharded = ctx.shard is not None and ctx.shard.world > 1
+    hl = 1 if sharded else 0
+    if sharded:
+        # depth-sharded hybrid (SURVEY.md section 8e, third row): this rank holds D planes of the volume plus ONE raw CT
+        # plane from each depth neighbour (`vol` has D+2 planes; Model._upload_x exchanges them, global edges replicate
+        # their own plane = the reference's edge slabs (0,0,1) / (D-2,D-1,D-1), denseunet3d.py:399-409).  The slabs of the
+        # halo'd volume are built for all D+2 planes; the 2D net -- per-slice, BN in inference mode in both hybrids --
+        # runs on the D interior ones.
+        xall = ctx.new_var(D + 2, 1, H, W, ops.cpad(3, dt))
+        Slab25DLayer(ctx, vol, xall)
+        a = xall.act
+        x2d = Var(ctx, ops.Act(a.buf, a.off + H * W * a.ld, D, 1, H, W, a.C, a.ld, a.dtype))
+        ctx.vars.append(x2d)
+        vol = vol[H * W:(D + 1) * H * W]
+    else:
+        x2d = ctx.new_var(D, 1, H, W, ops.cpad(3, dt))
+        Slab25DLayer(ctx, vol, x2d)
     ctx.grad_enabled = variant == "end2end"
     r2d = build_dense_unet_2d(ctx, x2d, variant=variant, nb_layers=nb_layers2d, materialize_feature=True)
     ctx.grad_enabled = True
@@ -247,7 +262,7 @@ def build_hybrid(ctx, vol, D, H, W, variant="3dpart", nb_layers2d=(6, 12, 36, 24
     feat3d, bn3d = build_dense_net_3d(ctx, in3d, variant=variant, nb_layers=nb_layers3d)
     fea2d = as3d(ctx, r2d["feat"])
     fc = ConvLayer(ctx, "fianl_conv", feat3d, 64, (3, 3, 3), pad=(1, 1, 1), bn=bn3d, skip=fea2d, keras_nd=3,
-                   dropout=0.1 if variant == "3dpart" else 0.3)
+                   dropout=0.1 if variant == "3dpart" else 0.3, halo=hl)
     st = StatsOp(ctx, fc.out)
     fbn = BNLayer(ctx, "final_bn", fc.out.C, 1e-3, 0.99, "batch", True)
     st.fuse(fbn)

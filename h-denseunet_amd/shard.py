@@ -98,3 +98,25 @@ def sync_stats(sh, mean, var, n_local, n_global, buf):
     torch.div(b1, float(n_global), out=mean)
     torch.div(b2, float(n_global), out=var)
     var.addcmul_(mean, mean, value=-1.0).clamp_(min=0.0)
+
+
+def exchange_ct_planes(sh, vol_h, D, plane):
+    """vol_h: float32 [D+2][plane] -- the rank's D raw CT planes with one halo plane on each side.  The halos come from
+    the depth neighbours (one small send/recv at the input); at the two ends of the volume the edge
+    plane is replicated, which is exactly the reference's first / last 2.5D slab (denseunet3d.py:399-409)."""
+    first, last = vol_h[plane:2 * plane], vol_h[D * plane:(D + 1) * plane]
+    lo_halo, hi_halo = vol_h[:plane], vol_h[(D + 1) * plane:(D + 2) * plane]
+    ops_ = []
+    if sh.lo is not None:
+        ops_.append(dist.P2POp(dist.isend, first, sh.lo, sh.group))
+        ops_.append(dist.P2POp(dist.irecv, lo_halo, sh.lo, sh.group))
+    else:
+        lo_halo.copy_(first)
+    if sh.hi is not None:
+        ops_.append(dist.P2POp(dist.isend, last, sh.hi, sh.group))
+        ops_.append(dist.P2POp(dist.irecv, hi_halo, sh.hi, sh.group))
+    else:
+        hi_halo.copy_(last)
+    if ops_:
+        for r in dist.batch_isend_irecv(ops_):
+            r.wait()

@@ -40,9 +40,9 @@ def synthetic_batch(kind, b, size, cols, seed=1234):
     return pkg("synth").synthetic_batch(kind, b, size, cols, seed)
 
 
-def build_pair(kind, variant, b, size, cols, dtype, nb2d, nb3d, seed=4321, odtype=torch.float64):
+def build_pair(kind, variant, b, size, cols, dtype, nb2d, nb3d, seed=4321, odtype=torch.float64, perturb=True):
     """returns (product model, oracle ParamStore, oracle forward fn) with identical weights"""
-    P = R.ParamStore(seed=seed, dtype=odtype, perturb=True)
+    P = R.ParamStore(seed=seed, dtype=odtype, perturb=perturb)
     fwd = oracle_forward_fn(kind, variant, nb2d, nb3d)
     x, _ = synthetic_batch(kind, b, size, cols)
     with torch.no_grad():

@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -12,5 +14,31 @@ def test_depth_shard_world2_gloo(emu_lib):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-5000:]
+    assert "SHARD_OK" in out.stdout
+
+
+def test_depth_shard_world4_gloo(emu_lib):
+    """4 ranks x 4 depth planes: ranks 1 and 2 are INTERIOR shards -- two depth neighbours each, halos received from and
+    halo gradients returned to both sides, no global edge (the world-2 run only has edge shards)."""
+    env = dict(os.environ, HIPEMU_THREADS="2", OMP_NUM_THREADS="1", SHARD_TEST_DL="4", SHARD_TEST_H="32")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-5000:]
+    assert "SHARD_OK" in out.stdout and out.stdout.count("rank ") >= 4
+
+
+@pytest.mark.parametrize("net,port", [("3dpart", "29545"), ("end2end", "29551")])
+def test_depth_sharded_hybrid_world2_gloo(emu_lib, net, port):
+    """SURVEY.md section 8e, third row: the HYBRID nets on one volume split over 2 ranks -- each rank runs the 2D branch on
+    its own slices (one raw CT plane exchanged with each depth neighbour for the 2.5D slabs, denseunet3d.py:399-409), the
+    3D net with halo exchange / sync-BN, the HFF add + `fianl_conv` with a halo, loss.py's slices 1:7 split over the
+    ranks; the sharded training step reproduces the unsharded one (logits, loss, all-reduced gradient, weights, moving
+    statistics).  end2end also returns the stem's halo gradients (stride-2 7x7x7 data gradient) to the 2D branch."""
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-5000:]
     assert "SHARD_OK" in out.stdout

@@ -203,16 +203,22 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols)
     cal_coss = np.array([r[2] for r in cal_rows if r[2] is not None])
     ratios = np.array([r[3] for r in rows if r[3] is not None])
     cal_ratios = np.array([r[3] for r in cal_rows if r[3] is not None])
+
+    def regression(g):      # least-squares scale of g on the float32 oracle's gradient, all tensors pooled
+        num = sum(float((g[k].astype(np.float64) * ref_g[k].astype(np.float64)).sum()) for k in ref_g)
+        return num / sum(float((ref_g[k].astype(np.float64) ** 2).sum()) for k in ref_g)
+    coef, cal_coef = regression(flat_grads(m.get_grads_dict())), regression(cal_g)
     worst = max(rows, key=lambda r: r[1] / max(BF16_SLACK * r[4], REL_FLOOR))
     print("[%s/%s] train step: loss %.6f (oracle %.6f, bf16-storage oracle %.6f); train-mode logits max abs err %.3e "
           "(bf16-storage oracle %.3e, max|logit| %.3f)" % (kind, variant, loss, ref_loss, cal_loss, e_train, e_cal,
                                                           float(np.abs(rl).max())))
     print("[%s/%s] gradients over %d tensors: rel-L2 worst %.4f / median %.4f (bf16-storage oracle: %.4f / %.4f); cosine "
-          "min %.5f / median %.6f (oracle-bf16: %.5f / %.6f); mean norm ratio %.4f (oracle-bf16 %.4f); worst vs its bound: "
+          "min %.5f / median %.6f (oracle-bf16: %.5f / %.6f); mean norm ratio %.4f (oracle-bf16 %.4f); pooled regression "
+          "coefficient on the oracle gradient %.4f (oracle-bf16 %.4f); worst vs its bound: "
           "%s rel %.4f noise %.4f" % (kind, variant, len(rows), rels.max(), float(np.median(rels)), cal_rels.max(),
                                       float(np.median(cal_rels)), coss.min(), float(np.median(coss)), cal_coss.min(),
                                       float(np.median(cal_coss)), float(ratios.mean()), float(cal_ratios.mean()),
-                                      worst[0], worst[1], worst[4]))
+                                      coef, cal_coef, worst[0], worst[1], worst[4]))
 
     # ---- gates
     for c in range(3):
@@ -229,10 +235,12 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols)
         if cos is not None:
             lim = min(COS_MIN, 1.0 - BF16_SLACK * (1.0 - crow[2]))
             assert cos >= lim, "gradient of %s: cosine %.5f < %.5f (bf16-storage oracle %.5f)" % (key, cos, lim, crow[2])
-    # a systematic deficit (dropped pixels / taps) shows as a norm ratio != 1 on average: within 1 % of the float32
-    # oracle, or as close to it as the bf16-storage oracle itself gets
-    assert abs(float(ratios.mean()) - 1.0) < max(1e-2, BF16_SLACK * abs(float(cal_ratios.mean()) - 1.0)), \
-        "mean |got|/|ref| = %.4f (bf16-storage oracle %.4f)" % (float(ratios.mean()), float(cal_ratios.mean()))
+    # a systematic deficit (dropped pixels / taps / a mis-scaled term) shows as a scale != 1 of the gradient on the
+    # oracle's: the pooled regression coefficient <got, ref> / <ref, ref> averages the zero-mean storage noise out over
+    # all parameters (the mean of per-tensor norm ratios does not: noise of tens of percent per tensor biases and
+    # scatters it by percents -- it is printed above, not gated)
+    assert abs(coef - 1.0) < max(1e-2, BF16_SLACK * abs(cal_coef - 1.0)), \
+        "gradient scale on the oracle's: %.4f (bf16-storage oracle %.4f)" % (coef, cal_coef)
     # SGD-Nesterov update of the head from the bf16 gradients (K.optimizers.py:168-185): delta = -lr*(1+momentum)*g
     last = {"2d": "dense167classifer", "hybrid": "2d3dclassifer", "3d": "3dclassifer"}[kind]
     d_got = m.get_weights_dict()[last][0] - W[last][0]

@@ -1,12 +1,15 @@
 """N1: z-sliding-window inference (lib/funcs.py:4-51) -- the HBM-resident implementation equals a literal numpy
 restatement of the reference loop driven through Model.predict."""
 import numpy as np
+import pytest
+import torch
 
 import parity_utils as U
 
 
 def reference_loop(model, imgs_test, num, mini, maxi, args):
-    """lib/funcs.py:4-51 restated with numpy (softmax via numpy instead of K.softmax/K.eval)"""
+    """lib/funcs.py:4-51 restated with numpy (softmax via numpy instead of K.softmax/K.eval); `model` only needs
+    .predict(box, batch_size, verbose)"""
     batch, img_deps, img_rows, img_cols = args.b, args.input_size, args.input_size, args.input_cols
     window_cols = img_cols // 4
     box_test = np.zeros((batch, img_deps, img_rows, img_cols, 1), dtype="float32")
@@ -38,3 +41,38 @@ def test_sliding_window_matches_reference_loop(emu_lib):
     np.testing.assert_allclose(s1, r1, atol=2e-6)
     np.testing.assert_allclose(s2, r2, atol=2e-6)
     assert float(np.abs(s1).max()) > 0
+
+
+class _OraclePredictor:
+    """the float32 torch restatement of hybridnet.py behind the one method lib/funcs.py calls"""
+
+    def __init__(self, P, fwd):
+        self.P, self.fwd = P, fwd
+
+    def predict(self, box, batch_size=None, verbose=0):
+        return U.R.predict(self.P, self.fwd, torch.tensor(box)).numpy()
+
+
+@pytest.mark.gpu
+def test_sliding_window_full_size_vs_torch_oracle(hip_lib):
+    """N1 on hardware: the HBM-resident sweep of `dense_rnn_net` (224 x 224 x 12 windows, float32 parity mode) over a
+    224 x 224 x 40 phantom against the literal lib/funcs.py loop driven by the TORCH ORACLE's predict (not the
+    product's): both averaged score volumes within 1e-3 absolute (probabilities) and thresholded masks that differ
+    on at most 1e-4 of the voxels (the host-side post-processing of test.py has its own test, test_postprocess.py)."""
+    args = U.make_args(1, 224, 12)
+    m, P, fwd = U.build_pair("hybrid", "end2end", 1, 224, 12, "f32", (6, 12, 36, 24), (3, 4, 12, 8),
+                             odtype=torch.float32, perturb=False)
+    vol, lab = U.pkg("synth").synthetic_ct((224, 224, 40), seed=3)
+    funcs = U.pkg("funcs")
+    mask, mini, maxi = funcs.liver_window_from_mask((lab > 0).astype(np.uint8)[:, :, :])
+    maxi = np.array([maxi[0], maxi[1], min(int(maxi[2]), 22)])        # 6 windows: bounds the oracle's CPU time
+    s1, s2 = funcs.predict_tumor_inwindow(m, vol, 3, mini, maxi, args)
+    r1, r2 = reference_loop(_OraclePredictor(P, fwd), vol, 3, mini, maxi, args)
+    assert s1.shape == r1.shape == (224, 224, 40)
+    e1, e2 = float(np.abs(s1 - r1).max()), float(np.abs(s2 - r2).max())
+    print("sliding window vs oracle: max abs score err %.2e / %.2e, swept planes %d" % (e1, e2, int((r1.sum((0, 1)) != 0).sum())))
+    assert e1 <= 1e-3 and e2 <= 1e-3
+    for thr in (0.3, 0.5):
+        for a, b in ((s1, r1), (s2, r2)):
+            assert float(((a >= thr) != (b >= thr)).mean()) <= 1e-4
+    assert float(np.abs(r1).max()) > 0
