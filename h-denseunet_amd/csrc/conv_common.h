@@ -32,6 +32,10 @@ struct ConvK {
   float* stats_partial;       // [stats_slots][2][Cout] float, zeroed by the caller; NULL = off
   const float* stats_shift;   // [Cout] shift against E[x^2]-E[x]^2 cancellation (any value near the mean)
   int stats_slots;
+  // fused BN(+Scale)+ReLU backward of a data-gradient launch (hdu_conv_desc.bnb_*)
+  const void* bnb_u; long long bnb_ldu;
+  const float* bnb_a; const float* bnb_b; const float* bnb_mean; const float* bnb_rstd;
+  float* bnb_partial; int bnb_slots; int bnb_relu;
   // split-K (ring kernel): gridDim.z workgroups share one output tile; partial accumulators meet in sk_ws
   float* sk_ws;               // [tile][split][wave][fragment][lane] f32x4, write-through stores
   unsigned* sk_cnt;           // [tile] arrival tickets, zero between launches

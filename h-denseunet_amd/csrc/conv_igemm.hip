@@ -733,6 +733,100 @@ __device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n
   }
 }
 
+// ---- fused BatchNormalization(+Scale)+ReLU backward of a data-gradient launch (ConvK::bnb_*, include/hdu.h).  The staged
+// tile is dz; each thread owns ONE 16-byte channel chunk (coefficients in registers) and walks the tile rows, so that
+// consecutive lanes store consecutive chunks of a row (full 128-byte lines) and a thread's S1 / S2 partial sums stay in
+// registers; lanes that share a chunk meet in a wave butterfly, the four waves in LDS, and one lane per channel adds
+// the workgroup's sums to a slot row with float atomics.
+template <typename T, int BM, int BN, int ROWB>
+__device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem, long long m0, int n0, int tid) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int NCC = BN / CH;
+  constexpr int NCCP = NCC <= 4 ? 4 : (NCC <= 8 ? 8 : (NCC <= 16 ? 16 : 32));
+  constexpr int RSTEP = 256 / NCCP;
+  constexpr int IT = (BM + RSTEP - 1) / RSTEP;
+  constexpr int UNR = IT < 4 ? IT : 4;
+  static_assert(NCC <= 32 && IT % UNR == 0, "tile shape");
+  const int cc = tid % NCCP, r0 = tid / NCCP;
+  const int n = n0 + cc * CH;
+  const bool col_ok = cc < NCC && n < p.Cout;
+  const bool sums = p.bnb_partial != nullptr;
+  float a[CH], b[CH], mu[CH], rs[CH], s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    a[j] = col_ok ? p.bnb_a[n + j] : 0.f;
+    b[j] = col_ok ? p.bnb_b[n + j] : 0.f;
+    mu[j] = col_ok && sums ? p.bnb_mean[n + j] : 0.f;
+    rs[j] = col_ok && sums ? p.bnb_rstd[n + j] : 0.f;
+    s1[j] = 0.f; s2[j] = 0.f;
+  }
+  const T* __restrict__ up = (const T*)p.bnb_u;
+  T* __restrict__ yp = (T*)p.y;
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  for (int it0 = 0; it0 < IT; it0 += UNR) {
+    u32x4 uv[UNR], ov[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      const int row = r0 + (it0 + q) * RSTEP;
+      const long long m = m0 + row;
+      ok[q] = col_ok && row < BM && m < p.M;
+      uv[q] = ok[q] ? *(const u32x4*)(up + m * p.bnb_ldu + n) : z4;
+      ov[q] = (ok[q] && p.accumulate) ? *(const u32x4*)(yp + m * p.ldy + n) : z4;
+    }
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int q = 0; q < UNR; ++q) {
+      if (!ok[q]) continue;
+      const int row = r0 + (it0 + q) * RSTEP;
+      float dz[CH], u[CH], o[CH];
+      Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), dz);
+      Chunk<T>::unpack(uv[q], u);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float sj = a[j] * u[j] + b[j];
+        const float g = (!p.bnb_relu || sj > 0.f) ? dz[j] : 0.f;
+        s1[j] += g;
+        s2[j] += g * ((u[j] - mu[j]) * rs[j]);
+        o[j] = a[j] * g;
+      }
+      if (p.accumulate) {
+        float old[CH];
+        Chunk<T>::unpack(ov[q], old);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) o[j] += old[j];
+      }
+      *(u32x4*)(yp + (m0 + row) * p.ldy + n) = Chunk<T>::pack(o);
+    }
+  }
+  if (!sums) return;
+#pragma unroll
+  for (int mask = NCCP; mask < 64; mask <<= 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], mask); s2[j] += __shfl_xor(s2[j], mask); }
+  }
+  __syncthreads();                                   // every thread is done with the staged tile: its LDS is reused
+  float* red = (float*)smem;                         // [4 waves][2][BN]
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < NCCP && cc < NCC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      red[(wave * 2 + 0) * BN + cc * CH + j] = s1[j];
+      red[(wave * 2 + 1) * BN + cc * CH + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  float* dst = p.bnb_partial + (long long)(blockIdx.x % (unsigned)p.bnb_slots) * 2 * p.Cout;
+  for (int q = tid; q < 2 * BN; q += 256) {
+    const int sidx = q / BN, col = q - sidx * BN;
+    if (n0 + col < p.Cout) {
+      const float t = red[(0 * 2 + sidx) * BN + col] + red[(1 * 2 + sidx) * BN + col] + red[(2 * 2 + sidx) * BN + col] +
+                      red[(3 * 2 + sidx) * BN + col];
+      atomicAdd(dst + (long long)sidx * p.Cout + n0 + col, t);
+    }
+  }
+}
+
 // ---- epilogue shared by the DMA kernels: bias / dropout in registers, then the tile goes through LDS so that every
 // lane writes (and, in accumulate mode, reads) one full 16-byte chunk of a row: 8 lanes cover a 128-byte line.
 template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int SMEM>
@@ -766,6 +860,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
     }
   }
   __syncthreads();
+  if (p.bnb_u != nullptr) {                          // data gradient with the consumer BN's backward fused in
+    epilogue_bn_backward<T, BM, BN, ROWB>(p, smem, m0, n0, tid);
+    return;
+  }
   T* __restrict__ yp = (T*)p.y;
   constexpr int NCC = BN / CH;                       // 16-byte chunks per tile row
   for (int q = tid; q < BM * NCC; q += 256) {
@@ -1990,6 +2088,16 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   k->stats_slots = d->stats_slots;
   if (k->stats_partial && (!k->stats_shift || k->stats_slots <= 0 || d->accumulate))
     return hdu_set_error(HDU_ERR_ARG, "conv: epilogue statistics need stats_shift, stats_slots > 0 and accumulate == 0");
+  k->bnb_u = wgrad ? nullptr : d->bnb_u; k->bnb_ldu = d->bnb_ldu;
+  k->bnb_a = d->bnb_a; k->bnb_b = d->bnb_b; k->bnb_mean = d->bnb_mean; k->bnb_rstd = d->bnb_rstd;
+  k->bnb_relu = d->bnb_relu; k->bnb_partial = d->bnb_partial; k->bnb_slots = d->bnb_slots;
+  if (k->bnb_u) {
+    if (!k->bnb_a || !k->bnb_b || (uintptr_t)k->bnb_u % 16 || k->bnb_ldu % ch || d->pro_a || d->skip || d->bias ||
+        d->stats_partial || (d->drop_keep > 0.f && d->drop_keep < 1.f))
+      return hdu_set_error(HDU_ERR_ARG, "conv: the fused BN backward needs bnb_a/bnb_b, a 16-byte addressable bnb_u and a plain data-gradient launch (no prologue / skip / bias / dropout / statistics)");
+    if (k->bnb_partial && (!k->bnb_mean || !k->bnb_rstd || k->bnb_slots <= 0))
+      return hdu_set_error(HDU_ERR_ARG, "conv: bnb_partial needs bnb_mean, bnb_rstd and bnb_slots > 0");
+  }
   k->sk_ws = wgrad ? nullptr : (float*)d->splitk_ws;
   k->sk_cnt = wgrad ? nullptr : d->splitk_counters;
   if (k->sk_ws && ((uintptr_t)k->sk_ws % 16 || !k->sk_cnt))
@@ -2102,7 +2210,7 @@ static void dispatch_igemm(const ConvK& k, size_t skb, hipStream_t s) {
 }
 
 static bool fprop_halo_ok(const ConvK& k, int dtype) {
-  return dtype == HDU_BF16 && !g_tuning[HDU_TUNE_NO_HALO_FPROP] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 &&
+  return dtype == HDU_BF16 && k.bnb_u == nullptr && !g_tuning[HDU_TUNE_NO_HALO_FPROP] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 &&
          k.KH == 3 && k.KW == 3 && k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 &&
          (k.ud | k.uh | k.uw) == 0 && k.Di == 1 && k.Cin % 8 == 0 && k.We >= 32 && k.He >= 4 &&
          // measured: pays when the K loop is long (>= 4 chunks of 32 channels) and one N tile covers Cout

@@ -19,6 +19,9 @@ struct FinK {
   float* a; float* b; float* rstd; float* mov_mean; float* mov_var;          // kind 1 outputs
   const float* rstd_in;                                                        // kind 2 input
   float* k1; float* k2; float* k3; float* dgamma; float* dbeta; float* dsgamma; float* dsbeta;  // kind 2 outputs
+  // kind 3 (sums of a fused conv-epilogue BN backward): parameter gradients as kind 2, and the deferred part of du
+  // accumulated per stored channel: corr3 += k3, corr4 += k3*mean - k2
+  const float* mean_in; float* corr3; float* corr4;
 };
 
 // tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
@@ -81,11 +84,22 @@ __device__ __forceinline__ void finalize_channel(int c, double a1, double a2, lo
       bn_fold_channel(c, (float)(shift + m1), (float)var, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a,
                       fin.b, fin.rstd, fin.mov_mean, fin.mov_var, fin.momentum);
   } else {
-    o1[c] = (float)a1;
+    if (o1) o1[c] = (float)a1;
     if (o2) o2[c] = (float)a2;
     if (MODE == 1 && fin.kind == 2)   // RED_BNBWD
       bn_coef_channel(c, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma, fin.beta, fin.sgamma, fin.rstd_in,
                       fin.k1, fin.k2, fin.k3, fin.dgamma, fin.dbeta, fin.dsgamma, fin.dsbeta);
+    if (MODE == 1 && fin.kind == 3) {
+      float k1, k2, k3;
+      bn_coef_channel(0, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma ? fin.gamma + c : nullptr,
+                      fin.beta ? fin.beta + c : nullptr, fin.sgamma ? fin.sgamma + c : nullptr, fin.rstd_in + c, &k1, &k2,
+                      &k3, fin.dgamma ? fin.dgamma + c : nullptr, fin.dbeta ? fin.dbeta + c : nullptr,
+                      fin.dsgamma ? fin.dsgamma + c : nullptr, fin.dsbeta ? fin.dsbeta + c : nullptr);
+      if (fin.batch_stats) {
+        fin.corr3[c] += k3;
+        fin.corr4[c] += k3 * fin.mean_in[c] - k2;
+      }
+    }
   }
 }
 
@@ -408,6 +422,21 @@ extern "C" int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M,
   return hdu_check_launch("bn_stats_finalize");
 }
 
+extern "C" int hdu_bn_bwd_finalize(const float* partial, int slots, int64_t M, int C, int batch_stats, const float* gamma,
+                                   const float* beta, const float* sgamma, const float* mean, const float* rstd,
+                                   float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, float* corr3, float* corr4,
+                                   void* stream) {
+  if (!partial || slots <= 0 || M <= 0 || C <= 0 || !rstd || (batch_stats && (!mean || !corr3 || !corr4)))
+    return hdu_set_error(HDU_ERR_ARG, "bn_bwd_finalize: bad args");
+  FinK f{};
+  f.kind = 3; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.rstd_in = rstd; f.invM = 1.0f / (float)M;
+  f.batch_stats = batch_stats; f.dgamma = dgamma; f.dbeta = dbeta; f.dsgamma = dsgamma; f.dsbeta = dsbeta;
+  f.mean_in = mean; f.corr3 = corr3; f.corr4 = corr4;
+  HDU_LAUNCH((reduce_finalize_kernel<float, RED_BNBWD>), dim3((unsigned)((C + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+             partial, slots, C, (long long)M, (const void*)nullptr, (float*)nullptr, (float*)nullptr, f);
+  return hdu_check_launch("bn_bwd_finalize");
+}
+
 extern "C" int hdu_bn_bwd_reduce_coef(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
                                       int C, const float* a, const float* b, int relu, const float* mean,
                                       const float* rstd, int batch_stats, const float* gamma, const float* beta,
@@ -629,6 +658,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   for (; m < r_end; m += ROWS)
     body(m, *(const u32x4*)(xp + m * p.ldx + c0), *(const u32x4*)(dzp + m * p.lddz + c0),
          p.accumulate ? *(const u32x4*)(op + m * p.ldo + c0) : z4);
+}
+
+// du += -corr3*u + corr4 (hdu_bn_bwd_correct): the deferred part of the BN backward of every consumer of these channels
+template <typename T, int COLS>
+__global__ __launch_bounds__(256) void bn_bwd_correct_kernel(RowK p) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int ROWS = 256 / COLS;
+  const int cc = threadIdx.x % COLS, rl = threadIdx.x / COLS;
+  const int c0 = (blockIdx.y * COLS + cc) * CH;
+  if (c0 >= p.C) return;
+  const T* __restrict__ xp = (const T*)p.x;
+  T* __restrict__ op = (T*)p.out;
+  float k3[CH], k4[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { k3[j] = p.k3[c0 + j]; k4[j] = p.k2[c0 + j]; }
+  const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
+  long long r_end = r_begin + p.rows_per_block;
+  if (r_end > p.M) r_end = p.M;
+  auto body = [&](long long m, const u32x4& xv, const u32x4& ov) {
+    float f[CH], o[CH];
+    Chunk<T>::unpack(xv, f);
+    Chunk<T>::unpack(ov, o);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o[j] += k4[j] - k3[j] * f[j];
+    *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(o);
+  };
+  long long m = r_begin + rl;
+  for (; m + (ROW_UNROLL - 1) * ROWS < r_end; m += ROW_UNROLL * ROWS) {
+    u32x4 xv[ROW_UNROLL], ov[ROW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) xv[u] = *(const u32x4*)(xp + (m + u * ROWS) * p.ldx + c0);
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) ov[u] = *(const u32x4*)(op + (m + u * ROWS) * p.ldo + c0);
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) body(m + u * ROWS, xv[u], ov[u]);
+  }
+  for (; m < r_end; m += ROWS) body(m, *(const u32x4*)(xp + m * p.ldx + c0), *(const u32x4*)(op + m * p.ldo + c0));
 }
 
 // geometry shared by the row kernels: column groups of COLS chunks, row blocks sized to ~2048 workgroups
@@ -869,6 +936,21 @@ extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const v
   if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(bn_bwd_apply_kernel, bf16_t, cols, gx, gy, stream, k); }
   else { HDU_ROW_LAUNCH(bn_bwd_apply_kernel, float, cols, gx, gy, stream, k); }
   return hdu_check_launch("bn_bwd_apply");
+}
+
+extern "C" int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t M, int C, const float* corr3,
+                                  const float* corr4, void* du, int64_t lddu, void* stream) {
+  RowK k{};
+  k.x = u; k.ldx = ldu; k.out = du; k.ldo = lddu; k.M = M; k.C = C;
+  k.k3 = corr3; k.k2 = corr4;          // the kernel reads corr3 through k3 and corr4 through k2
+  if (!u || !du || !corr3 || !corr4) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_correct: null pointer");
+  if (int e = rowk_check(dtype, k, "bn_bwd_correct: C / strides must be multiples of the 16-byte chunk")) return e;
+  if (M == 0) return 0;
+  int cols; unsigned gx, gy;
+  row_geometry(dtype, M, C, &cols, &gx, &gy, &k.rows_per_block);
+  if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(bn_bwd_correct_kernel, bf16_t, cols, gx, gy, stream, k); }
+  else { HDU_ROW_LAUNCH(bn_bwd_correct_kernel, float, cols, gx, gy, stream, k); }
+  return hdu_check_launch("bn_bwd_correct");
 }
 
 // ====================================================================== pooling / resampling

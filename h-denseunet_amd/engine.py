@@ -56,6 +56,7 @@ class Var:
             self.var = None
             self.needs_grad = False
             self.drop = None  # (keep, seed) if produced through dropout
+            self.corr_off = None   # offset of this tensor's [2][ld] deferred-BN-backward accumulators in Ctx.corr_acc
         self.C = act.C
 
     def slab(self, c0, C):
@@ -73,6 +74,18 @@ class Var:
     @property
     def grad(self):
         return self.root.grad_act.slab(self.c0, self.C)
+
+    def dy(self):
+        """the gradient of these channels as a READER takes it (the producing layer's backward): first the deferred,
+        reduction-dependent part of the BN backward of every fused consumer of these channels (`-k3*u + k4`, summed over
+        the consumers in corr3 / corr4 by hdu_bn_bwd_finalize) is added -- once, over just these channels."""
+        r = self.root
+        if r.corr_off is not None and self.ctx.corr_acc is not None and self.ctx.fuse_bn_bwd_now:
+            ld = r.act.ld
+            base = r.corr_off + self.c0
+            acc = self.ctx.corr_acc
+            ops.bn_bwd_correct(self.act, acc[base:base + self.C], acc[base + ld:base + ld + self.C], self.grad)
+        return self.grad
 
     def grad_mode(self):
         """returns accumulate flag for a writer into this var's gradient; first writer overwrites"""
@@ -135,6 +148,15 @@ class Ctx:
         # inference-mode BN folds depend on parameters only: all of them (every BN in a predict pass, the frozen ones in
         # a training pass) run as ONE launch at the head of the forward instead of one launch per layer
         self.batch_fold = os.environ.get("HDU_BATCH_FOLD", "1") == "1"
+        # BN(+Scale)+ReLU backward fused into the epilogue of the data-gradient launch that produces dz (include/hdu.h,
+        # hdu_conv_desc.bnb_*): no dz round trip, no reduction pass, and the full-width apply pass of a dense-block layer
+        # (C0 + l*growth channels) shrinks to a correction over the producer's own channels
+        self.fuse_bn_bwd = os.environ.get("HDU_FUSE_BN_BWD", "1") == "1"
+        self.fuse_bn_bwd_now = False
+        self.bnb_sinks = []          # (layer, offset into bnb_acc)
+        self.bnb_acc = None
+        self.corr_acc = None
+        self._corr_total = 0
         self._scratch = {}
         self.ws_bytes = 1 << 16
         self.ws = None
@@ -219,6 +241,17 @@ class Ctx:
             st.acc_off = tot
             tot += st.SLOTS * 2 * st.var.C
         self.stats_acc = torch.zeros(tot, dtype=torch.float32, device=self.dev) if tot else None
+        tot = 0
+        for cv in self.convs:
+            if cv.bnb_fused:
+                cv.bnb_off = tot
+                tot += cv.BNB_SLOTS * 2 * cv.bn.C
+                r = cv.x.root
+                if cv.bn.mode == "batch" and r.corr_off is None:
+                    r.corr_off = self._corr_total
+                    self._corr_total += 2 * r.act.ld
+        self.bnb_acc = torch.zeros(tot, dtype=torch.float32, device=self.dev) if tot else None
+        self.corr_acc = torch.zeros(self._corr_total, dtype=torch.float32, device=self.dev) if self._corr_total else None
         for cv in self.convs:
             cv.bind()
         self._build_prep_table()
@@ -385,6 +418,12 @@ class Ctx:
             for v in self.vars:
                 v.written = False
             self.wgrad_open = False
+            self.fuse_bn_bwd_now = self.fuse_bn_bwd and (self.shard is None or self.shard.world == 1)
+            if self.fuse_bn_bwd_now:
+                if self.bnb_acc is not None:
+                    self.bnb_acc.zero_()
+                if self.corr_acc is not None:
+                    self.corr_acc.zero_()
         order = list(reversed(self.bwd))
         for f in order[lo:hi]:
             f()
@@ -602,6 +641,11 @@ class ConvLayer:
                 self.xin = ctx.new_var(xa.N, xa.D, xa.H, xa.W, cin_p)
         self.need_input_grad = need_input_grad
         self.strided = stride != (1, 1, 1)
+        # the consumer BN's backward runs in the epilogue of this layer's data-gradient launch when dz IS that launch's
+        # output: no up-sampling in between, no skip add, no depth halo, no dropout on the BN input
+        self.bnb_fused = bool(ctx.fuse_bn_bwd and need_input_grad and bn is not None and up == (0, 0, 0) and skip is None
+                              and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None)
+        self.bnb_off = None
         self.need_dgrad_filter = need_input_grad and not self.strided
         self.wf_off = self.wd_off = None
         ctx.convs.append(self)
@@ -692,7 +736,7 @@ class ConvLayer:
         out = self.out
         if not out.root.needs_grad:
             return
-        dy = out.grad
+        dy = out.dy()
         x = self.x.act
         if self.trainable and getattr(self, "in_plan", False):
             if self.bias is not None:
@@ -720,6 +764,8 @@ class ConvLayer:
         K, pad = self.K, self.pad
         if self.halo:
             return self._backward_halo(dy)
+        if self.bnb_fused and ctx.fuse_bn_bwd_now:
+            return self._backward_fused_bn(dy)
         De, He, We = x.D << self.up[0], x.H << self.up[1], x.W << self.up[2]
         direct = self.bn is None and self.up == (0, 0, 0)
         skip_first = self.skip is not None and self.skip.root.needs_grad and not self.skip.root.written \
@@ -755,6 +801,46 @@ class ConvLayer:
             self.bn.backward(self.x, dz)
         else:
             ops.upsample_bwd(dz, self.x.grad, (0, 0, 0), accumulate=self.x.grad_mode())
+
+
+def _conv_backward_fused_bn(self, dy):
+    """data gradient with the BN(+Scale)+ReLU backward of `self.bn` in its epilogue: x.grad (+)= a * g directly, S1 / S2
+    into slot rows; hdu_bn_bwd_finalize turns the sums into the parameter gradients and adds this BN's share of the
+    deferred part of du to the accumulators of the tensor it normalises (applied by Var.dy())."""
+    ctx, bn, xv = self.ctx, self.bn, self.x
+    x = xv.act
+    K, pad = self.K, self.pad
+    acc = xv.grad_mode()
+    tgt = xv.grad
+    d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, x.D, x.H, x.W, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
+                      (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)
+    d.bnb_u, d.bnb_ldu = x.ptr, x.ld
+    d.bnb_a, d.bnb_b, d.bnb_relu = bn.a.data_ptr(), bn.b.data_ptr(), 1 if bn.relu else 0
+    need_sums = bn.batch_now or bn.any_trainable()
+    part = None
+    if need_sums:
+        n = self.BNB_SLOTS * 2 * bn.C
+        part = ctx.bnb_acc[self.bnb_off:self.bnb_off + n]
+        d.bnb_mean, d.bnb_rstd = bn.mean_used.data_ptr(), bn.rstd.data_ptr()
+        d.bnb_partial, d.bnb_slots = part.data_ptr(), self.BNB_SLOTS
+    ops.conv_fprop(d)
+    if need_sums:
+        tr_bn = bn.trainable
+        tr_sc = bn.sg is not None and bn.scale_trainable
+        c3 = c4 = None
+        if bn.batch_now:
+            r = xv.root
+            ld = r.act.ld
+            base = r.corr_off + xv.c0
+            c3, c4 = ctx.corr_acc[base:base + bn.C], ctx.corr_acc[base + ld:base + ld + bn.C]
+        ops.bn_bwd_finalize(part, self.BNB_SLOTS, x.M, bn.C, bn.batch_now, bn.gamma.data, bn.beta.data,
+                            bn.sg.data if bn.sg else None, bn.mean_used, bn.rstd,
+                            bn.gamma.grad if tr_bn else None, bn.beta.grad if tr_bn else None,
+                            bn.sg.grad if tr_sc else None, bn.sb.grad if tr_sc else None, c3, c4)
+
+
+ConvLayer._backward_fused_bn = _conv_backward_fused_bn
+ConvLayer.BNB_SLOTS = 32
 
 
 def _conv_backward_halo(self, dy):
@@ -892,7 +978,7 @@ class MaterializeLayer:
             _sh.halo_reduce(self.ctx.shard, self.out.grad, self.halo, self._halo_tmp().buf)
             self.bn.backward(self.x, self._interior(self.out.grad))
         else:
-            self.bn.backward(self.x, self.out.grad)
+            self.bn.backward(self.x, self.out.dy())
 
 
 class MaxPoolLayer:
@@ -915,7 +1001,7 @@ class MaxPoolLayer:
 
     def backward(self):
         if self.out.root.needs_grad and self.x.root.needs_grad:
-            ops.maxpool_bwd(self.argmax, self.out.grad, self.x.grad, self.x.grad_mode(), self.pad_d)
+            ops.maxpool_bwd(self.argmax, self.out.dy(), self.x.grad, self.x.grad_mode(), self.pad_d)
 
 
 class AvgPoolLayer:
@@ -930,7 +1016,7 @@ class AvgPoolLayer:
 
     def backward(self):
         if self.out.root.needs_grad and self.x.root.needs_grad:
-            ops.avgpool_bwd(self.out.grad, self.x.grad, self.x.grad_mode())
+            ops.avgpool_bwd(self.out.dy(), self.x.grad, self.x.grad_mode())
 
 
 class LossLayer:

@@ -41,6 +41,10 @@ class ConvDesc(ctypes.Structure):
         ("stats_partial", c_p),
         ("stats_shift", c_p),
         ("stats_slots", c_int),
+        ("bnb_u", c_p), ("bnb_ldu", c_i64),
+        ("bnb_a", c_p), ("bnb_b", c_p), ("bnb_mean", c_p), ("bnb_rstd", c_p),
+        ("bnb_relu", c_int),
+        ("bnb_partial", c_p), ("bnb_slots", c_int),
         ("splitk_ws", c_p),
         ("splitk_ws_bytes", c_sz),
         ("splitk_counters", c_p),
@@ -63,6 +67,8 @@ _SIGS = {
     "hdu_abi_version": (c_int, []),
     "hdu_set_tuning": (c_int, [c_int, c_int]),
     "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
+    "hdu_bn_bwd_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "hdu_bn_bwd_correct": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_i64, c_p]),
     "hdu_conv_splitk_ws_bytes": (c_sz, [ctypes.POINTER(ConvDesc)]),
     "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),

@@ -300,6 +300,18 @@ def bn_bwd_apply(dz, x, a, b, relu, mean, k1, k2, k3, dx, accumulate=False, drop
                                     stream()), "hdu_bn_bwd_apply")
 
 
+def bn_bwd_finalize(partial, slots, M, C, batch_stats, gamma, beta, sgamma, mean, rstd, dgamma, dbeta, dsgamma, dsbeta,
+                    corr3, corr4):
+    check(_l.get().hdu_bn_bwd_finalize(fptr(partial), slots, M, C, 1 if batch_stats else 0, fptr(gamma), fptr(beta),
+                                       fptr(sgamma), fptr(mean), fptr(rstd), fptr(dgamma), fptr(dbeta), fptr(dsgamma),
+                                       fptr(dsbeta), fptr(corr3), fptr(corr4), stream()), "hdu_bn_bwd_finalize")
+
+
+def bn_bwd_correct(u, corr3, corr4, du):
+    check(_l.get().hdu_bn_bwd_correct(u.dtype, u.ptr, u.ld, u.M, u.C, fptr(corr3), fptr(corr4), du.ptr, du.ld, stream()),
+          "hdu_bn_bwd_correct")
+
+
 def affine_act(x, a, b, relu, z):
     check(_l.get().hdu_affine_act(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0, z.ptr, z.ld,
                                   stream()), "hdu_affine_act")

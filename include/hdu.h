@@ -100,6 +100,20 @@ typedef struct hdu_conv_desc {
   float* stats_partial;
   const float* stats_shift;
   int stats_slots;
+  /* optional fused BatchNormalization(+Scale)+ReLU BACKWARD in the epilogue of a data-gradient launch (x = dy, w = the
+   * flipped filter): the launch's output tile is dz, the gradient w.r.t. z = relu(a*u + b) where u (`bnb_u`, same pixel
+   * grid and channel count as the output) is the BN input of the forward pass.  Instead of storing dz the epilogue
+   *   - stores (or, with `accumulate`, adds to) a[c] * g,  g = dz where a*u+b > 0 (or everywhere when bnb_relu == 0):
+   *     the part of du that needs no reduction (tf.gradients of TFB:1639 batch_normalization: du = a*(g - mean(g) -
+   *     uhat*mean(g*uhat)); the two mean terms are an affine function of u applied later by hdu_bn_bwd_correct);
+   *   - accumulates S1[c] += sum g and S2[c] += sum g*(u - bnb_mean[c])*bnb_rstd[c] into bnb_partial[slot][0|1][c]
+   *     (float atomics, slot = workgroup % bnb_slots; caller zeroes it; NULL = no sums wanted), finished by
+   *     hdu_bn_bwd_finalize.
+   * Replaces, per BN, the dz round trip through HBM, the reduction pass and the full-width apply pass. */
+  const void* bnb_u;  int64_t bnb_ldu;
+  const float* bnb_a; const float* bnb_b; const float* bnb_mean; const float* bnb_rstd;
+  int bnb_relu;
+  float* bnb_partial; int bnb_slots;
   /* optional split-K scratch of hdu_conv_fprop.  Layers whose output grid cannot fill the chip (dense blocks at 1/16 and
    * 1/32 resolution, every 3D dense block: M = 147..9408 pixels) are bound by what ONE compute unit can pull from L2;
    * with scratch the K loop is split over `S` workgroups per output tile (S chosen by the library,
@@ -110,6 +124,20 @@ typedef struct hdu_conv_desc {
   size_t splitk_ws_bytes;
   uint32_t* splitk_counters;
 } hdu_conv_desc;
+
+/* finishes the sums of a fused BN-backward epilogue (hdu_conv_desc.bnb_partial): S1, S2 totals -> parameter gradients
+ * (dgamma = sg*S2, dbeta = sg*S1, dsgamma = g*S2 + beta*S1, dsbeta = S1; NULL = not wanted) and, for a batch-statistics
+ * BN (batch_stats != 0), the coefficients of the deferred part of du = -k3*u + k4 ADDED to corr3 / corr4 (one pair of
+ * per-channel accumulators per stored tensor: every consumer BN of a dense-block slab adds its own; the caller zeroes
+ * them once per backward pass).  k3 = a*rstd*S2/M, k4 = k3*mean - a*S1/M. */
+int hdu_bn_bwd_finalize(const float* partial, int slots, int64_t M, int C, int batch_stats, const float* gamma,
+                        const float* beta, const float* sgamma, const float* mean, const float* rstd, float* dgamma,
+                        float* dbeta, float* dsgamma, float* dsbeta, float* corr3, float* corr4, void* stream);
+
+/* du[m][c] += -corr3[c]*u[m][c] + corr4[c]: the deferred, reduction-dependent part of the BN backward of every consumer
+ * of these channels, applied ONCE, right before their producer reads the gradient. */
+int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t M, int C, const float* corr3, const float* corr4,
+                       void* du, int64_t lddu, void* stream);
 
 /* bytes of split-K scratch hdu_conv_fprop would use for this descriptor (0 = it would not split) */
 size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d);

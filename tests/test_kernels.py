@@ -289,6 +289,84 @@ def test_conv_dgrad_via_fprop(hdu, cs, dtype, dma_stages):
     assert_close(dxe.to_torch().cpu(), xe.grad, dtype, what="dgrad")
 
 
+BNB_CASES = [
+    # data-gradient launches whose output is dz of a BN(+Scale)+ReLU: (pixels, dy channels = K side, dz channels = N side)
+    dict(N=2, D=1, H=9, W=7, Cdy=192, Cu=144, K=(1, 1, 1), p=(0, 0, 0), ldu=200, acc=True, sums=True, relu=True, id="x1_1x1_slab_acc"),
+    dict(N=1, D=1, H=10, W=12, Cdy=48, Cu=192, K=(1, 3, 3), p=(0, 1, 1), ldu=None, acc=False, sums=True, relu=True, id="x2_3x3_two_tiles"),
+    dict(N=1, D=3, H=5, W=6, Cdy=32, Cu=128, K=(3, 3, 3), p=(1, 1, 1), ldu=None, acc=False, sums=True, relu=True, id="x2_3x3x3"),
+    dict(N=1, D=1, H=16, W=16, Cdy=192, Cu=1056, K=(1, 1, 1), p=(0, 0, 0), ldu=None, acc=True, sums=False, relu=True, id="frozen_no_sums_wide"),
+    dict(N=1, D=1, H=6, W=6, Cdy=24, Cu=40, K=(1, 1, 1), p=(0, 0, 0), ldu=56, acc=False, sums=True, relu=False, id="no_relu_ragged_n"),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in BNB_CASES])
+def test_conv_fused_bn_backward(hdu, cs, dtype):
+    """hdu_conv_desc.bnb_*: the epilogue of a data-gradient launch stores a*g (g = dz masked by the forward ReLU) into /
+    onto the gradient slab and leaves S1 = sum g, S2 = sum g*uhat in slot rows; hdu_bn_bwd_finalize turns them into the
+    parameter gradients and the corr3 / corr4 accumulators, hdu_bn_bwd_correct applies -corr3*u + corr4: together
+    exactly tf.gradients of BN(+Scale)+ReLU (TFB:1639) in float64."""
+    import ctypes
+    ops = ops_mod()
+    N, D, H, W, Cdy, Cu, K, p = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cdy"], cs["Cu"], cs["K"], cs["p"]
+    M = N * D * H * W
+    dy = rnd((N, D, H, W, Cdy), 1, 1.0, dtype)
+    w = rnd((Cu,) + K + (Cdy,), 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cdy), dtype)      # the data-gradient filter [N side][taps][K side]
+    u = rnd((N, D, H, W, Cu), 7, 1.0, dtype)
+    old = rnd((N, D, H, W, Cu), 8, 0.5, dtype)
+    a = (rnd((Cu,), 9, 1.0).abs() + 0.3).float().double()
+    b = rnd((Cu,), 10, 0.4).float().double()
+    mean = rnd((Cu,), 11, 0.3).float().double()
+    rstd = (rnd((Cu,), 12, 0.5).abs() + 0.5).float().double()
+    dya = mkact(ops, dy, dtype)
+    ua = mkact(ops, u, dtype, cs["ldu"], 8 if cs["ldu"] else 0)
+    outa = mkact(ops, old, dtype, cs["ldu"], 8 if cs["ldu"] else 0)
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    slots = 5
+    keep = [dev(ops, t) for t in (a, b, mean, rstd)]
+    partial = torch.zeros(slots * 2 * Cu, dtype=torch.float32, device=ops.device())
+    d = ops.conv_desc(dya, ctypes.c_void_p(wt.data_ptr()), outa, K, (1, 1, 1), p, accumulate=cs["acc"])
+    d.bnb_u, d.bnb_ldu = ua.ptr, ua.ld
+    d.bnb_a, d.bnb_b, d.bnb_relu = keep[0].data_ptr(), keep[1].data_ptr(), 1 if cs["relu"] else 0
+    if cs["sums"]:
+        d.bnb_mean, d.bnb_rstd, d.bnb_partial, d.bnb_slots = keep[2].data_ptr(), keep[3].data_ptr(), partial.data_ptr(), slots
+    ops.conv_fprop(d)
+    # reference: dz = conv(dy, w) in the storage dtype (the tile is staged in it), then the masked scale
+    dz = q(ref_conv(dy, w, (1, 1, 1), p, None), dtype)
+    s = a * u + b
+    g = torch.where(s > 0, dz, torch.zeros_like(dz)) if cs["relu"] else dz
+    ref = a * g + (q(old, dtype) if cs["acc"] else 0.0)
+    assert_close(outa.to_torch().cpu(), ref, dtype, scale=float(ref.abs().max()), what="a*g")
+    if cs["ldu"]:       # neighbouring slab channels untouched
+        full = ops.Act(outa.buf, 0, N, D, H, W, cs["ldu"], cs["ldu"], dtype).to_torch().cpu()
+        assert float((full[..., :8] - 7.0).abs().max()) == 0.0 and float((full[..., 8 + Cu:] - 7.0).abs().max()) == 0.0
+    if not cs["sums"]:
+        return
+    S = partial.cpu().double().reshape(slots, 2, Cu).sum(0)
+    S1, S2 = g.reshape(M, Cu).sum(0), (g * (u - mean) * rstd).reshape(M, Cu).sum(0)
+    tol = 2e-5 if dtype == F32 else 2e-3
+    sc = float(max(S1.abs().max(), S2.abs().max()))
+    assert float((S[0] - S1).abs().max()) <= tol * sc and float((S[1] - S2).abs().max()) <= tol * sc
+    # finalize: parameter gradients + deferred coefficients; correct: du += -corr3*u + corr4
+    gamma = (rnd((Cu,), 13, 0.5).abs() + 0.5).float().double()
+    beta = rnd((Cu,), 14, 0.3).float().double()
+    sg = (rnd((Cu,), 15, 0.5).abs() + 0.5).float().double()
+    z = lambda: torch.zeros(Cu, dtype=torch.float32, device=ops.device())
+    dg, db, dsg, dsb, c3, c4 = z(), z(), z(), z(), z(), z()
+    c3.fill_(0.25)                                        # the accumulators ADD (other consumers were there first)
+    kp = [dev(ops, t) for t in (gamma, beta, sg)]
+    ops.bn_bwd_finalize(partial, slots, M, Cu, True, kp[0], kp[1], kp[2], keep[2], keep[3], dg, db, dsg, dsb, c3, c4)
+    kk = sg * gamma * rstd
+    k2, k3 = kk * S1 / M, kk * rstd * S2 / M
+    for got, want, what in ((dg, sg * S2, "dgamma"), (db, sg * S1, "dbeta"), (dsg, gamma * S2 + beta * S1, "dsgamma"),
+                            (dsb, S1, "dsbeta"), (c3, 0.25 + k3, "corr3"), (c4, k3 * mean - k2, "corr4")):
+        assert float((got.cpu().double() - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), what
+    before = outa.to_torch().cpu()
+    ops.bn_bwd_correct(ua, c3, c4, outa)
+    want = before - c3.cpu().double() * q(u, dtype) + c4.cpu().double()
+    assert_close(outa.to_torch().cpu(), want, dtype, scale=float(want.abs().max()), what="correct")
+
+
 SPLITK_CASES = [
     # dense-block shapes whose output grid cannot fill the chip (include/hdu.h, hdu_conv_desc.splitk_ws)
     dict(N=2, D=1, H=16, W=15, Cin=192, Cout=48, K=(1, 3, 3), p=(0, 1, 1), bias=False, ldout=96, id="block5_3x3_192to48"),

@@ -215,3 +215,35 @@ def test_splitk_step_vs_float64_oracle(emu_lib):
                 assert float(np.abs(gg[n][i] - g.numpy()).max()) <= 2e-3 * sc, (S, n, i)
     finally:
         lib.hdu_set_tuning(13, 0)
+
+
+@pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 2, 64, None), ("hybrid", "end2end", 1, 32, 8),
+                                                      ("hybrid", "3dpart", 1, 32, 8)])
+def test_fused_bn_backward_equals_separate_passes(emu_lib, monkeypatch, kind, variant, b, size, cols):
+    """BN(+Scale)+ReLU backward in the epilogue of the data-gradient launch (hdu_conv_desc.bnb_*: a*g stored / added
+    directly, S1 / S2 in slot rows, the mean terms deferred to hdu_bn_bwd_correct over the producer's own channels) vs
+    the separate reduction + apply passes (HDU_FUSE_BN_BWD=0): same loss, same gradient of every parameter -- batch
+    statistics BNs (2D net), inference-mode BNs with trainable Scale (end2end), 3D dense blocks with batch statistics."""
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("HDU_FUSE_BN_BWD", on)
+        m, P, fwd = U.build_pair(kind, variant, b, size, cols, "f32", NB2D, NB3D, odtype=torch.float32)
+        nf = sum(1 for cv in m.ctx.convs if cv.bnb_fused)
+        assert (nf >= 8) == (on == "1"), nf
+        m.ctx.dropout_enabled = False
+        m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True),
+                  loss=[U.pkg("loss").weighted_crossentropy])
+        x, y = U.synthetic_batch(kind, b, size, cols)
+        loss = m.train_on_batch(x, y)
+        res.append((loss, m.get_grads_dict()))
+    (l1, g1), (l0, g0) = res
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    gmax = max(float(np.abs(a).max()) for gs in g0.values() for a in gs)
+    worst = (0.0, None)
+    for n, gs in g0.items():
+        for i, a in enumerate(gs):
+            sc = max(float(np.abs(a).max()), 1e-3 * gmax)
+            e = float(np.abs(g1[n][i] - a).max()) / sc
+            if e > worst[0]:
+                worst = (e, (n, i))
+    assert worst[0] <= 2e-4, worst
