@@ -152,6 +152,7 @@ class Ctx:
         # hdu_conv_desc.bnb_*): no dz round trip, no reduction pass, and the full-width apply pass of a dense-block layer
         # (C0 + l*growth channels) shrinks to a correction over the producer's own channels
         self.fuse_bn_bwd = os.environ.get("HDU_FUSE_BN_BWD", "1") == "1"
+        self.fuse_bn_bwd_max_m = int(os.environ.get("HDU_FUSE_BN_BWD_MAXM", "0"))      # 0 = no pixel-count limit
         self.fuse_bn_bwd_now = False
         self.bnb_sinks = []          # (layer, offset into bnb_acc)
         self.bnb_acc = None
@@ -644,7 +645,8 @@ class ConvLayer:
         # the consumer BN's backward runs in the epilogue of this layer's data-gradient launch when dz IS that launch's
         # output: no up-sampling in between, no skip add, no depth halo, no dropout on the BN input
         self.bnb_fused = bool(ctx.fuse_bn_bwd and need_input_grad and bn is not None and up == (0, 0, 0) and skip is None
-                              and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None)
+                              and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None
+                              and (ctx.fuse_bn_bwd_max_m <= 0 or xa.M <= ctx.fuse_bn_bwd_max_m))
         self.bnb_off = None
         self.need_dgrad_filter = need_input_grad and not self.strided
         self.wf_off = self.wd_off = None

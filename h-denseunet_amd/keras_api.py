@@ -296,9 +296,13 @@ class Model:
         self._graph = (g_fb, g_upd)
         self._graph_hparams = (self.optimizer.lr, self.optimizer.momentum)
 
-    def train_on_batch(self, x, y, **kw):
-        self._upload_x(x)
-        self.loss_layer.set_labels(self._labels_internal(y))
+    def train_on_batch(self, x, y=None, **kw):
+        if hasattr(x, "fill_model"):
+            # augment.DeviceBatch: the sample assembly kernels write input and labels straight into the model's buffers
+            x.fill_model(self)
+        else:
+            self._upload_x(x)
+            self.loss_layer.set_labels(self._labels_internal(y))
         self.train_step_resident()
         return self.loss_value()
 

@@ -56,6 +56,12 @@ class PrepEntry(ctypes.Structure):
                 ("Cout", ctypes.c_int32), ("T", ctypes.c_int32), ("Cin", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
+class AugSample(ctypes.Structure):
+    _fields_ = [("img_off", c_i64), ("vrows", ctypes.c_int32), ("vcols", ctypes.c_int32), ("vslices", ctypes.c_int32),
+                ("a0", ctypes.c_int32), ("b0", ctypes.c_int32), ("c0", ctypes.c_int32), ("crop", ctypes.c_int32),
+                ("flip", ctypes.c_int32)]
+
+
 class FoldEntry(ctypes.Structure):
     _fields_ = [("mean", c_p), ("var", c_p), ("gamma", c_p), ("beta", c_p), ("sgamma", c_p), ("sbeta", c_p),
                 ("a", c_p), ("b", c_p), ("rstd", c_p), ("C", ctypes.c_int32), ("eps", c_f)]
@@ -78,6 +84,8 @@ _SIGS = {
     "hdu_reduce_ws_bytes": (c_sz, [c_i64, c_int]),
     "hdu_bn_stats": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_sz, c_p]),
     "hdu_bn_fold": (c_int, [c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
+    "hdu_augment_batch": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_int, c_f, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64,
+                                  c_i64, c_p]),
     "hdu_bn_fold_batched": (c_int, [c_p, c_p, c_int, ctypes.c_uint32, c_p]),
     "hdu_bn_stats_fold": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p,
                                   c_p, c_f, c_p, c_sz, c_p]),

@@ -189,6 +189,25 @@ typedef struct hdu_prep_entry {
 int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, int n, int64_t total_tiles,
                             const float* master_base, void* wc_base, void* stream);
 
+/* ------------------------------------------------------------------ training-sample assembly (N3)
+ * train_2ddense.py:40-133 / train_hybrid.py:40-133 on the device: the pre-processed CT volumes (float32) and label
+ * volumes (uint8), each [rows][cols][slices] with slices fastest, stay resident in HBM; one call crops `crop` x `crop` x
+ * nslices voxels at (a0, b0, c0), subtracts `mean`, applies flip / rotation case `flip` (0..7, train_2ddense.py:73-101)
+ * and resizes to size x size exactly as skimage.transform.resize does for the reference's two calls (:103-104: labels
+ * order 0 mode 'edge'; image order 3 mode 'constant' cval 0 clip=True -- Catmull-Rom cubic convolution, output clipped
+ * to the crop's value range), writing sample n / output pixel p / slice k to x_out[n*x_sample + p*x_pix + k*x_slice]
+ * and the labels to y_out[n*y_sample + p] (lab_slice >= 0: that slice only, the 2D net's middle slice) or
+ * y_out[n*y_sample + k*y_slice + p] (lab_slice < 0: all slices, the hybrid).  minmax_ws: 2*n floats of scratch. */
+typedef struct hdu_aug_sample {
+  int64_t img_off;                 /* element offset of the case's volume inside img / lab */
+  int32_t vrows, vcols, vslices;
+  int32_t a0, b0, c0;
+  int32_t crop, flip;
+} hdu_aug_sample;
+int hdu_augment_batch(const float* img, const uint8_t* lab, const hdu_aug_sample* samples, int n, int size, int nslices,
+                      int lab_slice, float mean, float* minmax_ws, float* x_out, int64_t x_sample, int64_t x_pix,
+                      int64_t x_slice, uint8_t* y_out, int64_t y_sample, int64_t y_slice, void* stream);
+
 /* ------------------------------------------------------------------ batch normalisation
  * K.layers/normalization.py:126-190 -> TFB:1620-1664 (normalize_batch_in_training = tf.nn.moments +
  * tf.nn.batch_normalization), TFB:1667-1684 (inference), TFB:915-927 (moving_average_update);

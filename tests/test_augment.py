@@ -1,0 +1,89 @@
+"""N3: the training-sample pipeline of train_2ddense.py:40-133 / train_hybrid.py:40-133 on the device.
+
+  oracle/augment_ref.py (numpy restatement)  ==  the REAL skimage.transform.resize   (tests/golden/skimage_resize.npz)
+  csrc/augment.hip (hdu_augment_batch)       ==  oracle/augment_ref.make_sample      (all 8 flips, 2D and hybrid form)
+  augment.DeviceDataset.generator            ->  Model.fit_generator                  (end to end, nothing staged on the host)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as U
+from oracle import augment_ref as A
+
+GOLD = os.path.join(U.ROOT, "tests", "golden", "skimage_resize.npz")
+
+
+def test_oracle_resize_equals_skimage():
+    z = np.load(GOLD)
+    assert str(z["skimage_version"]) == "0.18.3"
+    for tag in ("down45", "up26", "same32", "hyb38", "rect", "poscval"):
+        got = A.resize_like_skimage(z[tag + "_img"], 32, 32, 3, "constant", 0.0, True)
+        np.testing.assert_allclose(got, z[tag + "_img_out"], rtol=0, atol=1e-9)
+        if tag + "_lab" in z.files:
+            np.testing.assert_array_equal(A.resize_like_skimage(z[tag + "_lab"], 32, 32, 0, "edge"), z[tag + "_lab_out"])
+
+
+def _phantoms(n, shape, seed):
+    syn = U.pkg("synth")
+    imgs, labs, liver, tumor, mins, maxs = [], [], [], [], [], []
+    for i in range(n):
+        vol, lab = syn.synthetic_ct(shape, seed + i)
+        imgs.append((vol + 48.0).astype(np.float32))          # the stored volumes are NOT mean-subtracted yet
+        labs.append(lab.astype(np.uint8))
+        idx = np.argwhere(lab > 0)
+        liver.append(idx[:: max(1, len(idx) // 200)])
+        t = np.argwhere(lab == 2)
+        tumor.append(t[:: max(1, len(t) // 200)])
+        mins.append(np.zeros(3, np.int64))
+        maxs.append(np.array(shape, np.int64))
+    return imgs, labs, liver, tumor, mins, maxs
+
+
+@pytest.mark.parametrize("hybrid", [False, True], ids=["2d", "hybrid"])
+def test_device_samples_equal_reference_pipeline(hdu, hybrid):
+    aug = U.pkg("augment")
+    size, cols = 32, 8
+    imgs, labs, liver, tumor, mins, maxs = _phantoms(2, (56, 56, 20), 5)
+    ds = aug.DeviceDataset(imgs, labs, liver, tumor, mins, maxs, mean=48.0)
+    if hybrid:
+        m = U.pkg("hybridnet").dense_rnn_net(U.make_args(1, size, cols), dtype="f32", nb_layers2d=(2, 2, 2, 2), nb_layers3d=(1, 1, 2, 1))
+    else:
+        m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(8, size), dtype="f32", nb_layers=(2, 2, 2, 2))
+    rng = np.random.RandomState(3)
+    n = 1 if hybrid else 8
+    for trial in range(8 if hybrid else 1):
+        params = [ds.draw(rng, size, cols if hybrid else 3, [0, 1]) for _ in range(n)]
+        for i, p in enumerate(params):
+            p["flip"] = (i + trial) % 8                                  # every flip / rotation case
+        aug.DeviceBatch(ds, params, hybrid).fill_model(m)
+        for i, p in enumerate(params):
+            x_ref, y_ref = A.make_sample(imgs[p["case"]], labs[p["case"]], p, size, cols, 48.0, hybrid)
+            if hybrid:
+                x = m.vol.reshape(cols, size, size).permute(1, 2, 0).cpu().numpy()
+                y = m.loss_layer.labels.reshape(cols, size, size).permute(1, 2, 0).cpu().numpy()
+            else:
+                x = m.x_stage.reshape(n, size, size, 3)[i].cpu().numpy()
+                y = m.loss_layer.labels.reshape(n, size, size)[i].cpu().numpy()
+            np.testing.assert_array_equal(y, y_ref.astype(np.uint8), err_msg="labels, flip %d" % p["flip"])
+            assert float(np.abs(x - x_ref).max()) <= 2e-4 * float(np.abs(x_ref).max()), "image, flip %d" % p["flip"]
+
+
+def test_generator_drives_fit_generator(emu_lib):
+    """train_2ddense.py:190-203 with the device pipeline: fit_generator pulls (DeviceBatch, None) items; same seed ->
+    same batches -> same loss history; different seed -> different batches"""
+    aug, ka = U.pkg("augment"), U.pkg("keras_api")
+    imgs, labs, liver, tumor, mins, maxs = _phantoms(2, (56, 56, 12), 9)
+    ds = aug.DeviceDataset(imgs, labs, liver, tumor, mins, maxs)
+
+    def run(seed):
+        m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(2, 32), dtype="f32", nb_layers=(2, 2, 2, 2), seed=1)
+        m.ctx.dropout_enabled = False
+        m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy_2ddense])
+        h = m.fit_generator(ds.generator(m, 2, 32, 3, seed=seed), steps_per_epoch=2, epochs=2, verbose=0)
+        return h.history["loss"]
+
+    a, b, c = run(4), run(4), run(5)
+    assert all(np.isfinite(a)) and np.allclose(a, b, rtol=5e-4) and not np.allclose(a, c, rtol=5e-3)   # (float atomics: not bitwise)
