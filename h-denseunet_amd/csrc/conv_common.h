@@ -58,24 +58,14 @@ __device__ __forceinline__ unsigned xcd_tile_index(unsigned bid, unsigned nblk) 
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Filter-gradient work grid -> this workgroup.  The grid is launched 1-D.  The hardware hands consecutive workgroup ids
-// to the 8 XCDs round-robin; with bit 1 of xcd_swizzle set, ALL gx*gy workgroups of one pixel split go to ONE XCD
-// back to back, so the x tile (shared by the gy filter-row tiles) and the dy tile (shared by the gx k-column tiles)
-// come from HBM once and are re-read from that XCD's L2.  Measured on the 2D bench: FETCH_SIZE of the dense-layer filter
-// gradients drops 4x (71 MB -> 17 MB per launch) but the kernels get SLOWER (43.8 -> 48.7 us; layers with < 8 pixel
-// splits collapse onto few XCDs): they are bound by DMA issue latency, not by fabric bytes.  OFF by default (bit 1 of
-// HDU_TUNE_XCD_SWIZZLE).  Returns false for the padding workgroups.
+// Filter-gradient work grid -> this workgroup (1-D launch): k-column tiles x filter-row tiles x pixel splits, pixel split
+// slowest.  (An XCD-grouped order -- all tiles of one pixel split on one XCD -- cuts the fabric traffic 4x and was
+// measured SLOWER both per layer in round 1 and in the batched launches in round 2, profiles/r02_experiment_wgrad_plan_
+// sweep_2d.txt: these kernels are bound by DMA issue latency and atomics, not bytes.  Removed.)
 __device__ __forceinline__ bool wgrad_block(const ConvK& p, unsigned bid, unsigned* bx, unsigned* by, unsigned* bz) {
   const unsigned per = (unsigned)(p.wg_gx * p.wg_gy);
-  unsigned w;
-  if (p.xcd_swizzle & 2) {
-    const unsigned slot = bid >> 3;
-    *bz = (slot / per) * 8u + (bid & 7u);
-    w = slot % per;
-  } else {
-    *bz = bid / per;
-    w = bid % per;
-  }
+  *bz = bid / per;
+  const unsigned w = bid % per;
   *by = w % (unsigned)p.wg_gy;
   *bx = w / (unsigned)p.wg_gy;
   return *bz < (unsigned)p.wg_gz;

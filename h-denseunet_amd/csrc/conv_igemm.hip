@@ -2156,8 +2156,6 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
       if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) grid.z = (unsigned)S;
       if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, k);
-    } else if (mode == 3) {
-      HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3, false>), grid, dim3(256), 0, s, k);
     } else {
       if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, false>), grid, dim3(256), 0, s, k);
@@ -2299,11 +2297,8 @@ static int choose_wgrad(const ConvK& k) {
   return best;
 }
 
-// 1-D grid of the XCD-grouped filter-gradient kernels (wgrad_block in conv_common.h)
-static unsigned wgrad_grid(const ConvK& k) {
-  const unsigned per = (unsigned)(k.wg_gx * k.wg_gy);
-  return (k.xcd_swizzle & 2) ? 8u * (unsigned)((k.wg_gz + 7) / 8) * per : (unsigned)k.wg_gz * per;
-}
+// 1-D grid of the filter-gradient kernels (wgrad_block in conv_common.h)
+static unsigned wgrad_grid(const ConvK& k) { return (unsigned)k.wg_gz * (unsigned)(k.wg_gx * k.wg_gy); }
 
 
 static bool wgrad_pointwise(const ConvK& k) {
@@ -2323,7 +2318,6 @@ static long long wgrad_dma_geometry(const ConvK& k, int BCO, int target, ConvK* 
   const int min_steps = g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_WGRAD_MIN_STEPS] : default_min_steps;
   if (want > (steps + min_steps - 1) / min_steps) want = (steps + min_steps - 1) / min_steps;
   if (want < 1) want = 1;
-  if ((k.xcd_swizzle & 2) && want >= 6) want = (want + 4) / 8 * 8;        // whole pixel splits per XCD: balance the 8 XCDs
   long long steps_per = (steps + want - 1) / want;
   const long long rows_per = steps_per * PX;
   const unsigned gz = (unsigned)((k.M + rows_per - 1) / rows_per);
@@ -2360,7 +2354,6 @@ static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk) {
   if (want < 1) want = 1;
   if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;
   if (want < 1) want = 1;
-  if ((k.xcd_swizzle & 2) && want >= 6) want = (want + 4) / 8 * 8;
   const int per = (tiles + want - 1) / want;
   const unsigned gz = (unsigned)((tiles + per - 1) / per);
   *kk = k;
@@ -2518,7 +2511,6 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const bool ring = dma && igemm_ring_ok(nblk, k.Ktot, stage, nsd);
     const char* fast = igemm_fast_ok(k) ? "true" : "false";
     if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, nsd, fast);
-    else if (dma && mode == 3) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, 3, false>", t, bm, bn, wm, 4 / wm);
     else if (dma) snprintf(buf, buflen, "conv_igemm_dma_kernel<%s, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, fast);
     else snprintf(buf, buflen, "conv_igemm_kernel<%s, %d, %d, %d, %d>", t, bm, bn, wm, 4 / wm);
   }

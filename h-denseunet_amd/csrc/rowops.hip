@@ -114,11 +114,6 @@ struct RedK {
   const float* mean;
   const float* rstd;
   float* partial;  // [gridDim.x][2][C]
-  // fused finalize (small tensors): the workgroup that draws the last ticket of its column group sums the partials
-  unsigned* counter;   // [gridDim.y] tickets, zero between launches (reset by the last workgroup); NULL = two kernels
-  float* o1;
-  float* o2;
-  FinK fin;
 };
 
 template <typename T, int MODE, int COLS>
@@ -204,41 +199,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
 #pragma unroll 4
       for (int r = 0; r < ROWS; ++r) t += red[s][r][col];
       float* dst = p.partial + ((long long)blockIdx.x * 2 + s) * p.C + c;
-      if (p.counter == nullptr) *dst = t; else hdu_store_agent(dst, t);
+      *dst = t;
     }
   }
-  if (p.counter == nullptr) return;
-  // ---- fused finalize: last workgroup of this column group
-  __shared__ int s_last;
-  __shared__ double fred[2][256];
-  HDU_WAIT_STORES();
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = hdu_ticket(p.counter + blockIdx.y);
-    s_last = (t == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  constexpr int NCL = COLS * CH > 256 ? 256 : COLS * CH;      // channels of the group (<= 256)
-  constexpr int PL = 256 / NCL;                               // partial lanes per channel
-  const int cl = tid % NCL, pl = tid / NCL;
-  const int c = blockIdx.y * COLS * CH + cl;
-  double a1 = 0.0, a2 = 0.0;
-  if (c < p.C) {
-    for (int b = pl; b < (int)gridDim.x; b += PL) {
-      a1 += (double)hdu_load_agent(p.partial + ((long long)b * 2 + 0) * p.C + c);
-      if (MODE != RED_COLSUM) a2 += (double)hdu_load_agent(p.partial + ((long long)b * 2 + 1) * p.C + c);
-    }
-  }
-  fred[0][tid] = a1;
-  fred[1][tid] = a2;
-  __syncthreads();
-  if (pl == 0 && c < p.C) {
-#pragma unroll
-    for (int q = 1; q < PL; ++q) { a1 += fred[0][q * NCL + cl]; a2 += fred[1][q * NCL + cl]; }
-    finalize_channel<T, MODE>(c, a1, a2, p.M, p.x, p.o1, p.o2, p.fin);
-  }
-  if (tid == 0) hdu_store_agent_u32(p.counter + blockIdx.y, 0u);   // ready for the next launch that uses this slot
 }
 
 // sums the per-block partials (double accumulation) and post-processes per mode.
@@ -291,17 +254,6 @@ static int red_cols_for(int nchunks) {
   while (cols < nchunks && cols < 32) cols <<= 1;
   return cols;
 }
-// Optional single-launch reduction for small tensors (<= 8192 pixels): at most 64 row blocks per column group, summed
-// by the group's last workgroup (ticket counter, agent-scope partials).  Measured SLOWER than the separate
-// 8-channel x 32-lane finalize kernel on the 2D bench (250 vs 284 slices/s): the last workgroup reads 64 x 2 x 256
-// partials through one CU with device-scope loads, which costs more than the launch it saves.  OFF by default
-// (HDU_TUNE_FUSED_FINALIZE); kept because the emulator/GPU tests cover it and a tree version may pay later.
-enum { RED_FUSED_MAX_GX = 64, RED_COUNTER_SLOTS = 64, RED_COUNTER_GY = 64 };
-__device__ unsigned hdu_red_counters[RED_COUNTER_SLOTS * RED_COUNTER_GY];
-static unsigned g_red_slot = 0;
-static bool red_fused(long long M, unsigned gy) {
-  return g_tuning[HDU_TUNE_FUSED_FINALIZE] && M <= 8192 && gy <= RED_COUNTER_GY;
-}
 static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx, unsigned* gy, long long* rpb) {
   const int ch = dtype == HDU_BF16 ? 8 : 4;
   const int nchunks = (C + ch - 1) / ch;
@@ -313,7 +265,6 @@ static void red_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);  // >= 4 rows per thread
   if (maxb < 1) maxb = 1;
   if (want > maxb) want = maxb;
-  if (red_fused(M, *gy) && want > RED_FUSED_MAX_GX) want = RED_FUSED_MAX_GX;
   *rpb = (M + want - 1) / want;
   if (*rpb < 1) *rpb = 1;
   *gx = (unsigned)((M + *rpb - 1) / *rpb);
@@ -357,20 +308,6 @@ static int reduce_entry(int dtype, RedK k, float* o1, float* o2, void* ws, size_
     return hdu_set_error(HDU_ERR_WORKSPACE, "reduce: workspace too small (see hdu_reduce_ws_bytes)");
   k.rows_per_block = rpb;
   k.partial = (float*)ws;
-  if (red_fused(k.M, gy)) {
-#ifdef HDU_EMU
-    unsigned* base = hdu_red_counters;
-#else
-    static unsigned* base = nullptr;
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(hdu_red_counters)) != hipSuccess)
-      return hdu_set_error(HDU_ERR_LAUNCH, "reduce: counter symbol");
-#endif
-    k.counter = base + (size_t)(g_red_slot++ % RED_COUNTER_SLOTS) * RED_COUNTER_GY;
-    k.o1 = o1; k.o2 = o2; k.fin = fin;
-    if (dtype == HDU_BF16) run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
-    else run_reduce<float, MODE>(k, cols, gx, gy, s);
-    return hdu_check_launch(what);
-  }
   const unsigned fb = (unsigned)((k.C + 7) / 8);
   if (dtype == HDU_BF16) {
     run_reduce<bf16_t, MODE>(k, cols, gx, gy, s);
@@ -733,13 +670,6 @@ struct MatK {
   long long ldx, ldskip, ldo, Mo, rows_per_block;
   int N, D, H, W, C;
   int ud, uh, uw, relu;
-  // optional in-kernel BN fold (saves the separate bn_fold launch of every dense-layer BN that shares slab statistics):
-  // every thread derives a/b of its own channels from (mean, var, gamma, beta, Scale); the first row block also stores
-  // a/b/rstd for the backward pass and updates the moving statistics
-  const float* f_mean; const float* f_var; const float* f_gamma; const float* f_beta; const float* f_sgamma;
-  const float* f_sbeta;
-  float f_eps, f_momentum;
-  float* f_a; float* f_b; float* f_rstd; float* f_mov_mean; float* f_mov_var;
 };
 
 template <typename T, int COLS>
@@ -753,26 +683,8 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
   const T* __restrict__ sp = (const T*)p.skip;
   T* __restrict__ op = (T*)p.out;
   float a[CH], b[CH];
-  if (p.f_mean) {
-    const bool writer = blockIdx.x == 0 && rl == 0;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int c = c0 + j;
-      const float mu = p.f_mean[c], v = p.f_var[c];
-      float r;
-      bn_fold_coef(c, mu, v, p.f_gamma, p.f_beta, p.f_eps, p.f_sgamma, p.f_sbeta, &a[j], &b[j], &r);
-      if (writer) {
-        p.f_a[c] = a[j];
-        p.f_b[c] = b[j];
-        if (p.f_rstd) p.f_rstd[c] = r;
-        if (p.f_mov_mean) p.f_mov_mean[c] -= (p.f_mov_mean[c] - mu) * (1.f - p.f_momentum);
-        if (p.f_mov_var) p.f_mov_var[c] -= (p.f_mov_var[c] - v) * (1.f - p.f_momentum);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
-  }
+  for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
   const int We = p.W << p.uw, He = p.H << p.uh, De = p.D << p.ud;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
@@ -871,32 +783,9 @@ extern "C" int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, 
   return hdu_check_launch("affine_act");
 }
 
-static int materialize_impl(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
-                            const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
-                            void* out, int64_t ldout, void* stream, const MatK* fold);
-
 extern "C" int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
                                const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
                                void* out, int64_t ldout, void* stream) {
-  return materialize_impl(dtype, x, ldx, N, D, H, W, C, a, b, relu, ud, uh, uw, skip, ldskip, out, ldout, stream, nullptr);
-}
-
-extern "C" int hdu_materialize_bn(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C,
-                                  const float* mean, const float* var, const float* gamma, const float* beta, float eps,
-                                  const float* sgamma, const float* sbeta, float* a, float* b, float* rstd,
-                                  float* mov_mean, float* mov_var, float momentum, int relu, int ud, int uh, int uw,
-                                  const void* skip, int64_t ldskip, void* out, int64_t ldout, void* stream) {
-  if (!mean || !var || !a || !b) return hdu_set_error(HDU_ERR_ARG, "materialize_bn: null pointer");
-  MatK f{};
-  f.f_mean = mean; f.f_var = var; f.f_gamma = gamma; f.f_beta = beta; f.f_sgamma = sgamma; f.f_sbeta = sbeta;
-  f.f_eps = eps; f.f_momentum = momentum; f.f_a = a; f.f_b = b; f.f_rstd = rstd; f.f_mov_mean = mov_mean;
-  f.f_mov_var = mov_var;
-  return materialize_impl(dtype, x, ldx, N, D, H, W, C, a, b, relu, ud, uh, uw, skip, ldskip, out, ldout, stream, &f);
-}
-
-static int materialize_impl(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* a,
-                            const float* b, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip,
-                            void* out, int64_t ldout, void* stream, const MatK* fold) {
   if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "materialize: bad dtype");
   const int ch = dtype == HDU_BF16 ? 8 : 4;
   if (!x || !out || ((a == nullptr) != (b == nullptr)) || ((ud | uh | uw) & ~1))
@@ -904,7 +793,6 @@ static int materialize_impl(int dtype, const void* x, int64_t ldx, int N, int D,
   if (C <= 0 || C % ch || ldx % ch || ldout % ch || (skip && ldskip % ch) || N <= 0 || D <= 0 || H <= 0 || W <= 0)
     return hdu_set_error(HDU_ERR_ARG, "materialize: C / strides must be multiples of the 16-byte chunk");
   MatK k{};
-  if (fold) k = *fold;
   k.x = x; k.skip = skip; k.out = out; k.a = a; k.b = b; k.ldx = ldx; k.ldskip = ldskip; k.ldo = ldout;
   k.N = N; k.D = D; k.H = H; k.W = W; k.C = C; k.ud = ud; k.uh = uh; k.uw = uw; k.relu = relu;
   k.Mo = (long long)N * (D << ud) * (H << uh) * (W << uw);

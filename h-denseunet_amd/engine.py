@@ -151,8 +151,14 @@ class Ctx:
         # BN(+Scale)+ReLU backward fused into the epilogue of the data-gradient launch that produces dz (include/hdu.h,
         # hdu_conv_desc.bnb_*): no dz round trip, no reduction pass, and the full-width apply pass of a dense-block layer
         # (C0 + l*growth channels) shrinks to a correction over the producer's own channels
-        self.fuse_bn_bwd = os.environ.get("HDU_FUSE_BN_BWD", "1") == "1"
-        self.fuse_bn_bwd_max_m = int(os.environ.get("HDU_FUSE_BN_BWD_MAXM", "0"))      # 0 = no pixel-count limit
+        # Measured on MI355X (profiles/r02_experiment_fused_bn_backward.txt): for INFERENCE-mode BNs (the hybrids' 2D
+        # branch and 3D dense blocks: no mean terms, so nothing is deferred) the step gains 3.8 % (end2end 28.6 -> 27.5 ms);
+        # for batch-statistics BNs the 3.2 ms of reduction + apply passes it removes from the 2D step come back as +2.4 ms
+        # of data-gradient epilogues (the u / gradient-slab loads are exposed: 2-3 workgroups per CU cannot hide them
+        # the way the 2048-workgroup streaming kernels do) and +1.0 ms of correction launches: neutral (23.1 vs 23.2 ms).
+        # Default 1 = inference-mode BNs only; 2 = every BN (tests cover both); 0 = off.
+        self.fuse_bn_bwd_mode = int(os.environ.get("HDU_FUSE_BN_BWD", "1"))
+        self.fuse_bn_bwd = self.fuse_bn_bwd_mode > 0
         self.fuse_bn_bwd_now = False
         self.bnb_sinks = []          # (layer, offset into bnb_acc)
         self.bnb_acc = None
@@ -168,9 +174,6 @@ class Ctx:
         self.grad_enabled = True
         self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
-        # BN fold inside the materialise launch (hdu_materialize_bn): saves 82 tiny launches per step but makes every
-        # workgroup of 161 big launches derive its coefficients from six vectors -- measured 296 vs 310 slices/s: off
-        self.fuse_fold = os.environ.get("HDU_FUSE_FOLD", "0") == "1"
         # filter gradients deferred to the end of the backward pass and run as ONE launch per kernel family
         # (ops.WgradPlan); bf16 + materialised inputs only; off under depth sharding / bucketed data parallelism
         self.batch_wgrad = os.environ.get("HDU_BATCH_WGRAD", "1") == "1"
@@ -180,10 +183,6 @@ class Ctx:
         self.epilogue_stats = os.environ.get("HDU_EPILOGUE_STATS", "1") == "1"
         self.stats_sinks = []
         self.stats_acc = None
-        # 0 = off, 1 = every layer, 2 = only layers with <= 16384 output pixels (latency-bound on their own)
-        self.overlap_wgrad = int(os.environ.get("HDU_OVERLAP_WGRAD", "0"))
-        self._side = None
-        self.wgrad_open = False
         self.finalized = False
 
     # ---------------- parameters
@@ -263,8 +262,7 @@ class Ctx:
         self.wgrad_plan = None
         for cv in self.convs:
             cv.in_plan = False
-        if not (self.batch_wgrad and self.dtype == HDU_BF16 and self.grad_enabled and self.shard is None
-                and not self.overlap_wgrad):
+        if not (self.batch_wgrad and self.dtype == HDU_BF16 and self.grad_enabled and self.shard is None):
             return
         plan = ops.WgradPlan(int(os.environ.get("HDU_BATCH_WGRAD_TARGET", "0")))
         for cv in self.convs:
@@ -418,7 +416,6 @@ class Ctx:
         if lo == 0:
             for v in self.vars:
                 v.written = False
-            self.wgrad_open = False
             self.fuse_bn_bwd_now = self.fuse_bn_bwd and (self.shard is None or self.shard.world == 1)
             if self.fuse_bn_bwd_now:
                 if self.bnb_acc is not None:
@@ -430,7 +427,6 @@ class Ctx:
             f()
         if hi == len(self.bwd) and self.wgrad_plan is not None:
             self.wgrad_plan.run()
-        self.join_wgrad()
 
     def grad_buckets(self, fractions):
         """Cut the backward pass where the first-completed `fractions` of the trainable parameters have their final
@@ -461,23 +457,6 @@ class Ctx:
             prev_pos, prev_off = pos, off
         out.append((prev_pos, n, 0, prev_off))
         return out
-
-    # Filter gradients only feed the optimiser: they run on a side stream, concurrently with the data-gradient /
-    # BN-backward chain (forked after each dy is complete, joined once before the SGD update).  The many small
-    # late-stage layers are latency-bound on their own, so the two chains overlap almost for free.
-    def wgrad_stream(self, M=0):
-        if self.dev.type != "cuda" or not self.overlap_wgrad:
-            return None
-        if self.overlap_wgrad == 2 and M > 16384:
-            return None
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        return self._side
-
-    def join_wgrad(self):
-        if self.wgrad_open:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self.wgrad_open = False
 
 
 # ======================================================================================= layers
@@ -513,9 +492,8 @@ class BNLayer:
     def needs_stats(self):
         return self.mode == "batch"
 
-    def fold(self, xvar, defer=False):
-        """a/b/rstd of this pass.  defer=True (the caller materialises x right away): returns the argument tuple of
-        ops.materialize_bn instead of launching bn_fold, or None when nothing is left to do."""
+    def fold(self, xvar):
+        """a/b/rstd of this pass (nothing to do when the statistics reduction or the batched launch already did it)"""
         ctx = self.ctx
         sg = self.sg.data if self.sg else None
         sb = self.sb.data if self.sb else None
@@ -534,8 +512,6 @@ class BNLayer:
             self.mean_used = self.mm.data
             args = (self.mm.data, self.mv.data, self.gamma.data, self.beta.data, self.eps, sg, sb, self.a, self.b,
                     self.rstd, None, None, self.momentum)
-        if defer:
-            return args
         ops.bn_fold(self.C, *args)
         return None
 
@@ -646,7 +622,7 @@ class ConvLayer:
         # output: no up-sampling in between, no skip add, no depth halo, no dropout on the BN input
         self.bnb_fused = bool(ctx.fuse_bn_bwd and need_input_grad and bn is not None and up == (0, 0, 0) and skip is None
                               and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None
-                              and (ctx.fuse_bn_bwd_max_m <= 0 or xa.M <= ctx.fuse_bn_bwd_max_m))
+                              and (ctx.fuse_bn_bwd_mode >= 2 or bn.mode != "batch"))
         self.bnb_off = None
         self.need_dgrad_filter = need_input_grad and not self.strided
         self.wf_off = self.wd_off = None
@@ -710,19 +686,14 @@ class ConvLayer:
 
     def forward(self):
         ctx = self.ctx
-        deferred = None
         if self.bn is not None:
-            deferred = self.bn.fold(self.x, defer=self.xin is not None and ctx.fuse_fold)
+            self.bn.fold(self.x)
         if self.xin is not None:
             bn = self.bn
             up = self.up if self.skip is not None else (0, 0, 0)
             skip = self.skip.act if self.skip is not None else None
             dst = self.xin_interior if self.halo else self.xin.act
-            if deferred is not None:      # BN fold inside the materialise launch
-                ops.materialize_bn(self.x.act, *deferred, bn.relu, up, skip, dst)
-            else:
-                ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False, up,
-                                skip, dst)
+            ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False, up, skip, dst)
             if self.halo:
                 _sh.halo_exchange(ctx.shard, self.xin.act, self.halo)
         # epilogue statistics once the sink has a usable shift (the previous pass's mean); the first training pass
@@ -751,14 +722,7 @@ class ConvLayer:
                                   self.skip.act if self.skip is not None else None,
                                   (self.bn.a, self.bn.b) if self.bn is not None else None,
                                   self.bn.relu if self.bn is not None else False)
-            side = ctx.wgrad_stream(out.act.M)
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream())    # dy is complete on the main stream
-                with torch.cuda.stream(side):
-                    ops.conv_wgrad(d, self.kernel.grad)
-                ctx.wgrad_open = True
-            else:
-                ops.conv_wgrad(d, self.kernel.grad)
+            ops.conv_wgrad(d, self.kernel.grad)
             if self.bias is not None:
                 ops.colsum(dy, self.bias.grad, ctx.ws)
         if not self.need_input_grad:

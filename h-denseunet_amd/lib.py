@@ -105,8 +105,6 @@ _SIGS = {
     "hdu_wgrad_plan_run": (c_int, [c_int, c_p, c_p, c_int, ctypes.c_uint32, c_p]),
     "hdu_bn_stats_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                       c_f, c_p]),
-    "hdu_materialize_bn": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
-                                   c_p, c_p, c_p, c_p, c_p, c_f, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_int, c_p]),
     "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_int, c_p]),
@@ -168,8 +166,6 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(11, int(os.environ["HDU_RED_WGS"]))
     if "HDU_ROW_WGS" in os.environ:
         lib.hdu_set_tuning(12, int(os.environ["HDU_ROW_WGS"]))
-    if "HDU_FUSED_FINALIZE" in os.environ:
-        lib.hdu_set_tuning(10, int(os.environ["HDU_FUSED_FINALIZE"]))
     if "HDU_NO_HALO_FPROP" in os.environ:
         lib.hdu_set_tuning(9, int(os.environ["HDU_NO_HALO_FPROP"]))
     if "HDU_NO_HALO" in os.environ:

@@ -332,15 +332,6 @@ def bn_stats_finalize(partial, slots, M, C, shift, mean, var, fold=None):
                                          stream()), "hdu_bn_stats_finalize")
 
 
-def materialize_bn(x, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum, relu, up,
-                   skip, out):
-    check(_l.get().hdu_materialize_bn(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, fptr(mean), fptr(var), fptr(gamma),
-                                      fptr(beta), eps, fptr(sgamma), fptr(sbeta), fptr(a), fptr(b), fptr(rstd),
-                                      fptr(mov_mean), fptr(mov_var), momentum, 1 if relu else 0, up[0], up[1], up[2],
-                                      skip.ptr if skip is not None else None, skip.ld if skip is not None else 0,
-                                      out.ptr, out.ld, stream()), "hdu_materialize_bn")
-
-
 def colsum(x, out, ws):
     check(_l.get().hdu_colsum(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(out), ws.ptr, ws.nbytes, stream()), "hdu_colsum")
 

@@ -41,16 +41,15 @@ const char* hdu_last_error(void);
 /* "hip-gfx950" for the product library; "emu-x86" for the CPU test build of the same sources. */
 const char* hdu_backend(void);
 int hdu_abi_version(void);
-/* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES = LDS ring depth of the DMA implicit GEMM (2 or 3) */
+/* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES: 2 = two LDS stages, deep ring for small grids (default); 6 = deep ring everywhere */
 #define HDU_TUNE_DMA_STAGES 0
 #define HDU_TUNE_HALO_TARGET_WGS 7    /* workgroups a halo-tile filter-gradient launch aims for */
 #define HDU_TUNE_MAX_BN 6            /* widest N tile the dispatcher may pick (default 128) */
 #define HDU_TUNE_NO_FAST 5           /* 1 = disable the bitmask/32-bit-offset addressing path (A/B) */
 #define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!) */
-#define HDU_TUNE_XCD_SWIZZLE 3       /* bit0 = XCD-aware tile order in the implicit GEMM (default on); bit1 = XCD-grouped filter-gradient grid (off: measured slower) */
+#define HDU_TUNE_XCD_SWIZZLE 3       /* bit0 = XCD-aware tile order in the implicit GEMM (default on) */
 #define HDU_TUNE_RED_WGS 11          /* workgroups a per-channel reduction aims for (default 512) */
 #define HDU_TUNE_ROW_WGS 12          /* workgroups an element-wise row kernel aims for (default 2048) */
-#define HDU_TUNE_FUSED_FINALIZE 10   /* 1 = small-tensor reductions finish in the last workgroup of the same launch (off: measured slower) */
 #define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
 #define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
@@ -289,15 +288,6 @@ int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int D, int H, 
 int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M, int C, const float* shift, float* mean, float* var,
                           const float* gamma, const float* beta, float eps, const float* sgamma, const float* sbeta,
                           float* a, float* b, float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream);
-
-/* hdu_materialize with the BN(+Scale) fold of hdu_bn_fold done inside the same launch: a/b are derived per thread from
- * (mean, var, gamma, beta, Scale); a, b, rstd and the moving statistics are ALSO written (first row block) exactly as
- * hdu_bn_fold would -- K.layers/normalization.py:126-190 + lib/custom_layers.py:63-69 */
-int hdu_materialize_bn(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const float* mean,
-                       const float* var, const float* gamma, const float* beta, float eps, const float* sgamma,
-                       const float* sbeta, float* a, float* b, float* rstd, float* mov_mean, float* mov_var,
-                       float momentum, int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip, void* out,
-                       int64_t ldout, void* stream);
 
 /* per-channel column sum: out[c] = sum_m x[m][c]   (bias gradients) */
 int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws, size_t ws_bytes,

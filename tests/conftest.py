@@ -60,7 +60,7 @@ def hdu(request):
     return request.getfixturevalue("hip_lib")
 
 
-@pytest.fixture(params=[2, 3, 6], ids=["dma2", "ring3", "ring6"])
+@pytest.fixture(params=[2, 6], ids=["dma2", "ring6"])
 def dma_stages(request):
     """run a test under both LDS ring depths of the DMA implicit GEMM"""
     lib = hdu_pkg().lib

@@ -711,47 +711,6 @@ def test_materialize(hdu, dtype, up, use_skip, use_pro):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("C,up,moving", [(24, (0, 0, 0), True), (264, (0, 1, 1), True), (48, (0, 0, 0), False)])
-def test_materialize_bn_equals_fold_then_materialize(hdu, dtype, C, up, moving):
-    """the in-launch BN fold produces bit-identical a/b/rstd, moving statistics and output as bn_fold + materialize"""
-    ops = ops_mod()
-    N, D, H, W = 2, 1, 9, 6
-    x = rnd((N, D, H, W, C), 1, 1.0, dtype)
-    xa = mkact(ops, x, dtype)
-    f = lambda seed, sc, off=0.0: dev(ops, (rnd((C,), seed, sc) + off).float().double())
-    mean, var, gamma, beta, sg, sb = f(2, 0.5), f(3, 0.2, 1.0).abs(), f(4, 0.3, 1.0), f(5, 0.2), f(6, 0.2, 1.0), f(7, 0.1)
-    outs = []
-    for fused in (False, True):
-        a, b, r = (torch.zeros(C, device=ops.device()) for _ in range(3))
-        mm, mv = f(8, 0.5).clone(), f(9, 0.1, 1.0).abs().clone()
-        out = ops.Act.alloc(N, D << up[0], H << up[1], W << up[2], C, dtype)
-        args = (mean, var, gamma, beta, 1.1e-5, sg, sb, a, b, r, mm if moving else None, mv if moving else None, 0.99)
-        if fused:
-            ops.materialize_bn(xa, *args, True, up, None, out)
-        else:
-            ops.bn_fold(C, *args)
-            ops.materialize(xa, a, b, True, up, None, out)
-        outs.append([t.clone().cpu() for t in (a, b, r, mm, mv)] + [out.to_torch().cpu()])
-    for u, v in zip(*outs):
-        assert torch.equal(u, v)
-    assert float(outs[0][5].abs().max()) > 0
-    if moving:
-        assert not torch.equal(outs[0][3], f(8, 0.5).cpu())
-
-
-def test_sgd_nesterov(hdu):
-    ops = ops_mod()
-    n = 10007
-    p, v, g = rnd((n,), 1).float(), rnd((n,), 2, 0.1).float(), rnd((n,), 3).float()
-    pd, vd, gd = [t.clone().to(ops.device()) for t in (p, v, g)]
-    ops.sgd_nesterov(pd, vd, gd, 1e-3, 0.9, 0.5)
-    gs = g * 0.5
-    vn = 0.9 * v - 1e-3 * gs
-    pn = p + 0.9 * vn - 1e-3 * gs
-    assert torch.allclose(vd.cpu(), vn, rtol=1e-6, atol=1e-8) and torch.allclose(pd.cpu(), pn, rtol=1e-6, atol=1e-8)
-
-
-@pytest.mark.parametrize("dtype", DT)
 def test_plumbing(hdu, dtype):
     ops = ops_mod()
     D, H, W = 5, 4, 6
