@@ -2033,10 +2033,10 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep
 // ------------------------------------------------------------------ host-side dispatch
 #include "hdu_host.h"
 
-int g_tuning[16] = {2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tuning[24] = {2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" int hdu_set_tuning(int key, int value) {
-  if (key < 0 || key >= 16) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
+  if (key < 0 || key >= 24) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
   g_tuning[key] = value;
   return 0;
 }
@@ -2125,9 +2125,11 @@ static bool igemm_fast_ok(const ConvK& k) {
 static int choose_splitk(long long nblk, int nk, int bm, int bn, size_t* bytes) {
   *bytes = 0;
   const int mode = g_tuning[HDU_TUNE_SPLITK];
-  if (mode == 1 || nblk > 128) return 1;
-  int S = mode >= 2 ? mode : (int)((256 + nblk - 1) / nblk);
-  if (S > nk / 3) S = nk / 3;
+  const int target = g_tuning[HDU_TUNE_SPLITK_TARGET] > 0 ? g_tuning[HDU_TUNE_SPLITK_TARGET] : 256;
+  const int min_steps = g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] : 3;
+  if (mode == 1 || nblk > target / 2) return 1;
+  int S = mode >= 2 ? mode : (int)((target + nblk - 1) / nblk);
+  if (S > nk / min_steps) S = nk / min_steps;
   if (S > 16) S = 16;
   if (S < 2) return 1;
   *bytes = (size_t)nblk * (size_t)S * (size_t)bm * (size_t)bn * sizeof(float);
@@ -2153,7 +2155,7 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
       constexpr int BK = 8 * Chunk<T>::CH;
       size_t need;
       const int S = choose_splitk(nblk, (k.Ktot + BK - 1) / BK, BM, BN, &need);
-      if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) grid.z = (unsigned)S;
+      if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) grid.z = (unsigned)S;   // (512 ticket counters)
       if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, k);
     } else {

@@ -158,6 +158,10 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
     if "HDU_SPLITK" in os.environ:
         lib.hdu_set_tuning(13, int(os.environ["HDU_SPLITK"]))
+    if "HDU_SPLITK_TARGET" in os.environ:
+        lib.hdu_set_tuning(16, int(os.environ["HDU_SPLITK_TARGET"]))
+    if "HDU_SPLITK_MIN_STEPS" in os.environ:
+        lib.hdu_set_tuning(17, int(os.environ["HDU_SPLITK_MIN_STEPS"]))
     if "HDU_HALO_MIN_TILES" in os.environ:
         lib.hdu_set_tuning(15, int(os.environ["HDU_HALO_MIN_TILES"]))
     if "HDU_RING_MIN_K" in os.environ:

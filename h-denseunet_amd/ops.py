@@ -88,9 +88,9 @@ class Act:
 
 # split-K scratch of hdu_conv_fprop (include/hdu.h): one float32 buffer + ticket counters per process, shared by every
 # launch (launches of one stream are ordered; the filter gradients on the side stream never use it).  Sized for the
-# library's worst case: 128 tiles x 16 splits x 64x128 outputs.
+# library's worst case (tile count x 16 splits x 64x128 float32 outputs).
 _SPLITK = None
-SPLITK_BYTES = 128 * 16 * 64 * 128 * 4
+SPLITK_BYTES = 320 * 16 * 64 * 128 * 4
 
 
 def splitk_scratch():
