@@ -474,6 +474,36 @@ extern "C" int hdu_bn_bwd_coef(int C, int64_t M, int batch_stats, const float* s
   return hdu_check_launch("bn_bwd_coef");
 }
 
+// sync-BN of a depth-sharded volume (shard.py): local (mean, biased var) over n_local pixels -> (n*mean, n*(var+mean^2))
+// for the all-reduce, and back to the statistics of the whole volume
+__global__ __launch_bounds__(256) void stats_pack_kernel(int C, const float* mean, const float* var, float n_local, float* buf) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = mean[c];
+  buf[c] = m * n_local;
+  buf[C + c] = (var[c] + m * m) * n_local;
+}
+__global__ __launch_bounds__(256) void stats_unpack_kernel(int C, const float* buf, float inv_n_global, float* mean, float* var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = buf[c] * inv_n_global;
+  const float v = buf[C + c] * inv_n_global - m * m;
+  mean[c] = m;
+  var[c] = v > 0.f ? v : 0.f;
+}
+extern "C" int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, float* buf, void* stream) {
+  if (C <= 0 || !mean || !var || !buf || n_local <= 0) return hdu_set_error(HDU_ERR_ARG, "stats_pack: bad args");
+  HDU_LAUNCH(stats_pack_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, mean, var,
+             (float)n_local, buf);
+  return hdu_check_launch("stats_pack");
+}
+extern "C" int hdu_stats_unpack(int C, const float* buf, int64_t n_global, float* mean, float* var, void* stream) {
+  if (C <= 0 || !mean || !var || !buf || n_global <= 0) return hdu_set_error(HDU_ERR_ARG, "stats_unpack: bad args");
+  HDU_LAUNCH(stats_unpack_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, buf,
+             1.0f / (float)n_global, mean, var);
+  return hdu_check_launch("stats_unpack");
+}
+
 // ====================================================================== element-wise row kernels
 struct RowK {
   const void* x;

@@ -105,6 +105,8 @@ _SIGS = {
     "hdu_wgrad_plan_run": (c_int, [c_int, c_p, c_p, c_int, ctypes.c_uint32, c_p]),
     "hdu_bn_stats_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                       c_f, c_p]),
+    "hdu_stats_pack": (c_int, [c_int, c_p, c_p, c_i64, c_p, c_p]),
+    "hdu_stats_unpack": (c_int, [c_int, c_p, c_i64, c_p, c_p, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_int, c_p]),
     "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_int, c_p]),

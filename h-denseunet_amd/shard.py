@@ -11,8 +11,8 @@ contiguous memory range).  Every depth-coupled layer keeps `h` halo planes on bo
   BN      : sync statistics -- all-reduce of per-channel (n*mean, n*(var+mean^2)) forward and (S1, S2) backward, so a
                               sharded step equals the single-device step.
 
-Exchanges are point-to-point with the two depth neighbours (RCCL send/recv over xGMI; gloo in the CPU tests);
-nothing here touches the per-voxel data path kernels.
+Exchanges are point-to-point with the two depth neighbours (RCCL send/recv over xGMI; gloo in the CPU tests); torch is
+the transport only: the halo-gradient add and the sync-BN packing run in libhdu kernels.
 """
 import torch
 import torch.distributed as dist
@@ -72,10 +72,16 @@ def halo_reduce(sh, act, h, tmp):
         ops_.append(dist.P2POp(dist.irecv, r_hi, sh.hi, sh.group))
     for r in dist.batch_isend_irecv(ops_):
         r.wait()
+    # the returned halo gradients are ADDED to my boundary planes by the library's accumulate kernel
+    from . import ops
+    H, W, C, ld = act.H, act.W, act.C, act.ld
+
+    def view(buf, off, ldv):
+        return ops.Act(buf, off, 1, h, H, W, C, ldv, act.dtype)
     if sh.lo is not None:
-        _planes(act, h, h).add_(r_lo)
+        ops.upsample_bwd(view(tmp, 0, C), view(act.buf, act.off + h * plane, ld), (0, 0, 0), accumulate=True)
     if sh.hi is not None:
-        _planes(act, D - 2 * h, h).add_(r_hi)
+        ops.upsample_bwd(view(tmp, h * plane, C), view(act.buf, act.off + (D - 2 * h) * plane, ld), (0, 0, 0), accumulate=True)
 
 
 def allreduce_sum(sh, t):
@@ -89,15 +95,13 @@ def sync_stats(sh, mean, var, n_local, n_global, buf):
     buf: float32 [2*C] scratch."""
     if sh is None or sh.world == 1:
         return
+    import ctypes
+    from . import lib as _l, ops
     C = mean.numel()
-    b1, b2 = buf[:C], buf[C:2 * C]
-    torch.mul(mean, float(n_local), out=b1)
-    torch.addcmul(var, mean, mean, out=b2)
-    b2.mul_(float(n_local))
+    lib = _l.get()
+    _l.check(lib.hdu_stats_pack(C, ops.fptr(mean), ops.fptr(var), n_local, ops.fptr(buf), ops.stream()), "hdu_stats_pack")
     dist.all_reduce(buf[:2 * C], op=dist.ReduceOp.SUM, group=sh.group)
-    torch.div(b1, float(n_global), out=mean)
-    torch.div(b2, float(n_global), out=var)
-    var.addcmul_(mean, mean, value=-1.0).clamp_(min=0.0)
+    _l.check(lib.hdu_stats_unpack(C, ops.fptr(buf), n_global, ops.fptr(mean), ops.fptr(var), ops.stream()), "hdu_stats_unpack")
 
 
 def exchange_ct_planes(sh, vol_h, D, plane):

@@ -291,6 +291,11 @@ int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M, int C, con
                           const float* gamma, const float* beta, float eps, const float* sgamma, const float* sbeta,
                           float* a, float* b, float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream);
 
+/* sync-BN over the depth shards of one volume: buf[0:C] = n_local*mean, buf[C:2C] = n_local*(var + mean^2) (the caller
+ * all-reduces buf over the ranks), then mean = buf[0:C]/n_global, var = buf[C:2C]/n_global - mean^2 (clamped at 0) */
+int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, float* buf, void* stream);
+int hdu_stats_unpack(int C, const float* buf, int64_t n_global, float* mean, float* var, void* stream);
+
 /* per-channel column sum: out[c] = sum_m x[m][c]   (bias gradients) */
 int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws, size_t ws_bytes,
                void* stream);
