@@ -738,15 +738,46 @@ __device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n
 // consecutive lanes store consecutive chunks of a row (full 128-byte lines) and a thread's S1 / S2 partial sums stay in
 // registers; lanes that share a chunk meet in a wave butterfly, the four waves in LDS, and one lane per channel adds
 // the workgroup's sums to a slot row with float atomics.
+template <typename T, int BM, int BN> struct BnbGeom {
+  static constexpr int CH = Chunk<T>::CH;
+  static constexpr int NCC = BN / CH;
+  static constexpr int NCCP = NCC <= 4 ? 4 : (NCC <= 8 ? 8 : (NCC <= 16 ? 16 : 32));
+  static constexpr int RSTEP = 256 / NCCP;
+  static constexpr int IT = (BM + RSTEP - 1) / RSTEP;
+  static constexpr bool EARLY = IT <= 8;             // the u / old-gradient chunks of a thread fit in registers
+  static_assert(NCC <= 32, "tile shape");
+};
+
+// issues the thread's u (and, in accumulate mode, old-gradient) loads: called BEFORE the accumulators are staged through
+// LDS, so that their latency hides behind the two barriers and the staging pass instead of standing in the epilogue
+template <typename T, int BM, int BN, int NIT>
+__device__ __forceinline__ void bnb_issue_loads(const ConvK& p, long long m0, int n0, int tid, int it0, u32x4 (&uv)[NIT],
+                                                u32x4 (&ov)[NIT]) {
+  typedef BnbGeom<T, BM, BN> G;
+  const int cc = tid % G::NCCP, r0 = tid / G::NCCP;
+  const int n = n0 + cc * G::CH;
+  const bool col_ok = cc < G::NCC && n < p.Cout;
+  const T* __restrict__ up = (const T*)p.bnb_u;
+  const T* __restrict__ yp = (const T*)p.y;
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < NIT; ++q) {
+    const int row = r0 + (it0 + q) * G::RSTEP;
+    const long long m = m0 + row;
+    const bool ok = col_ok && row < BM && m < p.M;
+    uv[q] = ok ? *(const u32x4*)(up + m * p.bnb_ldu + n) : z4;
+    ov[q] = (ok && p.accumulate) ? *(const u32x4*)(yp + m * p.ldy + n) : z4;
+  }
+}
+
 template <typename T, int BM, int BN, int ROWB>
-__device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem, long long m0, int n0, int tid) {
-  constexpr int CH = Chunk<T>::CH;
-  constexpr int NCC = BN / CH;
-  constexpr int NCCP = NCC <= 4 ? 4 : (NCC <= 8 ? 8 : (NCC <= 16 ? 16 : 32));
-  constexpr int RSTEP = 256 / NCCP;
-  constexpr int IT = (BM + RSTEP - 1) / RSTEP;
-  constexpr int UNR = IT < 4 ? IT : 4;
-  static_assert(NCC <= 32 && IT % UNR == 0, "tile shape");
+__device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem, long long m0, int n0, int tid,
+                                                     u32x4 (&pre_uv)[BnbGeom<T, BM, BN>::EARLY ? BnbGeom<T, BM, BN>::IT : 1],
+                                                     u32x4 (&pre_ov)[BnbGeom<T, BM, BN>::EARLY ? BnbGeom<T, BM, BN>::IT : 1]) {
+  typedef BnbGeom<T, BM, BN> G;
+  constexpr int CH = G::CH, NCC = G::NCC, NCCP = G::NCCP, RSTEP = G::RSTEP, IT = G::IT;
+  constexpr int UNR = G::EARLY ? IT : 4;
+  static_assert(IT % UNR == 0, "tile shape");
   const int cc = tid % NCCP, r0 = tid / NCCP;
   const int n = n0 + cc * CH;
   const bool col_ok = cc < NCC && n < p.Cout;
@@ -760,28 +791,22 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
     rs[j] = col_ok && sums ? p.bnb_rstd[n + j] : 0.f;
     s1[j] = 0.f; s2[j] = 0.f;
   }
-  const T* __restrict__ up = (const T*)p.bnb_u;
   T* __restrict__ yp = (T*)p.y;
-  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
   for (int it0 = 0; it0 < IT; it0 += UNR) {
-    u32x4 uv[UNR], ov[UNR];
-    bool ok[UNR];
-#pragma unroll
-    for (int q = 0; q < UNR; ++q) {
-      const int row = r0 + (it0 + q) * RSTEP;
-      const long long m = m0 + row;
-      ok[q] = col_ok && row < BM && m < p.M;
-      uv[q] = ok[q] ? *(const u32x4*)(up + m * p.bnb_ldu + n) : z4;
-      ov[q] = (ok[q] && p.accumulate) ? *(const u32x4*)(yp + m * p.ldy + n) : z4;
+    u32x4 luv[UNR], lov[UNR];
+    if constexpr (!G::EARLY) {
+      bnb_issue_loads<T, BM, BN, UNR>(p, m0, n0, tid, it0, luv, lov);
+      HDU_SCHED_BARRIER();
     }
-    HDU_SCHED_BARRIER();
 #pragma unroll
     for (int q = 0; q < UNR; ++q) {
-      if (!ok[q]) continue;
       const int row = r0 + (it0 + q) * RSTEP;
+      if (!(col_ok && row < BM && m0 + row < p.M)) continue;
       float dz[CH], u[CH], o[CH];
       Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), dz);
-      Chunk<T>::unpack(uv[q], u);
+      u32x4 uq, oq;
+      if constexpr (G::EARLY) { uq = pre_uv[q]; oq = pre_ov[q]; } else { uq = luv[q]; oq = lov[q]; }
+      Chunk<T>::unpack(uq, u);
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const float sj = a[j] * u[j] + b[j];
@@ -792,7 +817,7 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
       }
       if (p.accumulate) {
         float old[CH];
-        Chunk<T>::unpack(ov[q], old);
+        Chunk<T>::unpack(oq, old);
 #pragma unroll
         for (int j = 0; j < CH; ++j) o[j] += old[j];
       }
@@ -838,6 +863,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
   constexpr int ROWB = BN * (int)sizeof(T) + (BM * (BN * (int)sizeof(T) + 16) <= SMEM ? 16 : 0);
   static_assert(BM * ROWB <= SMEM, "epilogue staging tile must fit the LDS of the operand stages");
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+  typedef BnbGeom<T, BM, BN> G;
+  u32x4 bnb_uv[G::EARLY ? G::IT : 1], bnb_ov[G::EARLY ? G::IT : 1];
+  if constexpr (G::EARLY) {
+    if (p.bnb_u != nullptr) bnb_issue_loads<T, BM, BN, G::IT>(p, m0, n0, tid, 0, bnb_uv, bnb_ov);
+  }
   __syncthreads();                                   // all MFMA operand reads of the last K tile are done
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -861,7 +891,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
   }
   __syncthreads();
   if (p.bnb_u != nullptr) {                          // data gradient with the consumer BN's backward fused in
-    epilogue_bn_backward<T, BM, BN, ROWB>(p, smem, m0, n0, tid);
+    epilogue_bn_backward<T, BM, BN, ROWB>(p, smem, m0, n0, tid, bnb_uv, bnb_ov);
     return;
   }
   T* __restrict__ yp = (T*)p.y;
@@ -2120,13 +2150,13 @@ static bool igemm_fast_ok(const ConvK& k) {
 
 // Split-K factor of a small-grid launch (ring kernel).  A grid of <= 128 workgroups leaves half the chip idle and each
 // busy compute unit is bound by what it alone can pull from L2 (measured: 14-20 KB per K step at ~1 us per step whatever
-// the MFMA work), so the K steps are dealt to S workgroups per tile until ~256 workgroups run, keeping >= 3 K steps per
+// the MFMA work), so the K steps are dealt to S workgroups per tile until ~256 workgroups run, keeping >= 4 K steps per
 // split and S <= 16 (the last arriver reads S-1 partial tiles).  `bytes`: scratch the launch needs.
 static int choose_splitk(long long nblk, int nk, int bm, int bn, size_t* bytes) {
   *bytes = 0;
   const int mode = g_tuning[HDU_TUNE_SPLITK];
   const int target = g_tuning[HDU_TUNE_SPLITK_TARGET] > 0 ? g_tuning[HDU_TUNE_SPLITK_TARGET] : 256;
-  const int min_steps = g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] : 3;
+  const int min_steps = g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] : 4;   // swept: profiles/r02_experiment_splitk_sweep.txt
   if (mode == 1 || nblk > target / 2) return 1;
   int S = mode >= 2 ? mode : (int)((target + nblk - 1) / nblk);
   if (S > nk / min_steps) S = nk / min_steps;

@@ -55,7 +55,7 @@ int hdu_abi_version(void);
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
 #define HDU_TUNE_SPLITK 13           /* 0 = library default (split small grids), 1 = never split, N >= 2 = force N splits where possible (tests) */
 #define HDU_TUNE_SPLITK_TARGET 16     /* workgroups a split-K launch aims for (default 256) */
-#define HDU_TUNE_SPLITK_MIN_STEPS 17  /* K steps every split keeps at least (default 3) */
+#define HDU_TUNE_SPLITK_MIN_STEPS 17  /* K steps every split keeps at least (default 4) */
 #define HDU_TUNE_HALO_MIN_TILES 15   /* the halo-tile forward kernel needs this many 4x32-pixel tiles (default 128) */
 #define HDU_TUNE_RING_MIN_K 14       /* small grids use the deep LDS ring when Ktot > this (default 0: always) */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
