@@ -2000,6 +2000,74 @@ __global__ __launch_bounds__(256) void conv_dgrad_strided_kernel(ConvK p) {
 // =====================================================================================
 // filter preparation: float32 master [Cout][T][Cin] -> compute dtype forward copy (same layout) and the
 // data-gradient filter [Cin][T flipped][Cout].
+// ---- stride-2 data gradient as 2^d stride-1 implicit GEMMs (the 7x7x7 stride-2 stem of the end-to-end hybrid).
+// dx[i] = sum_k dy[(i + p - k) / 2] * w[k] over the taps k with (i + p - k) even: input positions of parity r = i & 1 only
+// see the taps k = kmax_r, kmax_r - 2, ... -- a stride-1 correlation of dy with a sub-filter of ceil/floor(K/2) taps per
+// axis.  hdu_stride2_dgrad_filters gathers the 2^d sub-filters ([Cin][taps][Cout], the layout hdu_conv_fprop takes as a
+// data-gradient filter), hdu_conv_fprop runs each class on the MFMA path, hdu_parity_interleave scatters the class
+// outputs into dx.  Replaces the scalar gather kernel above on the hot path (9.7 ms -> ~1 ms per end2end step).
+struct ParityGeom {
+  int nt[3];        // taps per axis of this class
+  int kmax[3];      // largest forward-filter tap of the class's parity: tap t of the sub-filter is k = kmax - step*t
+  int step[3];      // 2 on a stride-2 axis, 1 on a stride-1 axis
+  long long dst_off;
+};
+struct ParityTable { ParityGeom c[8]; int n; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void stride2_filter_kernel(const float* __restrict__ wm, int Cout, int KD, int KH, int KW,
+                                                            int Cin, ParityTable tab, T* __restrict__ out) {
+  const ParityGeom g = tab.c[blockIdx.y];
+  const long long total = (long long)Cin * g.nt[0] * g.nt[1] * g.nt[2] * Cout;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(q % Cout);
+    long long t = q / Cout;
+    const int tw = (int)(t % g.nt[2]); t /= g.nt[2];
+    const int th = (int)(t % g.nt[1]); t /= g.nt[1];
+    const int td = (int)(t % g.nt[0]);
+    const int ci = (int)(t / g.nt[0]);
+    const int kd = g.kmax[0] - g.step[0] * td, kh = g.kmax[1] - g.step[1] * th, kw = g.kmax[2] - g.step[2] * tw;
+    const float v = wm[((((long long)co * KD + kd) * KH + kh) * KW + kw) * Cin + ci];
+    Chunk<T>::store1(out + g.dst_off + q, v);
+  }
+}
+
+// dx[n][2qd+rd][2qh+rh][2qw+rw][c] (+)= cls[class(rd,rh,rw)][n][qd][qh][qw][c]; a stride-1 axis has one class (r = 0, q = i)
+template <typename T>
+__global__ __launch_bounds__(256) void parity_interleave_kernel(const T* __restrict__ cls, int N, int Di, int Hi, int Wi, int C,
+                                                               int sd, int sh, int sw, T* __restrict__ dx, long long lddx,
+                                                               int accumulate) {
+  constexpr int CH = Chunk<T>::CH;
+  const int ncc = C / CH;
+  const long long total = (long long)N * Di * Hi * Wi * ncc;
+  const int Dq = (Di + sd - 1) / sd, Hq = (Hi + sh - 1) / sh, Wq = (Wi + sw - 1) / sw;   // class grids (even dims: equal for all r)
+  const long long cls_elems = (long long)N * Dq * Hq * Wq * C;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(q % ncc);
+    long long pix = q / ncc;
+    const int iw = (int)(pix % Wi);
+    long long t = pix / Wi;
+    const int ih = (int)(t % Hi);
+    t /= Hi;
+    const int id = (int)(t % Di);
+    const int n = (int)(t / Di);
+    const int rd = id % sd, rh = ih % sh, rw = iw % sw;
+    const int ci = (rd * sh + rh) * sw + rw;
+    const long long src = ci * cls_elems + ((((long long)n * Dq + id / sd) * Hq + ih / sh) * Wq + iw / sw) * C + cc * CH;
+    u32x4 v = *(const u32x4*)(cls + src);
+    T* o = dx + pix * lddx + cc * CH;
+    if (accumulate) {
+      float a[CH], b[CH];
+      Chunk<T>::unpack(v, a);
+      Chunk<T>::unpack(*(const u32x4*)o, b);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] += b[j];
+      v = Chunk<T>::pack(a);
+    }
+    *(u32x4*)o = v;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ wm, int Cout, int Tn, int Cin,
                                                          T* __restrict__ wf, T* __restrict__ wd) {
@@ -2097,7 +2165,10 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   const int eDo = (k->De + 2 * d->pd - d->KD) / d->sd + 1;
   const int eHo = (k->He + 2 * d->ph - d->KH) / d->sh + 1;
   const int eWo = (k->We + 2 * d->pw - d->KW) / d->sw + 1;
-  if (eDo != d->Do || eHo != d->Ho || eWo != d->Wo)
+  // The kernels test every tap against the input bounds, so an output grid LARGER than the symmetric-padding formula is
+  // well defined: the extra positions see implicit zero padding on the high side (the parity classes of a stride-2 data
+  // gradient need pad_low = 1, pad_high = 2).  Up to K-1 extra positions per axis are accepted; anything else is an error.
+  if (d->Do < eDo || d->Do > eDo + d->KD - 1 || d->Ho < eHo || d->Ho > eHo + d->KH - 1 || d->Wo < eWo || d->Wo > eWo + d->KW - 1)
     return hdu_set_error(HDU_ERR_ARG, "conv: output dims inconsistent with input dims / kernel / stride / pad");
   k->M = (long long)d->N * d->Do * d->Ho * d->Wo;
   if ((long long)d->N * k->De * k->He * k->We >= (1ll << 31) || k->M >= (1ll << 31))
@@ -2495,6 +2566,65 @@ extern "C" int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream) {
   else
     HDU_LAUNCH((conv_dgrad_strided_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, k);
   return hdu_check_launch("conv_dgrad_strided");
+}
+
+static int parity_table(int KD, int KH, int KW, int sd, int sh, int sw, int pd, int ph, int pw, int Cin, int Cout,
+                        ParityTable* tab) {
+  const int K[3] = {KD, KH, KW}, S[3] = {sd, sh, sw}, P[3] = {pd, ph, pw};
+  for (int a = 0; a < 3; ++a)
+    if (S[a] != 1 && S[a] != 2) return -1;
+  tab->n = sd * sh * sw;
+  long long off = 0;
+  for (int c = 0; c < tab->n; ++c) {
+    const int r[3] = {c / (sh * sw), (c / sw) % sh, c % sw};
+    ParityGeom& g = tab->c[c];
+    for (int a = 0; a < 3; ++a) {
+      g.step[a] = S[a];
+      int kmax = K[a] - 1;
+      if (S[a] == 2 && ((kmax - r[a] - P[a]) & 1)) --kmax;         // k = (r + p) mod 2
+      g.kmax[a] = kmax;
+      g.nt[a] = kmax < 0 ? 0 : kmax / S[a] + 1;
+      if (g.nt[a] <= 0) return -1;
+    }
+    g.dst_off = off;
+    off += (long long)Cin * g.nt[0] * g.nt[1] * g.nt[2] * Cout;
+  }
+  return 0;
+}
+
+extern "C" int hdu_stride2_dgrad_filters(int dtype, const float* w_master, int Cout, int KD, int KH, int KW, int Cin, int sd,
+                                         int sh, int sw, int pd, int ph, int pw, void* w_out, void* stream) {
+  ParityTable tab;
+  if (!w_master || !w_out || Cout <= 0 || Cin <= 0 || parity_table(KD, KH, KW, sd, sh, sw, pd, ph, pw, Cin, Cout, &tab))
+    return hdu_set_error(HDU_ERR_ARG, "stride2_dgrad_filters: bad args (strides must be 1 or 2)");
+  const dim3 grid(64, (unsigned)tab.n);
+  if (dtype == HDU_BF16)
+    HDU_LAUNCH((stride2_filter_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, KD, KH, KW, Cin, tab, (bf16_t*)w_out);
+  else if (dtype == HDU_F32)
+    HDU_LAUNCH((stride2_filter_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, w_master, Cout, KD, KH, KW, Cin, tab, (float*)w_out);
+  else
+    return hdu_set_error(HDU_ERR_ARG, "stride2_dgrad_filters: bad dtype");
+  return hdu_check_launch("stride2_dgrad_filters");
+}
+
+extern "C" int hdu_parity_interleave(int dtype, const void* cls, int N, int Di, int Hi, int Wi, int C, int sd, int sh, int sw,
+                                     void* dx, int64_t lddx, int accumulate, void* stream) {
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if (!cls || !dx || N <= 0 || C <= 0 || C % ch || lddx % ch || Di % sd || Hi % sh || Wi % sw || (sd != 1 && sd != 2) ||
+      (sh != 1 && sh != 2) || (sw != 1 && sw != 2))
+    return hdu_set_error(HDU_ERR_ARG, "parity_interleave: bad args (dims must be multiples of the strides)");
+  const long long total = (long long)N * Di * Hi * Wi * (C / ch);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (dtype == HDU_BF16)
+    HDU_LAUNCH((parity_interleave_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cls,
+               N, Di, Hi, Wi, C, sd, sh, sw, (bf16_t*)dx, (long long)lddx, accumulate);
+  else if (dtype == HDU_F32)
+    HDU_LAUNCH((parity_interleave_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)cls, N,
+               Di, Hi, Wi, C, sd, sh, sw, (float*)dx, (long long)lddx, accumulate);
+  else
+    return hdu_set_error(HDU_ERR_ARG, "parity_interleave: bad dtype");
+  return hdu_check_launch("parity_interleave");
 }
 
 extern "C" int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, void* w_f, void* w_d,

@@ -624,6 +624,10 @@ class ConvLayer:
                               and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None
                               and (ctx.fuse_bn_bwd_mode >= 2 or bn.mode != "batch"))
         self.bnb_off = None
+        self._s2 = None
+        self._s2_ok = (os.environ.get("HDU_STRIDE2_DGRAD", "1") == "1" and all(v in (1, 2) for v in stride)
+                       and xa.D % stride[0] == 0 and xa.H % stride[1] == 0 and xa.W % stride[2] == 0 and up == (0, 0, 0)
+                       and bn is None and skip is None and not halo)
         self.need_dgrad_filter = need_input_grad and not self.strided
         self.wf_off = self.wd_off = None
         ctx.convs.append(self)
@@ -655,6 +659,12 @@ class ConvLayer:
         if self.xin is not None:            # materialised operand: plain conv
             x, pro, relu, skip, up = self.xin.act, None, False, None, self.conv_up
         bias = self.bias.data if self.bias is not None else None
+        if self.strided and self.need_input_grad and self._s2_ok and self.out.root.needs_grad:
+            # stride-2 data gradient on the MFMA path: 2^d stride-1 implicit GEMMs over the parity classes of the input
+            # grid (the scalar gather form took 9.7 of the 27 ms of an end2end step for 0.4 % of its FLOPs)
+            xa = self.x.act
+            self._s2 = ops.Stride2Dgrad(ctx.dtype, self.kernel.data, self.out.grad, (xa.N, xa.D, xa.H, xa.W), xa.C, self.K,
+                                        self.stride, self.pad)
         self.d_f = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu, bias)
         self.d_f_drop = None
         if self.dropout > 0:
@@ -744,9 +754,12 @@ class ConvLayer:
         else:
             tgt, acc = self._dxe(), False
         if self.strided:
-            d = ops.conv_desc(ops.Act(tgt.buf, tgt.off, x.N, x.D, x.H, x.W, x.C, tgt.ld, tgt.dtype), self.wf_ptr, dy,
-                              K, self.stride, pad, accumulate=acc)
-            ops.conv_dgrad_strided(d)
+            tgt_act = ops.Act(tgt.buf, tgt.off, x.N, x.D, x.H, x.W, x.C, tgt.ld, tgt.dtype)
+            if self._s2 is not None:
+                self._s2.run(tgt_act, accumulate=acc)
+            else:
+                d = ops.conv_desc(tgt_act, self.wf_ptr, dy, K, self.stride, pad, accumulate=acc)
+                ops.conv_dgrad_strided(d)
         else:
             d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K,
                               (1, 1, 1), (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)

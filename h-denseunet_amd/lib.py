@@ -78,6 +78,10 @@ _SIGS = {
     "hdu_conv_splitk_ws_bytes": (c_sz, [ctypes.POINTER(ConvDesc)]),
     "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
+    "hdu_stride2_dgrad_filters": (c_int, [c_int, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_p, c_p]),
+    "hdu_parity_interleave": (c_int, [c_int, c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int,
+                                      c_p]),
     "hdu_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
     "hdu_weight_prep": (c_int, [c_int, c_p, c_int, c_int, c_int, c_p, c_p, c_p]),
     "hdu_weight_prep_batched": (c_int, [c_int, c_p, c_int, c_i64, c_p, c_p, c_p]),

@@ -193,6 +193,57 @@ def conv_dgrad_strided(d):
     check(_l.get().hdu_conv_dgrad_strided(ctypes.byref(d), stream()), "hdu_conv_dgrad_strided")
 
 
+class Stride2Dgrad:
+    """Data gradient of a stride-2 (per axis: 1 or 2) convolution as 2^d stride-1 implicit GEMMs (include/hdu.h,
+    hdu_stride2_dgrad_filters / hdu_parity_interleave): built once per layer, run() per backward pass."""
+
+    def __init__(self, dtype, w_master, dy, dx_dims, Cin_p, K, stride, pad):
+        """w_master: float32 master filter [Cout_p][KD][KH][KW][Cin_p] (flat tensor view); dy: Act of the output gradient;
+        dx_dims = (N, Di, Hi, Wi) of the input"""
+        N, Di, Hi, Wi = dx_dims
+        for a in range(3):
+            if stride[a] not in (1, 2) or (Di, Hi, Wi)[a] % stride[a]:
+                raise ValueError("stride-2 data gradient: strides 1 or 2 and input dims divisible by them")
+        self.dtype, self.w_master, self.dy, self.dims, self.C = dtype, w_master, dy, dx_dims, Cin_p
+        self.K, self.stride, self.pad = K, stride, pad
+        self.Cout = dy.C
+        q = (Di // stride[0], Hi // stride[1], Wi // stride[2])
+        classes, off = [], 0
+        for rd in range(stride[0]):
+            for rh in range(stride[1]):
+                for rw in range(stride[2]):
+                    nt, pl = [], []
+                    for a, r in enumerate((rd, rh, rw)):
+                        kmax = K[a] - 1
+                        if stride[a] == 2 and ((kmax - r - pad[a]) & 1):
+                            kmax -= 1
+                        nt.append(kmax // stride[a] + 1)
+                        pl.append(-(r + pad[a] - kmax) // stride[a])
+                    classes.append((tuple(nt), tuple(pl), off))
+                    off += Cin_p * nt[0] * nt[1] * nt[2] * self.Cout
+        tdt = _TORCH_DT[dtype]
+        self.wsub = torch.zeros(off, dtype=tdt, device=device())
+        cls_elems = N * q[0] * q[1] * q[2] * Cin_p
+        self.cls = torch.zeros(len(classes) * cls_elems, dtype=tdt, device=device())
+        esz = self.wsub.element_size()
+        self.descs = []
+        for i, (nt, pl, woff) in enumerate(classes):
+            y = Act(self.cls, i * cls_elems, N, q[0], q[1], q[2], Cin_p, Cin_p, dtype)
+            self.descs.append(conv_desc(dy, ctypes.c_void_p(self.wsub.data_ptr() + woff * esz), y, nt, (1, 1, 1), pl))
+
+    def run(self, dx, accumulate=False):
+        lib = _l.get()
+        K, st, pd = self.K, self.stride, self.pad
+        check(lib.hdu_stride2_dgrad_filters(self.dtype, fptr(self.w_master), self.Cout, K[0], K[1], K[2], self.C, st[0], st[1],
+                                            st[2], pd[0], pd[1], pd[2], ctypes.c_void_p(self.wsub.data_ptr()), stream()),
+              "hdu_stride2_dgrad_filters")
+        for d in self.descs:
+            conv_fprop(d)
+        N, Di, Hi, Wi = self.dims
+        check(lib.hdu_parity_interleave(self.dtype, ctypes.c_void_p(self.cls.data_ptr()), N, Di, Hi, Wi, self.C, st[0], st[1],
+                                        st[2], dx.ptr, dx.ld, 1 if accumulate else 0, stream()), "hdu_parity_interleave")
+
+
 def conv_kernel_name(d, op=0):
     buf = ctypes.create_string_buffer(96)
     check(_l.get().hdu_conv_kernel_name(ctypes.byref(d), op, buf, 96), "hdu_conv_kernel_name")

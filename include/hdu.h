@@ -171,6 +171,20 @@ int hdu_wgrad_plan_run(int variant, const void* dev_entries, const uint32_t* dev
  * dx[n,i,c] (+)= sum_{o,k: o*s+k-p=i} dy[n,o,co]*w[co][k][c].  d->x is the output dx, d->y is dy. */
 int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream);
 
+/* A stride-2 data gradient on the MFMA path: input positions of parity r = i mod 2 (per stride-2 axis) only see the taps
+ * k = (r + pad) mod 2 of the forward filter, so the gradient is 2^d stride-1 correlations of dy with sub-filters of
+ * ceil / floor(K/2) taps per axis.  hdu_stride2_dgrad_filters gathers the sub-filters of all classes from the float32
+ * master filter [Cout][KD][KH][KW][Cin] into w_out, class (rd, rh, rw) after class in row-major order, each
+ * [Cin][ntd][nth][ntw][Cout] in the compute dtype: tap t of a stride-2 axis is k = kmax_r - 2t, kmax_r the largest tap of
+ * the class's parity; a stride-1 axis has one class with the taps reversed.  The caller then runs hdu_conv_fprop per
+ * class (x = dy, w = the sub-filter, KD/KH/KW = the class's taps, stride 1, pad = (r + pad - kmax_r)/-2 per stride-2
+ * axis, output = the class grid of size Di/sd x Hi/sh x Wi/sw) into a buffer [class][N][Dq][Hq][Wq][Cin], and
+ * hdu_parity_interleave scatters (or adds) the class grids into dx.  (hdu_conv_dgrad_strided stays as the general form.) */
+int hdu_stride2_dgrad_filters(int dtype, const float* w_master, int Cout, int KD, int KH, int KW, int Cin, int sd, int sh,
+                              int sw, int pd, int ph, int pw, void* w_out, void* stream);
+int hdu_parity_interleave(int dtype, const void* cls, int N, int Di, int Hi, int Wi, int C, int sd, int sh, int sw, void* dx,
+                          int64_t lddx, int accumulate, void* stream);
+
 /* name of the kernel template instance the dispatcher launches for this descriptor (op 0 = fprop/dgrad-form,
  * 1 = wgrad); lets a profiler-side tool group launches exactly like rocprofv3's per-kernel statistics. */
 int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, size_t buflen);

@@ -756,3 +756,28 @@ def test_abi_errors(hdu):
     bad = ops.Act(x.buf, 0, 1, 1, 4, 4, 6, 6, BF16)
     with pytest.raises(hdu.lib.HduError):
         ops.affine_act(bad, None, None, True, bad)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [dict(N=1, D=8, H=10, W=12, Cin=8, Cout=16, K=(7, 7, 7), s=(2, 2, 2), p=(3, 3, 3), id="stem7x7x7s2"),
+                                   dict(N=2, D=1, H=12, W=8, Cin=8, Cout=24, K=(1, 7, 7), s=(1, 2, 2), p=(0, 3, 3), id="stem7x7s2_2d"),
+                                   dict(N=1, D=4, H=6, W=6, Cin=16, Cout=8, K=(3, 3, 3), s=(2, 2, 2), p=(1, 1, 1), id="k3s2")],
+                         ids=lambda c: c["id"])
+def test_stride2_dgrad_parity_classes(hdu, dtype, shape):
+    """hdu_stride2_dgrad_filters + hdu_conv_fprop per parity class + hdu_parity_interleave == the data gradient of the
+    strided convolution (autograd, float64), plain and accumulating -- and == the scalar hdu_conv_dgrad_strided form"""
+    ops = ops_mod()
+    N, D, H, W, Cin, Cout, K, s, p = (shape[k] for k in ("N", "D", "H", "W", "Cin", "Cout", "K", "s", "p"))
+    w = rnd((Cout,) + K + (Cin,), 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cout), dtype)
+    Do, Ho, Wo = [(n + 2 * pp - k) // ss + 1 for n, pp, k, ss in zip((D, H, W), p, K, s)]
+    dy = rnd((N, Do, Ho, Wo, Cout), 9, 1.0, dtype)
+    dya = mkact(ops, dy, dtype)
+    wm = dev(ops, q(w, dtype)).reshape(-1)
+    xe = torch.zeros((N, D, H, W, Cin), dtype=torch.float64, requires_grad=True)
+    (ref_conv(xe, q(w, dtype), s, p, None) * dy).sum().backward()
+    dx = ops.Act.alloc(N, D, H, W, Cin, dtype, zero=True)
+    s2 = ops.Stride2Dgrad(dtype, wm, dya, (N, D, H, W), Cin, K, s, p)
+    s2.run(dx)
+    assert_close(dx.to_torch().cpu(), xe.grad, dtype, what="stride-2 dgrad")
+    s2.run(dx, accumulate=True)
+    assert_close(dx.to_torch().cpu(), 2 * xe.grad, dtype, scale=2 * float(xe.grad.abs().max()), what="stride-2 dgrad accumulate")
