@@ -2283,7 +2283,7 @@ static void choose_igemm(const ConvK& k, int* bm, int* bn) {
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
   }
   *bn = best;
-  *bm = (k.M <= 16384) ? 64 : 128;
+  *bm = (k.M <= (g_tuning[HDU_TUNE_BM64_MAX_M] > 0 ? (long long)g_tuning[HDU_TUNE_BM64_MAX_M] : 16384)) ? 64 : 128;
 }
 
 template <int BM, int BN> struct WaveLayout {           // (waves along M, waves along N)

@@ -54,6 +54,7 @@ int hdu_abi_version(void);
 #define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
 #define HDU_TUNE_SPLITK 13           /* 0 = library default (split small grids), 1 = never split, N >= 2 = force N splits where possible (tests) */
+#define HDU_TUNE_BM64_MAX_M 18        /* layers with at most this many output pixels use 64-row tiles (default 16384) */
 #define HDU_TUNE_SPLITK_TARGET 16     /* workgroups a split-K launch aims for (default 256) */
 #define HDU_TUNE_SPLITK_MIN_STEPS 17  /* K steps every split keeps at least (default 4) */
 #define HDU_TUNE_HALO_MIN_TILES 15   /* the halo-tile forward kernel needs this many 4x32-pixel tiles (default 128) */
