@@ -134,7 +134,8 @@ def instrumented_step(m):
             e0.record()
             fn(d, *a)
             e1.record()
-            recs.append((ops.conv_kernel_name(d, op), flops(d, op), e0, e1, d.N * d.Do * d.Ho * d.Wo))
+            recs.append((ops.conv_kernel_name(d, op), flops(d, op), e0, e1, d.N * d.Do * d.Ho * d.Wo,
+                         (d.Cout, d.KD * d.KH * d.KW * d.Cin, d.KD * d.KH * d.KW)))
         return f
 
     ops.conv_fprop, ops.conv_wgrad = wrap(orig_f, 0), wrap(orig_w, 1)
@@ -160,12 +161,13 @@ def instrumented_step(m):
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w
     agg = {}
     bym = {}
-    for name, fl, e0, e1, mm in recs:
+    detail = os.environ.get("HDU_BENCH_VERBOSE") == "2"      # one row per GEMM shape (N, K, taps) instead of per M
+    for name, fl, e0, e1, mm, shape in recs:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += fl
-        b = bym.setdefault((mm, name), [0, 0.0, 0.0])
+        b = bym.setdefault((mm, name + (" N=%d K=%d taps=%d" % shape if detail else "")), [0, 0.0, 0.0])
         b[0] += 1
         b[1] += e0.elapsed_time(e1)
         b[2] += fl

@@ -18,6 +18,10 @@ struct ConvK {
   int KD, KH, KW, sd, sh, sw, pd, ph, pw;
   int Do, Ho, Wo, Cout;
   int Ktot;                   // KD*KH*KW*Cin
+  // output pixel index -> (n, od, oh, ow) without hardware division: q = umulhi(m, mul) >> shr for m < 2^31 (mul == 0:
+  // divisor 1).  Filled on the host (fill_convk); the per-row state of a tile costs a few VALU ops instead of three
+  // ~30-instruction division sequences per row (measured: 2-3 us of a 10-15 us short-K launch).
+  unsigned div_wo_mul, div_wo_shr, div_ho_mul, div_ho_shr, div_do_mul, div_do_shr;
   int pro_relu, accumulate;
   float drop_scale;           // 1/keep (0 => dropout disabled)
   unsigned drop_thresh;       // keep iff hash < thresh
@@ -40,6 +44,54 @@ struct ConvK {
   float* sk_ws;               // [tile][split][wave][fragment][lane] f32x4, write-through stores
   unsigned* sk_cnt;           // [tile] arrival tickets, zero between launches
 };
+
+__device__ __forceinline__ unsigned hdu_fastdiv(unsigned n, unsigned mul, unsigned shr) {
+  return mul == 0u ? n : (unsigned)(((unsigned long long)n * mul) >> 32) >> shr;
+}
+
+// taps q in [0, K) of one axis whose input coordinate i0 + q lies inside [0, E): a contiguous bit range (K <= 32)
+__device__ __forceinline__ unsigned hdu_tap_range_mask(int i0, int K, int E) {
+  const int lo = i0 < 0 ? -i0 : 0;
+  const int hi = E - i0 < K ? E - i0 : K;
+  return hi > lo ? (hi >= 32 ? 0xffffffffu : (1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+}
+
+// per-row state of an implicit-GEMM tile row (output pixel m): the row's top-left-front input coordinate and, in the
+// FAST form, its tap-validity bit mask + element offset of tap (0,0,0) channel 0.
+template <bool FAST>
+__device__ __forceinline__ void hdu_row_state(const ConvK& p, unsigned m, bool pointwise, int& rn, int& rid, int& rih, int& riw,
+                                              int& rpix, unsigned& rmask) {
+  rmask = 0u;
+  if (FAST && pointwise) {                             // 1x1x1 stride 1 no padding: input pixel == output pixel
+    rn = 0; rid = 0; rih = 0; riw = 0;
+    rpix = (long long)m < p.M ? (int)m * (int)p.ldx : 0;
+    rmask = (long long)m < p.M ? 1u : 0u;
+  } else if ((long long)m < p.M) {
+    unsigned t = hdu_fastdiv(m, p.div_wo_mul, p.div_wo_shr);
+    const unsigned ow = m - t * (unsigned)p.Wo;
+    unsigned t2 = hdu_fastdiv(t, p.div_ho_mul, p.div_ho_shr);
+    const unsigned oh = t - t2 * (unsigned)p.Ho;
+    const unsigned n = hdu_fastdiv(t2, p.div_do_mul, p.div_do_shr);
+    const unsigned od = t2 - n * (unsigned)p.Do;
+    rn = (int)n;
+    rid = (int)od * p.sd - p.pd;
+    rih = (int)oh * p.sh - p.ph;
+    riw = (int)ow * p.sw - p.pw;
+    rpix = ((rn * p.De + rid) * p.He + rih) * p.We + riw;
+    if (FAST) {
+      const unsigned mw = hdu_tap_range_mask(riw, p.KW, p.We);
+      const unsigned mh = hdu_tap_range_mask(rih, p.KH, p.He);
+      const unsigned md = hdu_tap_range_mask(rid, p.KD, p.De);
+      unsigned mhw = 0u, mall = 0u;
+      for (int q = 0; q < p.KH; ++q) mhw |= ((mh >> q) & 1u ? mw : 0u) << (q * p.KW);
+      for (int q = 0; q < p.KD; ++q) mall |= ((md >> q) & 1u ? mhw : 0u) << (q * p.KH * p.KW);
+      rmask = mall;
+      rpix *= (int)p.ldx;                               // element offset of tap (0,0,0), channel 0
+    }
+  } else {
+    rn = 0; rid = -(1 << 28); rih = -(1 << 28); riw = -(1 << 28); rpix = 0;
+  }
+}
 
 // byte offset of 16-byte chunk `chunk` (0..7) of row `row` inside a [rows][128 B] LDS tile.
 // XOR swizzle: the 16 lanes of a ds_read_b128 group (rows r..r+15, fixed logical chunk) hit 16

@@ -924,6 +924,36 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
 // padding / tails read a 16-byte page of zeros.  The LDS image is lane-linear per wave instruction, so the XOR
 // swizzle is applied by permuting which logical k-chunk each lane fetches.
 __device__ __attribute__((aligned(16))) unsigned hdu_zero_page[16];
+// Developer instrumentation (tools/timeline_probe.py builds its own library with -DHDU_TIMELINE; never in libhdu.so):
+// lane 0 of every workgroup stamps the shader clock at a few points of the implicit-GEMM kernels, plus the constant
+// 100 MHz clock at entry / exit so that workgroups of different XCDs share one time axis.
+#ifdef HDU_TIMELINE
+#define HDU_TL_WGS 8192
+__device__ unsigned long long hdu_timeline[HDU_TL_WGS * 10];
+#define HDU_TP(i)                                                                                               \
+  do {                                                                                                           \
+    if (threadIdx.x == 0) {                                                                                      \
+      const unsigned b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
+      if (b_ < HDU_TL_WGS) {                                                                                     \
+        hdu_timeline[b_ * 10 + (i)] = __builtin_readcyclecounter();                                              \
+        if ((i) == 0) hdu_timeline[b_ * 10 + 8] = wall_clock64();                                                \
+        if ((i) >= 5) hdu_timeline[b_ * 10 + 9] = wall_clock64();                                                \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+extern "C" int hdu_timeline_read(unsigned long long* host, int clear) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(hdu_timeline), sizeof(unsigned long long) * HDU_TL_WGS * 10) != hipSuccess) return 1;
+  if (clear) {
+    void* dp = nullptr;
+    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(hdu_timeline)) != hipSuccess) return 1;
+    if (hipMemset(dp, 0, sizeof(unsigned long long) * HDU_TL_WGS * 10) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define HDU_TP(i) do { } while (0)
+#endif
+
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
@@ -952,6 +982,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   const int kcl = (tid & 7) ^ (r0 & 7);   // logical chunk this lane fetches (it lands at physical chunk tid&7)
   const long long m0 = (long long)((p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
+  HDU_TP(0);
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ wp = (const T*)p.w;
   const char* zero = (const char*)hdu_zero_page;
@@ -964,36 +995,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
   unsigned rmask[A_IT];
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const unsigned m = (unsigned)(m0 + r0 + i * 32);     // M < 2^31 (checked on the host)
-    rmask[i] = 0u;
-    if (FAST && pointwise) {                             // 1x1x1 stride 1 no padding: input pixel == output pixel
-      rn[i] = 0; rid[i] = 0; rih[i] = 0; riw[i] = 0;
-      rpix[i] = (long long)m < p.M ? (int)m * (int)p.ldx : 0;
-      rmask[i] = (long long)m < p.M ? 1u : 0u;
-    } else if ((long long)m < p.M) {
-      const unsigned ow = m % (unsigned)p.Wo;
-      unsigned t = m / (unsigned)p.Wo;
-      const unsigned oh = t % (unsigned)p.Ho;
-      t /= (unsigned)p.Ho;
-      const unsigned od = t % (unsigned)p.Do;
-      rn[i] = (int)(t / (unsigned)p.Do);
-      rid[i] = (int)od * p.sd - p.pd;
-      rih[i] = (int)oh * p.sh - p.ph;
-      riw[i] = (int)ow * p.sw - p.pw;
-      rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
-      if (FAST) {
-        unsigned mw = 0u, mhw = 0u, mall = 0u;
-        for (int q = 0; q < p.KW; ++q) mw |= ((unsigned)(riw[i] + q) < (unsigned)p.We ? 1u : 0u) << q;
-        for (int q = 0; q < p.KH; ++q) if ((unsigned)(rih[i] + q) < (unsigned)p.He) mhw |= mw << (q * p.KW);
-        for (int q = 0; q < p.KD; ++q) if ((unsigned)(rid[i] + q) < (unsigned)p.De) mall |= mhw << (q * p.KH * p.KW);
-        rmask[i] = mall;
-        rpix[i] *= (int)p.ldx;                             // element offset of tap (0,0,0), channel 0
-      }
-    } else {
-      rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
-    }
-  }
+  for (int i = 0; i < A_IT; ++i)     // M < 2^31 (checked on the host)
+    hdu_row_state<FAST>(p, (unsigned)(m0 + r0 + i * 32), pointwise, rn[i], rid[i], rih[i], riw[i], rpix[i], rmask[i]);
   int k = kcl * CH;
   int c, kd, kh, kw, tap_i;
   {
@@ -1070,8 +1073,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.Ktot + BK - 1) / BK;
+  HDU_TP(1);
   issue_tile(0);
+  HDU_TP(2);
   __syncthreads();
+  HDU_TP(3);
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) {
@@ -1098,7 +1104,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     __syncthreads();
   }
 
+  HDU_TP(4);
+  HDU_TP(5);
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  HDU_TP(6);
 }
 
 // NS-stage ring variant: tiles t+1 .. t+NS-1 stay in flight while tile t is multiplied.  Per iteration: counted
@@ -1223,6 +1232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   const int kcl = (tid & 7) ^ (r0 & 7);
   const long long m0 = (long long)((p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x) * BM;
   const int n0 = blockIdx.y * BN;
+  HDU_TP(0);
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ wp = (const T*)p.w;
   const char* zero = (const char*)hdu_zero_page;
@@ -1235,36 +1245,8 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   int rn[A_IT], rid[A_IT], rih[A_IT], riw[A_IT], rpix[A_IT];
   unsigned rmask[A_IT];
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const unsigned m = (unsigned)(m0 + r0 + i * 32);     // M < 2^31 (checked on the host)
-    rmask[i] = 0u;
-    if (FAST && pointwise) {                             // 1x1x1 stride 1 no padding: input pixel == output pixel
-      rn[i] = 0; rid[i] = 0; rih[i] = 0; riw[i] = 0;
-      rpix[i] = (long long)m < p.M ? (int)m * (int)p.ldx : 0;
-      rmask[i] = (long long)m < p.M ? 1u : 0u;
-    } else if ((long long)m < p.M) {
-      const unsigned ow = m % (unsigned)p.Wo;
-      unsigned t = m / (unsigned)p.Wo;
-      const unsigned oh = t % (unsigned)p.Ho;
-      t /= (unsigned)p.Ho;
-      const unsigned od = t % (unsigned)p.Do;
-      rn[i] = (int)(t / (unsigned)p.Do);
-      rid[i] = (int)od * p.sd - p.pd;
-      rih[i] = (int)oh * p.sh - p.ph;
-      riw[i] = (int)ow * p.sw - p.pw;
-      rpix[i] = ((rn[i] * p.De + rid[i]) * p.He + rih[i]) * p.We + riw[i];
-      if (FAST) {
-        unsigned mw = 0u, mhw = 0u, mall = 0u;
-        for (int q = 0; q < p.KW; ++q) mw |= ((unsigned)(riw[i] + q) < (unsigned)p.We ? 1u : 0u) << q;
-        for (int q = 0; q < p.KH; ++q) if ((unsigned)(rih[i] + q) < (unsigned)p.He) mhw |= mw << (q * p.KW);
-        for (int q = 0; q < p.KD; ++q) if ((unsigned)(rid[i] + q) < (unsigned)p.De) mall |= mhw << (q * p.KH * p.KW);
-        rmask[i] = mall;
-        rpix[i] *= (int)p.ldx;                             // element offset of tap (0,0,0), channel 0
-      }
-    } else {
-      rn[i] = 0; rid[i] = -(1 << 28); rih[i] = -(1 << 28); riw[i] = -(1 << 28); rpix[i] = 0;
-    }
-  }
+  for (int i = 0; i < A_IT; ++i)     // M < 2^31 (checked on the host)
+    hdu_row_state<FAST>(p, (unsigned)(m0 + r0 + i * 32), pointwise, rn[i], rid[i], rih[i], riw[i], rpix[i], rmask[i]);
   // split-K: gridDim.z workgroups share this output tile, each takes a contiguous range of K steps
   const int nk_all = (p.Ktot + BK - 1) / BK;
   const int nsplit = (int)gridDim.z, split = (int)blockIdx.z;
@@ -1341,9 +1323,11 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = kt_end - kt_begin;
+  HDU_TP(1);
 #pragma unroll
   for (int pre = 0; pre < NS - 1; ++pre)
     if (pre < nk) issue_tile(pre);
+  HDU_TP(2);
   int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tiles issued beyond kt: min(NS-2, nk-1-kt) may stay in flight
@@ -1354,6 +1338,9 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     else if (NS > 5 && ahead == 3) hdu_wait_vmcnt_n<3 * L>();
     else hdu_wait_vmcnt_n<0>();
     HDU_RAW_BARRIER();
+#ifdef HDU_TIMELINE
+    if (kt == 0) HDU_TP(3);
+#endif
     if (kt + NS - 1 < nk) issue_tile(slot == 0 ? NS - 1 : slot - 1);   // slot (kt+NS-1) % NS
     {
       const char* As = smem + slot * STAGE;
@@ -1375,11 +1362,17 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
+  HDU_TP(4);
   if (nsplit > 1) {
     HDU_WAIT_VMCNT(0);
-    if (!splitk_combine<TM, TN>(p, acc, smem, blockIdx.y * gridDim.x + blockIdx.x, split, nsplit, wave, lane, tid)) return;
+    if (!splitk_combine<TM, TN>(p, acc, smem, blockIdx.y * gridDim.x + blockIdx.x, split, nsplit, wave, lane, tid)) {
+      HDU_TP(5);
+      return;
+    }
   }
+  HDU_TP(5);
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NS * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  HDU_TP(6);
 }
 
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
@@ -2139,6 +2132,16 @@ extern "C" int hdu_set_tuning(int key, int value) {
   return 0;
 }
 
+// magic numbers of hdu_fastdiv (conv_common.h): exact for dividends below 2^31
+static void fastdiv_magic(int d, unsigned* mul, unsigned* shr) {
+  if (d <= 1) { *mul = 0u; *shr = 0u; return; }
+  int cl = 0;
+  while ((1ll << cl) < (long long)d) ++cl;
+  const int p = 31 + cl;
+  *mul = (unsigned)((((unsigned long long)1 << p) + (unsigned long long)d - 1) / (unsigned long long)d);
+  *shr = (unsigned)(p - 32);
+}
+
 static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   if (!d) return hdu_set_error(HDU_ERR_ARG, "conv: null descriptor");
   if (d->dtype != HDU_BF16 && d->dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "conv: bad dtype");
@@ -2174,6 +2177,9 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   if ((long long)d->N * k->De * k->He * k->We >= (1ll << 31) || k->M >= (1ll << 31))
     return hdu_set_error(HDU_ERR_ARG, "conv: more than 2^31 pixels per tensor (shard the volume)");
   k->Ktot = d->KD * d->KH * d->KW * d->Cin;
+  fastdiv_magic(d->Wo, &k->div_wo_mul, &k->div_wo_shr);
+  fastdiv_magic(d->Ho, &k->div_ho_mul, &k->div_ho_shr);
+  fastdiv_magic(d->Do, &k->div_do_mul, &k->div_do_shr);
   k->pro_relu = d->pro_relu; k->accumulate = d->accumulate;
   if (d->drop_keep > 0.f && d->drop_keep < 1.f) {
     k->drop_scale = 1.f / d->drop_keep;

@@ -748,9 +748,10 @@ def test_abi_errors(hdu):
     ops = ops_mod()
     import ctypes
     x = ops.Act.alloc(1, 1, 4, 4, 8, BF16)
-    y = ops.Act.alloc(1, 1, 4, 4, 8, BF16)
+    y = ops.Act.alloc(1, 1, 5, 5, 8, BF16)
     w = torch.zeros(8 * 9 * 8, dtype=torch.bfloat16, device=ops.device())
-    d = ops.conv_desc(x, ctypes.c_void_p(w.data_ptr()), y, (1, 3, 3), (1, 1, 1), (0, 0, 0))  # wrong out dims for pad 0
+    # pad 0: 2x2 outputs; up to K-1 = 2 extra positions per axis are legal (implicit high-side padding), 5x5 is not
+    d = ops.conv_desc(x, ctypes.c_void_p(w.data_ptr()), y, (1, 3, 3), (1, 1, 1), (0, 0, 0))
     with pytest.raises(hdu.lib.HduError, match="output dims"):
         ops.conv_fprop(d)
     bad = ops.Act(x.buf, 0, 1, 1, 4, 4, 6, 6, BF16)
