@@ -22,6 +22,8 @@ struct ConvK {
   // divisor 1).  Filled on the host (fill_convk); the per-row state of a tile costs a few VALU ops instead of three
   // ~30-instruction division sequences per row (measured: 2-3 us of a 10-15 us short-K launch).
   unsigned div_wo_mul, div_wo_shr, div_ho_mul, div_ho_shr, div_do_mul, div_do_shr;
+  unsigned div_cin_mul, div_cin_shr, div_kw_mul, div_kw_shr, div_kh_mul, div_kh_shr;   // k -> (tap, channel), tap -> (kd, kh, kw)
+  unsigned sk_div_mul, sk_div_shr;     // split-K: division by the split count (set at launch)
   int pro_relu, accumulate;
   float drop_scale;           // 1/keep (0 => dropout disabled)
   unsigned drop_thresh;       // keep iff hash < thresh
@@ -47,6 +49,18 @@ struct ConvK {
 
 __device__ __forceinline__ unsigned hdu_fastdiv(unsigned n, unsigned mul, unsigned shr) {
   return mul == 0u ? n : (unsigned)(((unsigned long long)n * mul) >> 32) >> shr;
+}
+
+// first K-tile state of a lane: GEMM column k -> channel c inside tap (kd, kh, kw)
+__device__ __forceinline__ void hdu_k_state(const ConvK& p, int k, int& c, int& kd, int& kh, int& kw, int& tap_i) {
+  const unsigned tap = hdu_fastdiv((unsigned)k, p.div_cin_mul, p.div_cin_shr);
+  tap_i = (int)tap;
+  c = k - (int)tap * p.Cin;
+  const unsigned t = hdu_fastdiv(tap, p.div_kw_mul, p.div_kw_shr);
+  kw = (int)(tap - t * (unsigned)p.KW);
+  const unsigned d = hdu_fastdiv(t, p.div_kh_mul, p.div_kh_shr);
+  kh = (int)(t - d * (unsigned)p.KH);
+  kd = (int)d;
 }
 
 // taps q in [0, K) of one axis whose input coordinate i0 + q lies inside [0, E): a contiguous bit range (K <= 32)

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     if (more) store_tile(buf ^ 1);
@@ -719,10 +719,7 @@ __device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n
       }
     }
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], m); s2[j] += __shfl_xor(s2[j], m); }
-    }
+    for (int j = 0; j < CH; ++j) { s1[j] = hdu_row16_sum(s1[j]); s2[j] = hdu_row16_sum(s2[j]); }
     if (rl == 0 && cc < NCC && nbase < p.Cout) {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
@@ -869,24 +866,31 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
     if (p.bnb_u != nullptr) bnb_issue_loads<T, BM, BN, G::IT>(p, m0, n0, tid, 0, bnb_uv, bnb_ov);
   }
   __syncthreads();                                   // all MFMA operand reads of the last K tile are done
+  // The K loops multiply with the operands SWAPPED (kgroup(b, a, acc)): a lane holds C[m = lane & 15][n = 4 * (lane >> 4)
+  // + r] of its 16x16 fragment, i.e. 4 consecutive output channels of one pixel -- one 8- / 16-byte LDS store per
+  // fragment instead of four 2- / 4-byte ones.
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int row = wm * WM + i * 16 + (lane & 15);
+    const long long m = m0 + row;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = wm * WM + i * 16 + (lane >> 4) * 4 + r;
-      const long long m = m0 + row;
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * WN + j * 16 + (lane >> 4) * 4;
+      const int n = n0 + col;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (has_bias && n < p.Cout) {                  // Cout is a multiple of the 16-byte chunk: 4 channels are all-or-nothing
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = wn * WN + j * 16 + (lane & 15);
-        const int n = n0 + col;
-        float v = acc[i][j][r];
-        if (p.bias && n < p.Cout) v += p.bias[n];
-        if (p.drop_scale != 0.f) {
-          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)n, dseed);
-          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
-        }
-        Chunk<T>::store1((T*)(smem + row * ROWB) + col, v);
+        for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
       }
+      if (drop) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(n + r), dseed);
+          v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+        }
+      }
+      Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
     }
   }
   __syncthreads();
@@ -896,22 +900,44 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
   }
   T* __restrict__ yp = (T*)p.y;
   constexpr int NCC = BN / CH;                       // 16-byte chunks per tile row
-  for (int q = tid; q < BM * NCC; q += 256) {
-    const int row = q / NCC, cc = q % NCC;
-    const long long m = m0 + row;
-    const int n = n0 + cc * CH;
-    if (m >= p.M || n >= p.Cout) continue;           // Cout is a multiple of CH: chunks are all-or-nothing
-    u32x4 v = *(const u32x4*)(smem + row * ROWB + cc * 16);
-    T* dst = yp + m * p.ldy + n;
-    if (p.accumulate) {
+  constexpr int NIT = (BM * NCC + 255) / 256;
+  if (p.accumulate) {
+    // read-modify-write: ALL of this thread's old chunks are requested before the first one is used (the accumulators
+    // are dead, their registers hold the loads) -- one memory round trip per tile instead of one per chunk
+    u32x4 old[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = tid + it * 256;
+      const int row = q / NCC, cc = q % NCC;
+      const long long m = m0 + row;
+      const int n = n0 + cc * CH;
+      old[it] = u32x4{0u, 0u, 0u, 0u};
+      if (q < BM * NCC && m < p.M && n < p.Cout) old[it] = *(const u32x4*)(yp + m * p.ldy + n);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = tid + it * 256;
+      const int row = q / NCC, cc = q % NCC;
+      const long long m = m0 + row;
+      const int n = n0 + cc * CH;
+      if (q >= BM * NCC || m >= p.M || n >= p.Cout) continue;
       float f[CH], g[CH];
-      Chunk<T>::unpack(v, f);
-      Chunk<T>::unpack(*(const u32x4*)dst, g);
+      Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), f);
+      Chunk<T>::unpack(old[it], g);
 #pragma unroll
       for (int jj = 0; jj < CH; ++jj) f[jj] += g[jj];
-      v = Chunk<T>::pack(f);
+      *(u32x4*)(yp + m * p.ldy + n) = Chunk<T>::pack(f);
     }
-    *(u32x4*)dst = v;
+  } else {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = tid + it * 256;
+      const int row = q / NCC, cc = q % NCC;
+      const long long m = m0 + row;
+      const int n = n0 + cc * CH;
+      if (q >= BM * NCC || m >= p.M || n >= p.Cout) continue;      // Cout is a multiple of CH: chunks are all-or-nothing
+      *(u32x4*)(yp + m * p.ldy + n) = *(const u32x4*)(smem + row * ROWB + cc * 16);
+    }
   }
   if (p.stats_partial)
     epilogue_stats<T, BM, BN, ROWB>(p, smem, n0, tid, blockIdx.x, [&](int row) { return m0 + row < p.M; });
@@ -999,15 +1025,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     hdu_row_state<FAST>(p, (unsigned)(m0 + r0 + i * 32), pointwise, rn[i], rid[i], rih[i], riw[i], rpix[i], rmask[i]);
   int k = kcl * CH;
   int c, kd, kh, kw, tap_i;
-  {
-    const int tap = k / p.Cin;
-    tap_i = tap;
-    c = k - tap * p.Cin;
-    kw = tap % p.KW;
-    const int t = tap / p.KW;
-    kh = t % p.KH;
-    kd = t / p.KH;
-  }
+  hdu_k_state(p, k, c, kd, kh, kw, tap_i);
   // filter rows of this lane
   const T* wrow[B_IT];
 #pragma unroll
@@ -1098,7 +1116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     __syncthreads();
@@ -1250,19 +1268,12 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   // split-K: gridDim.z workgroups share this output tile, each takes a contiguous range of K steps
   const int nk_all = (p.Ktot + BK - 1) / BK;
   const int nsplit = (int)gridDim.z, split = (int)blockIdx.z;
-  const int kt_begin = nsplit > 1 ? (int)((long long)nk_all * split / nsplit) : 0;
-  const int kt_end = nsplit > 1 ? (int)((long long)nk_all * (split + 1) / nsplit) : nk_all;
+  // split s takes K steps [nk * s / S, nk * (s + 1) / S)
+  const int kt_begin = nsplit > 1 ? (int)hdu_fastdiv((unsigned)(nk_all * split), p.sk_div_mul, p.sk_div_shr) : 0;
+  const int kt_end = nsplit > 1 ? (int)hdu_fastdiv((unsigned)(nk_all * (split + 1)), p.sk_div_mul, p.sk_div_shr) : nk_all;
   int k = kt_begin * BK + kcl * CH;
   int c, kd, kh, kw, tap_i;
-  {
-    const int tap = k / p.Cin;
-    tap_i = tap;
-    c = k - tap * p.Cin;
-    kw = tap % p.KW;
-    const int t = tap / p.KW;
-    kh = t % p.KH;
-    kd = t / p.KH;
-  }
+  hdu_k_state(p, k, c, kd, kh, kw, tap_i);
   const T* wrow[B_IT];
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
@@ -1356,7 +1367,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     slot = slot == NS - 1 ? 0 : slot + 1;
@@ -1872,7 +1883,7 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     __syncthreads();
@@ -1881,26 +1892,31 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
   // ---- epilogue: bias / dropout in registers, LDS-staged 16-byte row stores (tile pixel -> image pixel)
   constexpr int ROWB = BN * 2 + 16;
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {                      // (operands swapped in the K loop: lane = pixel li, 4 channels lg*4..)
+    const int tx = i * 16 + li;
+    const int row = wave * 32 + tx;
+    const long long m = ((long long)(n * H + y0 + wave)) * W + x0 + tx;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int tx = i * 16 + lg * 4 + r;
-      const int row = wave * 32 + tx;
-      const long long m = ((long long)(n * H + y0 + wave)) * W + x0 + tx;
+    for (int j = 0; j < TN; ++j) {
+      const int col = j * 16 + lg * 4;
+      const int nn = n0 + col;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (has_bias && nn < p.Cout) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = j * 16 + li;
-        const int nn = n0 + col;
-        float v = acc[i][j][r];
-        if (p.bias && nn < p.Cout) v += p.bias[nn];
-        if (p.drop_scale != 0.f) {
-          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)nn, dseed);
-          v = h < p.drop_thresh ? v * p.drop_scale : 0.f;
-        }
-        Chunk<T>::store1((T*)(smem + row * ROWB) + col, v);
+        for (int r = 0; r < 4; ++r) v[r] += p.bias[nn + r];
       }
+      if (drop) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(nn + r), dseed);
+          v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+        }
+      }
+      Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
     }
+  }
   __syncthreads();
   T* __restrict__ yp = (T*)p.y;
   constexpr int NCC = BN / 8;
@@ -2180,6 +2196,10 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   fastdiv_magic(d->Wo, &k->div_wo_mul, &k->div_wo_shr);
   fastdiv_magic(d->Ho, &k->div_ho_mul, &k->div_ho_shr);
   fastdiv_magic(d->Do, &k->div_do_mul, &k->div_do_shr);
+  fastdiv_magic(d->Cin, &k->div_cin_mul, &k->div_cin_shr);
+  fastdiv_magic(d->KW, &k->div_kw_mul, &k->div_kw_shr);
+  fastdiv_magic(d->KH, &k->div_kh_mul, &k->div_kh_shr);
+  k->sk_div_mul = 0u; k->sk_div_shr = 0u;
   k->pro_relu = d->pro_relu; k->accumulate = d->accumulate;
   if (d->drop_keep > 0.f && d->drop_keep < 1.f) {
     k->drop_scale = 1.f / d->drop_keep;
@@ -2262,9 +2282,13 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
       constexpr int BK = 8 * Chunk<T>::CH;
       size_t need;
       const int S = choose_splitk(nblk, (k.Ktot + BK - 1) / BK, BM, BN, &need);
-      if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) grid.z = (unsigned)S;   // (512 ticket counters)
-      if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, k);
-      else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, k);
+      ConvK kk = k;
+      if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) {      // (512 ticket counters)
+        grid.z = (unsigned)S;
+        fastdiv_magic(S, &kk.sk_div_mul, &kk.sk_div_shr);
+      }
+      if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, kk);
+      else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, kk);
     } else {
       if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, false>), grid, dim3(256), 0, s, k);

@@ -90,6 +90,10 @@ template <> struct Chunk<float> {
   }
   __device__ __forceinline__ static float load1(const float* p) { return *p; }
   __device__ __forceinline__ static void store1(float* p, float v) { *p = v; }
+  // 4 consecutive elements, 16-byte aligned destination
+  __device__ __forceinline__ static void store4(float* p, const float* v) {
+    *(u32x4*)p = u32x4{hdu_f2u(v[0]), hdu_f2u(v[1]), hdu_f2u(v[2]), hdu_f2u(v[3])};
+  }
 };
 
 template <> struct Chunk<bf16_t> {
@@ -106,6 +110,10 @@ template <> struct Chunk<bf16_t> {
   }
   __device__ __forceinline__ static float load1(const bf16_t* p) { return bf16_to_f32(*p); }
   __device__ __forceinline__ static void store1(bf16_t* p, float v) { *p = hdu_f32_to_bf16_dev(v); }
+  // 4 consecutive elements, 8-byte aligned destination
+  __device__ __forceinline__ static void store4(bf16_t* p, const float* v) {
+    *(u32x2*)p = u32x2{hdu_pack_bf16x2(v[0], v[1]), hdu_pack_bf16x2(v[2], v[3])};
+  }
 };
 
 // ---- MFMA wrappers: one "k-group" = 16 bytes of k per lane for A and B ----
@@ -140,6 +148,21 @@ template <> struct Mma<float> {
     return c;
   }
 };
+
+// sum over the 16 lanes of a DPP row (lanes 16r..16r+15), result in every lane: quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror -- four VALU adds with DPP operands instead of four ds_bpermute round trips.  (After the two quad steps the
+// values are quad-uniform, so the mirrors pair the same quads / halves as xor 4 / xor 8 would: bit-identical sums.)
+__device__ __forceinline__ float hdu_row16_sum(float v) {
+#ifdef HDU_EMU
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+#else
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+#endif
+  return v;
+}
 
 // LDS transpose read: lane i of each 16-lane group passes the address of row (i>>2), columns (i&3)*4.. of a 4x16
 // row-major 16-bit tile and receives column i (4 elements, rows 0..3) -- ds_read_b64_tr_b16.
