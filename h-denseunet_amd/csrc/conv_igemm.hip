@@ -2301,7 +2301,10 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
 // writes full output rows, so wide tiles are preferred: cost model = n_tiles * (BN + 32) (MFMA columns + the A-load
 // expressed in column equivalents); 64-row tiles below 16 K pixels.
 static void choose_igemm(const ConvK& k, int* bm, int* bn) {
-  const int cands[5] = {128, 96, 64, 48, 32};     // 192 measured slower (and its f32 tile cannot be staged)
+  // 192-column tiles (one N tile for the 192-channel bottleneck outputs / 3x3 data gradients: 29 % fewer DMA instructions
+  // per FLOP, still 2 workgroups / CU) were measured slower in both rounds (r02: 2D 21.6 -> 22.0 ms, 3dpart 11.09 -> 11.17,
+  // profiles/r02_experiment_knob_probes.txt); their f32 form cannot be staged in the operand LDS anyway.
+  const int cands[5] = {128, 96, 64, 48, 32};
   int best = 64;
   long long best_cost = -1;
   const int maxbn = g_tuning[HDU_TUNE_MAX_BN] > 0 ? g_tuning[HDU_TUNE_MAX_BN] : 128;
