@@ -2249,10 +2249,13 @@ static bool igemm_fast_ok(const ConvK& k) {
 // busy compute unit is bound by what it alone can pull from L2 (measured: 14-20 KB per K step at ~1 us per step whatever
 // the MFMA work), so the K steps are dealt to S workgroups per tile until ~256 workgroups run, keeping >= 4 K steps per
 // split and S <= 16 (the last arriver reads S-1 partial tiles).  `bytes`: scratch the launch needs.
-static int choose_splitk(long long nblk, int nk, int bm, int bn, size_t* bytes) {
+// bf16 64-row tiles run a 3-stage ring (<= 72 KB of LDS): two workgroups share a CU, so a split launch aims at 512
+static int ring_wgs_per_cu(int bm, bool bf16) { return (bm == 64 && bf16 && g_tuning[HDU_TUNE_RING_STAGES] != 6) ? 2 : 1; }
+
+static int choose_splitk(long long nblk, int nk, int bm, int bn, int per_cu, size_t* bytes) {
   *bytes = 0;
   const int mode = g_tuning[HDU_TUNE_SPLITK];
-  const int target = g_tuning[HDU_TUNE_SPLITK_TARGET] > 0 ? g_tuning[HDU_TUNE_SPLITK_TARGET] : 256;
+  const int target = g_tuning[HDU_TUNE_SPLITK_TARGET] > 0 ? g_tuning[HDU_TUNE_SPLITK_TARGET] : 256 * per_cu;
   const int min_steps = g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] > 0 ? g_tuning[HDU_TUNE_SPLITK_MIN_STEPS] : 4;   // swept: profiles/r02_experiment_splitk_sweep.txt
   if (mode == 1 || nblk > target / 2) return 1;
   int S = mode >= 2 ? mode : (int)((target + nblk - 1) / nblk);
@@ -2281,11 +2284,21 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
     if (igemm_ring_ok(nblk, k.Ktot, STAGE, NSD)) {
       constexpr int BK = 8 * Chunk<T>::CH;
       size_t need;
-      const int S = choose_splitk(nblk, (k.Ktot + BK - 1) / BK, BM, BN, &need);
+      const int S = choose_splitk(nblk, (k.Ktot + BK - 1) / BK, BM, BN, ring_wgs_per_cu(BM, sizeof(T) == 2), &need);
       ConvK kk = k;
       if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) {      // (512 ticket counters)
         grid.z = (unsigned)S;
         fastdiv_magic(S, &kk.sk_div_mul, &kk.sk_div_shr);
+      }
+      if constexpr (BM == 64 && sizeof(T) == 2 && NSD == 6) {
+        // 64-row bf16 tiles: THREE stages (<= 72 KB) so that two workgroups share a CU and the prologue issues 2 tiles,
+        // not 5, before the first MFMA (measured r02 call P: 3dpart 11.12 -> 10.68 ms with the 512-workgroup split
+        // target, 2D 21.62 -> 21.57; 4 stages in between).  HDU_TUNE_RING_STAGES = 6 restores the deep ring (A/B).
+        if (g_tuning[HDU_TUNE_RING_STAGES] != 6) {
+          if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3, true>), grid, dim3(256), 0, s, kk);
+          else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3, false>), grid, dim3(256), 0, s, kk);
+          return;
+        }
       }
       if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, kk);
       else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, kk);
@@ -2403,7 +2416,7 @@ extern "C" size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d) {
   if (!igemm_ring_ok(nblk, k.Ktot, stage, nsd)) return 0;
   const int bk = d->dtype == HDU_BF16 ? 64 : 32;
   size_t need;
-  choose_splitk(nblk, (k.Ktot + bk - 1) / bk, bm, bn, &need);
+  choose_splitk(nblk, (k.Ktot + bk - 1) / bk, bm, bn, ring_wgs_per_cu(bm, d->dtype == HDU_BF16), &need);
   return need;
 }
 
@@ -2704,8 +2717,9 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
     const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;
     const bool ring = dma && igemm_ring_ok(nblk, k.Ktot, stage, nsd);
+    const int nsr = (nsd == 6 && ring_wgs_per_cu(bm, d->dtype == HDU_BF16) == 2) ? 3 : nsd;     // (launch_igemm)
     const char* fast = igemm_fast_ok(k) ? "true" : "false";
-    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, nsd, fast);
+    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, nsr, fast);
     else if (dma) snprintf(buf, buflen, "conv_igemm_dma_kernel<%s, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, fast);
     else snprintf(buf, buflen, "conv_igemm_kernel<%s, %d, %d, %d, %d>", t, bm, bn, wm, 4 / wm);
   }

@@ -1,0 +1,15 @@
+#!/bin/bash
+# round-2 GPU call Q: 3-stage ring default -- split target / min-steps sweep
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+run() { echo "== $1 / $2" ; env $1 python bench.py --config $2 --steps 15 --warmup 4 --no-cpu-baseline --no-roofline --extras none 2>&1 | grep -o '"ms_per_step": [0-9.]*' ; }
+( for c in 3dpart end2end 2d; do
+  run "A=0" $c
+  run "HDU_RING_STAGES=6" $c
+  run "HDU_SPLITK_TARGET=384" $c
+  run "HDU_SPLITK_TARGET=768" $c
+  run "HDU_SPLITK_MIN_STEPS=6" $c
+  run "HDU_SPLITK_TARGET=768 HDU_SPLITK_MIN_STEPS=6" $c
+  run "A=0" $c
+done ) > gpurun_out/q_ab.log 2>&1
+cat gpurun_out/q_ab.log
