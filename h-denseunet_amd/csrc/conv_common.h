@@ -10,6 +10,9 @@ struct ConvK {
   const float* pro_a;
   const float* pro_b;
   const float* bias;
+  const float* epi_a;         // optional output affine (+ReLU) after bias / dropout (hdu_conv_desc.epi_*)
+  const float* epi_b;
+  int epi_relu;
   long long ldx, ldskip, ldy;
   long long M;                // N*Do*Ho*Wo
   int N, Di, Hi, Wi, Cin;     // stored input dims

@@ -869,7 +869,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
   // The K loops multiply with the operands SWAPPED (kgroup(b, a, acc)): a lane holds C[m = lane & 15][n = 4 * (lane >> 4)
   // + r] of its 16x16 fragment, i.e. 4 consecutive output channels of one pixel -- one 8- / 16-byte LDS store per
   // fragment instead of four 2- / 4-byte ones.
-  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f;
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = wm * WM + i * 16 + (lane & 15);
@@ -888,6 +888,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
         for (int r = 0; r < 4; ++r) {
           const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(n + r), dseed);
           v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+        }
+      }
+      if (has_epi && n < p.Cout) {                   // the BN(+Scale)(+ReLU) that follows this conv (stored statistics)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = p.epi_a[n + r] * v[r] + p.epi_b[n + r];
+          if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
       }
       Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
@@ -1892,7 +1899,7 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
   // ---- epilogue: bias / dropout in registers, LDS-staged 16-byte row stores (tile pixel -> image pixel)
   constexpr int ROWB = BN * 2 + 16;
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f;
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {                      // (operands swapped in the K loop: lane = pixel li, 4 channels lg*4..)
     const int tx = i * 16 + li;
@@ -1912,6 +1919,13 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
         for (int r = 0; r < 4; ++r) {
           const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(nn + r), dseed);
           v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+        }
+      }
+      if (has_epi && nn < p.Cout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = p.epi_a[nn + r] * v[r] + p.epi_b[nn + r];
+          if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
       }
       Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
@@ -2173,6 +2187,9 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   if ((d->pro_a == nullptr) != (d->pro_b == nullptr)) return hdu_set_error(HDU_ERR_ARG, "conv: pro_a/pro_b must both be set");
   k->x = d->x; k->skip = d->skip; k->w = d->w; k->y = d->y;
   k->pro_a = d->pro_a; k->pro_b = d->pro_b; k->bias = d->bias;
+  k->epi_a = wgrad ? nullptr : d->epi_a; k->epi_b = d->epi_b; k->epi_relu = d->epi_relu;
+  if (k->epi_a && (!k->epi_b || d->accumulate || d->stats_partial || d->bnb_u))
+    return hdu_set_error(HDU_ERR_ARG, "conv: the output affine needs epi_b and excludes accumulate / epilogue statistics / the fused BN backward");
   k->ldx = d->ldx; k->ldskip = d->ldskip; k->ldy = d->ldy;
   k->N = d->N; k->Di = d->Di; k->Hi = d->Hi; k->Wi = d->Wi; k->Cin = d->Cin;
   k->ud = d->ud; k->uh = d->uh; k->uw = d->uw;
@@ -2603,6 +2620,7 @@ extern "C" int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream) {
   if (int e = fill_convk(d, &k, false)) return e;
   if (d->ud | d->uh | d->uw) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: upsampled input not supported");
   if (!d->x || !d->y) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: null dx / dy");
+  if (d->epi_a) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: no output affine");
   const long long total = (long long)d->N * d->Di * d->Hi * d->Wi * (d->Cin / (d->dtype == HDU_BF16 ? 8 : 4));
   if (total == 0) return 0;
   long long blocks = (total + 255) / 256;

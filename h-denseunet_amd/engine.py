@@ -172,6 +172,7 @@ class Ctx:
         self.drop_layers = 0
         self.dropout_enabled = True
         self.grad_enabled = True
+        self.fuse_bn_epilogue = os.environ.get("HDU_FUSE_BN_EPILOGUE", "1") == "1"
         self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
         # filter gradients deferred to the end of the backward pass and run as ONE launch per kernel family
@@ -559,9 +560,13 @@ class ConvLayer:
 
     def __init__(self, ctx, name, x, filters, K, stride=(1, 1, 1), pad=(0, 0, 0), bn=None, up=(0, 0, 0), skip=None,
                  use_bias=True, out=None, init="glorot", trainable=True, dropout=0.0, keras_nd=2, cin_logical=None,
-                 halo=0):
+                 halo=0, producer=None):
         """halo > 0 (depth sharding): the conv input buffer carries `halo` extra depth planes on both sides, filled
-        from the depth neighbours before the launch; the padding on the depth axis shrinks accordingly."""
+        from the depth neighbours before the launch; the padding on the depth axis shrinks accordingly.
+        producer: the ConvLayer whose output `x` is, when NOTHING else reads that output (the model builder's promise:
+        a bottleneck's 1x1 -> BN -> ReLU -> 3x3).  Whenever `bn` runs on stored statistics and no gradient flows through
+        it (every predict; the frozen 2D branch of the 3dpart hybrid), the producer applies bn + ReLU in its own
+        epilogue and writes this conv's operand directly (hdu_conv_desc.epi_*): one full-width pass less."""
         self.ctx, self.name, self.x, self.bn, self.up, self.skip = ctx, name, x, bn, up, skip
         self.K, self.stride = K, stride
         self.halo = halo
@@ -617,6 +622,12 @@ class ConvLayer:
             else:
                 self.xin = ctx.new_var(xa.N, xa.D, xa.H, xa.W, cin_p)
         self.need_input_grad = need_input_grad
+        self.epi_consumer = None          # set by the conv that consumes self.out through a foldable BN (see `producer`)
+        self.epi_producer = None
+        if (producer is not None and ctx.fuse_bn_epilogue and bn is not None and self.xin is not None and not halo
+                and skip is None and up == (0, 0, 0) and x is producer.out and x.root is x and producer.epi_consumer is None):
+            self.epi_producer = producer
+            producer.epi_consumer = self
         self.strided = stride != (1, 1, 1)
         # the consumer BN's backward runs in the epilogue of this layer's data-gradient launch when dz IS that launch's
         # output: no up-sampling in between, no skip add, no depth halo, no dropout on the BN input
@@ -670,6 +681,16 @@ class ConvLayer:
         if self.dropout > 0:
             self.d_f_drop = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu,
                                           bias, False, 1.0 - self.dropout, self.drop_seed, ctx.seed_dev)
+        # variants that apply the consumer's BN(+Scale)+ReLU in the epilogue and write the consumer's operand buffer
+        self.d_f_epi = self.d_f_drop_epi = None
+        cons = self.epi_consumer
+        if cons is not None:
+            epi = (cons.bn.a, cons.bn.b, cons.bn.relu)
+            self.d_f_epi = ops.conv_desc(x, self.wf_ptr, cons.xin.act, self.K, self.stride, self.pad, up, skip, pro, relu, bias,
+                                         epi=epi)
+            if self.dropout > 0:
+                self.d_f_drop_epi = ops.conv_desc(x, self.wf_ptr, cons.xin.act, self.K, self.stride, self.pad, up, skip, pro,
+                                                  relu, bias, False, 1.0 - self.dropout, self.drop_seed, ctx.seed_dev, epi=epi)
         # training-phase variants that also accumulate the output's moments for the StatsOp that follows this conv
         self.d_f_st = self.d_f_drop_st = None
         sink = getattr(self, "stats_sink", None)
@@ -694,8 +715,18 @@ class ConvLayer:
         wd = ctx.Wc[self.wd_off:self.wd_off + self.kernel.numel] if self.need_dgrad_filter else None
         ops.weight_prep(ctx.dtype, self.kernel.data, self.cout_p, self.T, self.cin_p, wf, wd)
 
+    def epi_active(self):
+        """does the PRODUCER write this conv's operand in the current pass?  The BN must run on stored statistics and
+        nothing may need the producer's raw output: no gradient through the BN, no trainable BN / Scale parameter."""
+        ctx, bn = self.ctx, self.bn
+        if self.epi_producer is None or (bn.mode == "batch" and ctx.learning_phase == 1):
+            return False
+        return ctx.learning_phase == 0 or not (self.need_input_grad or bn.any_trainable())    # (phase 1 = a backward pass follows)
+
     def forward(self):
         ctx = self.ctx
+        if self.epi_producer is not None and self.epi_active():
+            return self._forward_conv()          # the producer's epilogue already wrote self.xin
         if self.bn is not None:
             self.bn.fold(self.x)
         if self.xin is not None:
@@ -706,6 +737,16 @@ class ConvLayer:
             ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False, up, skip, dst)
             if self.halo:
                 _sh.halo_exchange(ctx.shard, self.xin.act, self.halo)
+        self._forward_conv()
+
+    def _forward_conv(self):
+        ctx = self.ctx
+        cons = self.epi_consumer
+        if cons is not None and cons.epi_active():
+            cons.bn.fold(self.out)               # (no-op after the batched fold at the head of the pass)
+            drop = self.d_f_drop_epi is not None and ctx.learning_phase == 1 and ctx.dropout_enabled
+            ops.conv_fprop(self.d_f_drop_epi if drop else self.d_f_epi)
+            return
         # epilogue statistics once the sink has a usable shift (the previous pass's mean); the first training pass
         # after build / after new weights uses the two-pass reduction (shift = a sample of the tensor itself)
         st = ctx.learning_phase == 1 and self.d_f_st is not None and self.stats_sink.primed

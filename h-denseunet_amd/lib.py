@@ -34,6 +34,7 @@ class ConvDesc(ctypes.Structure):
         ("y", c_p), ("ldy", c_i64),
         ("Do", c_int), ("Ho", c_int), ("Wo", c_int), ("Cout", c_int),
         ("bias", c_p),
+        ("epi_a", c_p), ("epi_b", c_p), ("epi_relu", c_int),
         ("accumulate", c_int),
         ("drop_keep", c_f),
         ("drop_seed", c_u32),

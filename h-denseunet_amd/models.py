@@ -65,7 +65,7 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
             bn_b = bn_dense(base + "_x2", growth * 4)
             _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (1, 3, 3), pad=(0, 1, 1), bn=bn_b, use_bias=False,
-                      out=buf.slab(c, growth), trainable=tr_conv)
+                      out=buf.slab(c, growth), trainable=tr_conv, producer=c1)
             _stats(ctx, buf.slab(c, growth), mode)
             c += growth
         return c
@@ -157,7 +157,7 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
             bn_b = BNLayer(ctx, base + "_x2_bn", growth * 4, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x2_scale", True)
             _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (3, 3, 3), pad=(1, 1, 1), bn=bn_b, use_bias=False,
-                      out=buf.slab(c, growth), keras_nd=3, halo=hl)
+                      out=buf.slab(c, growth), keras_nd=3, halo=hl, producer=c1)
             _stats(ctx, buf.slab(c, growth), blk_mode)
             c += growth
         return c

@@ -102,8 +102,8 @@ def splitk_scratch():
 
 
 def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
-              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None):
-    """x: Act (stored input), y: Act (output), K=(KD,KH,KW)."""
+              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None):
+    """x: Act (stored input), y: Act (output), K=(KD,KH,KW); epi = (a, b, relu): output affine of the BN that follows."""
     d = ConvDesc()
     ws, cnt = splitk_scratch()
     d.splitk_ws, d.splitk_ws_bytes, d.splitk_counters = ws.data_ptr(), SPLITK_BYTES, cnt.data_ptr()
@@ -122,6 +122,8 @@ def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), ski
     d.y, d.ldy = y.ptr, y.ld
     d.Do, d.Ho, d.Wo, d.Cout = y.D, y.H, y.W, y.C
     d.bias = fptr(bias)
+    if epi is not None:
+        d.epi_a, d.epi_b, d.epi_relu = fptr(epi[0]), fptr(epi[1]), 1 if epi[2] else 0
     d.accumulate = 1 if accumulate else 0
     d.drop_keep = drop_keep
     d.drop_seed = drop_seed

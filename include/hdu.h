@@ -91,6 +91,12 @@ typedef struct hdu_conv_desc {
   void* y;            int64_t ldy;
   int Do, Ho, Wo, Cout;
   const float* bias;               /* optional [Cout] */
+  /* optional output affine (+ReLU) AFTER bias and dropout: y = act(epi_a[co] * y + epi_b[co]).  The folded
+   * BatchNormalization(+Scale)+Activation('relu') that FOLLOWS this conv (K.layers/normalization.py:126-190,
+   * lib/custom_layers.py:63-69) when it runs on stored statistics and nothing needs the conv's raw output: the conv
+   * writes the next conv's operand directly -- one full-width pass per bottleneck less (frozen 2D branch of the hybrids,
+   * every predict).  Not with accumulate / epilogue statistics / the fused BN backward. */
+  const float* epi_a; const float* epi_b; int epi_relu;
   int accumulate;                  /* y += result instead of y = result */
   float drop_keep;                 /* 1.0 = no dropout; else keep-probability */
   uint32_t drop_seed;

@@ -149,6 +149,18 @@ def test_conv_fprop(hdu, cs, dtype):
     d.accumulate = 1
     ops.conv_fprop(d)
     assert_close(ya.to_torch().cpu(), q(ref, dtype) * 2, dtype, scale=2 * float(ref.abs().max()), what="fprop accumulate")
+    # output affine (+ReLU) of the BN that follows (hdu_conv_desc.epi_*): relu(a * (conv + bias) + b)
+    ea, eb = rnd((Cout,), 31, 1.0).float().double() + 1.5, rnd((Cout,), 32, 0.5).float().double()
+    ea_d, eb_d = dev(ops, ea), dev(ops, eb)          # (the descriptor holds raw pointers: keep the tensors alive)
+    for relu in (True, False):
+        d2 = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), ya, cs["K"], cs["s"], cs["p"], cs["up"], b["sa"], pro, True,
+                           bias, epi=(ea_d, eb_d, relu))
+        ops.conv_fprop(d2)
+        r2 = ref * ea + eb
+        assert_close(ya.to_torch().cpu(), r2.clamp_min(0) if relu else r2, dtype, scale=float(r2.abs().max()), what="fprop + output affine")
+    d2.accumulate = 1
+    with pytest.raises(hdu.lib.HduError, match="output affine"):
+        ops.conv_fprop(d2)
 
 
 @pytest.mark.parametrize("dtype", DT)

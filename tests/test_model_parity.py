@@ -252,3 +252,33 @@ def test_fused_bn_backward_equals_separate_passes(emu_lib, monkeypatch, kind, va
             if e > worst[0]:
                 worst = (e, (n, i))
     assert worst[0] <= 2e-4, worst
+
+@pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 1, 64, None), ("hybrid", "3dpart", 1, 32, 8)])
+def test_bn_in_producer_epilogue_equals_materialize_pass(emu_lib, monkeypatch, kind, variant, b, size, cols):
+    """hdu_conv_desc.epi_*: the bottleneck 1x1 conv applies the following BN(+Scale)+ReLU in its epilogue and writes the
+    3x3 conv's operand directly -- in every predict, and in the training step of the 3dpart hybrid's frozen 2D branch.
+    Same logits / loss / gradients as the separate materialise pass (HDU_FUSE_BN_EPILOGUE=0)."""
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("HDU_FUSE_BN_EPILOGUE", on)
+        m = U.build_pair(kind, variant, b, size, cols, "f32", NB2D, NB3D, odtype=torch.float32)[0]
+        m.ctx.dropout_enabled = False
+        fused = [c for c in m.ctx.convs if c.epi_consumer is not None]
+        assert (len(fused) >= 8) == (on == "1")
+        x, y = U.synthetic_batch(kind, b, size, cols)
+        pred = m.predict(x)
+        if on == "1":
+            m.ctx.learning_phase = 0
+            assert all(c.epi_consumer.epi_active() for c in fused)
+            m.ctx.learning_phase = 1
+            # training: only where no gradient flows through the BN (the frozen 2D branch of 3dpart)
+            act = [c for c in fused if c.epi_consumer.epi_active()]
+            assert (len(act) > 0) == (variant == "3dpart") and len(act) < len(fused) + (variant == "3dpart")
+        m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True),
+                  loss=[U.pkg("loss").weighted_crossentropy if kind != "2d" else U.pkg("loss").weighted_crossentropy_2ddense])
+        loss = m.train_on_batch(x, y)
+        res.append((pred, loss, m.ctx.G[:m.ctx.n_trainable].clone()))
+    (p1, l1, g1), (p0, l0, g0) = res
+    assert float(np.abs(p1 - p0).max()) <= 1e-5 * max(1.0, float(np.abs(p0).max()))
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    assert float((g1 - g0).norm() / g0.norm()) <= 1e-4
