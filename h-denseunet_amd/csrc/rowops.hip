@@ -359,6 +359,71 @@ extern "C" int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M,
   return hdu_check_launch("bn_stats_finalize");
 }
 
+// finalize of a slab SEGMENT's epilogue statistics + fold of the NEXT BatchNormalization(+Scale), whose input is the whole
+// slab [0, C_all) ending with that segment (dense blocks: layer l's 3x3 conv writes channels [c, c+g); layer l+1's first BN
+// reads [0, c+g)).  One thread column per slab channel: segment channels sum their slot rows first (and publish mean / var),
+// the others read the stored moments; every channel then folds -- no cross-channel dependency, one launch instead of two.
+__global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __restrict__ partial, int slots, int Cseg,
+                                                                 int seg_c0, int C_all, long long M,
+                                                                 float* __restrict__ mean_all, float* __restrict__ var_all,
+                                                                 FinK fin) {
+  __shared__ double red[2][32][8];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  const bool in_seg = c >= seg_c0 && c < seg_c0 + Cseg;
+  const bool wg_has_seg = (int)blockIdx.x * 8 + 7 >= seg_c0 && (int)blockIdx.x * 8 < seg_c0 + Cseg;   // workgroup-uniform
+  if (wg_has_seg) {
+    double a1 = 0.0, a2 = 0.0;
+    if (in_seg) {
+      const int cs = c - seg_c0;
+      for (int b = pl; b < slots; b += 32) {
+        a1 += (double)partial[((long long)b * 2 + 0) * Cseg + cs];
+        a2 += (double)partial[((long long)b * 2 + 1) * Cseg + cs];
+      }
+    }
+    red[0][pl][cl] = a1;
+    red[1][pl][cl] = a2;
+    __syncthreads();
+    for (int s = 16; s > 0; s >>= 1) {
+      if (pl < s) {
+        red[0][pl][cl] += red[0][pl + s][cl];
+        red[1][pl][cl] += red[1][pl + s][cl];
+      }
+      __syncthreads();
+    }
+  }
+  if (pl != 0 || c >= C_all) return;
+  float mu, v;
+  if (in_seg) {
+    const double m1 = red[0][0][cl] / (double)M;
+    double var = red[1][0][cl] / (double)M - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    mu = (float)((double)mean_all[c] + m1);          // the epilogue's shift is the previous pass's mean (same array)
+    v = (float)var;
+    mean_all[c] = mu;
+    var_all[c] = v;
+  } else {
+    mu = mean_all[c];
+    v = var_all[c];
+  }
+  bn_fold_channel(c, mu, v, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a, fin.b, fin.rstd, fin.mov_mean,
+                  fin.mov_var, fin.momentum);
+}
+
+extern "C" int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, int Cseg, int seg_c0, int C_all,
+                                               float* mean_all, float* var_all, const float* gamma, const float* beta,
+                                               float eps, const float* sgamma, const float* sbeta, float* a, float* b,
+                                               float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream) {
+  if (!partial || slots <= 0 || M <= 0 || Cseg <= 0 || seg_c0 < 0 || C_all < seg_c0 + Cseg || !mean_all || !var_all || !a || !b)
+    return hdu_set_error(HDU_ERR_ARG, "bn_stats_finalize_fold_next: bad args");
+  FinK f{};
+  f.kind = 1; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.sbeta = sbeta; f.eps = eps; f.momentum = momentum;
+  f.a = a; f.b = b; f.rstd = rstd; f.mov_mean = mov_mean; f.mov_var = mov_var;
+  HDU_LAUNCH(finalize_fold_next_kernel, dim3((unsigned)((C_all + 7) / 8)), dim3(256), 0, (hipStream_t)stream, partial, slots,
+             Cseg, seg_c0, C_all, (long long)M, mean_all, var_all, f);
+  return hdu_check_launch("bn_stats_finalize_fold_next");
+}
+
 extern "C" int hdu_bn_bwd_finalize(const float* partial, int slots, int64_t M, int C, int batch_stats, const float* gamma,
                                    const float* beta, const float* sgamma, const float* mean, const float* rstd,
                                    float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, float* corr3, float* corr4,

@@ -173,6 +173,7 @@ class Ctx:
         self.dropout_enabled = True
         self.grad_enabled = True
         self.fuse_bn_epilogue = os.environ.get("HDU_FUSE_BN_EPILOGUE", "1") == "1"
+        self.fold_next = os.environ.get("HDU_FOLD_NEXT", "1") == "1"
         self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
         # filter gradients deferred to the end of the backward pass and run as ONE launch per kernel family
@@ -906,6 +907,7 @@ class StatsOp:
     def __init__(self, ctx, var):
         self.ctx, self.var = ctx, var
         self.fused = None
+        self.fold_next = None
         self.sync_buf = ctx.fvec(2 * var.C)
         ctx.need_ws(var.act.M, var.C)
         var.stats()
@@ -926,6 +928,13 @@ class StatsOp:
     def fuse(self, bn):
         assert bn.C == self.var.C and bn.mode == "batch"
         self.fused = bn
+        return self
+
+    def then_fold(self, bn):
+        """`bn` (batch statistics) reads the slab [0, end of this segment): the finalize launch of this segment's
+        epilogue statistics also folds it (hdu_bn_stats_finalize_fold_next) -- one launch less per dense layer."""
+        if self.fused is None and bn.mode == "batch" and self.ctx.fold_next and bn.C == self.var.c0 + self.var.C:
+            self.fold_next = bn
         return self
 
     def forward(self):
@@ -952,6 +961,17 @@ class StatsOp:
         elif self.producer is not None:
             # the conv epilogue left sum(y - shift), sum((y - shift)^2) in the slot rows; shift = last step's mean
             n = self.SLOTS * 2 * self.var.C
+            nb = self.fold_next
+            if nb is not None:
+                r = self.var.root
+                f2 = (nb.gamma.data, nb.beta.data, nb.eps, nb.sg.data if nb.sg else None, nb.sb.data if nb.sb else None,
+                      nb.a, nb.b, nb.rstd, nb.mm.data, nb.mv.data, nb.momentum)
+                ops.bn_stats_finalize_fold_next(ctx.stats_acc[self.acc_off:self.acc_off + n], self.SLOTS, self.var.act.M,
+                                                self.var.C, self.var.c0, nb.C, r.mean[:nb.C], r.var[:nb.C], f2)
+                nb.batch_now = True
+                nb.mean_used = r.mean[:nb.C]
+                nb.folded_pass = ctx.pass_id
+                return
             ops.bn_stats_finalize(ctx.stats_acc[self.acc_off:self.acc_off + n], self.SLOTS, self.var.act.M, self.var.C,
                                   mean, mean, var, fold)
         elif bn is None:

@@ -54,11 +54,15 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
     z0 = MaterializeLayer(ctx, conv1.out, bn1).out          # relu1 = box[0]
     box = [z0]
 
+    seg_stats = [None]        # StatsOp of the slab segment written last: its finalize launch also folds the next BN
+
     def dense_block(stage, nlayers, buf, c0):
         c = c0
         for i in range(nlayers):
             base = "conv%d_%d" % (stage, i + 1)
             bn_a = bn_dense(base + "_x1", c)
+            if seg_stats[0] is not None:
+                seg_stats[0].then_fold(bn_a)
             c1 = ConvLayer(ctx, base + "_x1", buf.slab(0, c), growth * 4, (1, 1, 1), bn=bn_a, use_bias=False,
                            trainable=tr_conv)
             st = _stats(ctx, c1.out, mode)
@@ -66,7 +70,7 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
             _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (1, 3, 3), pad=(0, 1, 1), bn=bn_b, use_bias=False,
                       out=buf.slab(c, growth), trainable=tr_conv, producer=c1)
-            _stats(ctx, buf.slab(c, growth), mode)
+            seg_stats[0] = _stats(ctx, buf.slab(c, growth), mode)
             c += growth
         return c
 
@@ -81,6 +85,9 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
         box.append(buf)
         base = "conv%d_blk" % stage
         bn_t = bn_dense(base, nb_filter)
+        if seg_stats[0] is not None:
+            seg_stats[0].then_fold(bn_t)
+        seg_stats[0] = None
         nout = int(nb_filter * compression)
         ct = ConvLayer(ctx, base, buf, nout, (1, 1, 1), bn=bn_t, use_bias=False, trainable=tr_conv)
         h, w = h // 2, w // 2
@@ -91,6 +98,8 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
     final_stage = stage + 1
     nb_filter = dense_block(final_stage, nb_layers[-1], buf, nb_filter)
     bn5 = bn_dense("conv%d_blk" % final_stage, nb_filter)
+    if seg_stats[0] is not None:
+        seg_stats[0].then_fold(bn5)
 
     # decoder widths equal the skip widths: 768, 384, 96 for DenseNet-161 (denseunet.py:192-204)
     dec = [(box[2].C, "0"), (box[1].C, "1"), (box[0].C, "2"), (96, "3"), (64, "4")]
@@ -147,18 +156,22 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     MaxPoolLayer(ctx, z0, out=buf.slab(0, nb_filter), pad_d=0 if sharded else 1)
     _stats(ctx, buf.slab(0, nb_filter), blk_mode)
 
+    seg_stats = [None]
+
     def dense_block(stage, nlayers, buf, c0):
         c = c0
         for i in range(nlayers):
             base = "3dconv%d_%d" % (stage, i + 1)
             bn_a = BNLayer(ctx, base + "_x1_bn", c, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x1_scale", True)
+            if seg_stats[0] is not None:
+                seg_stats[0].then_fold(bn_a)
             c1 = ConvLayer(ctx, base + "_x1", buf.slab(0, c), growth * 4, (1, 1, 1), bn=bn_a, use_bias=False, keras_nd=3)
             st = _stats(ctx, c1.out, blk_mode)
             bn_b = BNLayer(ctx, base + "_x2_bn", growth * 4, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x2_scale", True)
             _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (3, 3, 3), pad=(1, 1, 1), bn=bn_b, use_bias=False,
                       out=buf.slab(c, growth), keras_nd=3, halo=hl, producer=c1)
-            _stats(ctx, buf.slab(c, growth), blk_mode)
+            seg_stats[0] = _stats(ctx, buf.slab(c, growth), blk_mode)
             c += growth
         return c
 
@@ -168,6 +181,9 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
         nb_filter = dense_block(stage, nb_layers[bi], buf, nb_filter)
         base = "3dconv%d_blk" % stage
         bn_t = BNLayer(ctx, base + "_bn", nb_filter, EPS_DENSE, 0.99, blk_mode, True, base + "_scale", True)
+        if seg_stats[0] is not None:
+            seg_stats[0].then_fold(bn_t)
+        seg_stats[0] = None
         nout = int(nb_filter * compression)
         ct = ConvLayer(ctx, base, buf, nout, (1, 1, 1), bn=bn_t, use_bias=False, keras_nd=3)
         h, w = h // 2, w // 2
@@ -185,6 +201,8 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
             StatsOp(ctx, buf.slab(c0_last + i * growth, growth))
     bn5 = BNLayer(ctx, "3dconv%d_blk_bn" % final_stage, nb_filter, EPS_DENSE, 0.99, "batch", True,
                   "3dconv%d_blk_scale" % final_stage, True)
+    if seg_stats[0] is not None:
+        seg_stats[0].then_fold(bn5)
     ups = [(0, 1, 1), (0, 1, 1), (0, 1, 1), (1, 1, 1), (1, 1, 1)]   # reference (2,2,1)x3 then (2,2,2)x2 over (H,W,D)
     filt = [504 if nb_layers == (3, 4, 12, 8) else nb_filter, 224, 192, 96, 64]
     cur, cur_bn = buf, bn5

@@ -385,6 +385,14 @@ def bn_stats_finalize(partial, slots, M, C, shift, mean, var, fold=None):
                                          stream()), "hdu_bn_stats_finalize")
 
 
+def bn_stats_finalize_fold_next(partial, slots, M, Cseg, seg_c0, C_all, mean_all, var_all, fold):
+    """finalize the segment's epilogue statistics and fold the next BN over [0, C_all) in one launch (fold as above)"""
+    g, be, eps, sg, sb, a, b, r, mm, mv, mom = fold
+    check(_l.get().hdu_bn_stats_finalize_fold_next(fptr(partial), slots, M, Cseg, seg_c0, C_all, fptr(mean_all), fptr(var_all),
+                                                   fptr(g), fptr(be), eps, fptr(sg), fptr(sb), fptr(a), fptr(b), fptr(r),
+                                                   fptr(mm), fptr(mv), mom, stream()), "hdu_bn_stats_finalize_fold_next")
+
+
 def colsum(x, out, ws):
     check(_l.get().hdu_colsum(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(out), ws.ptr, ws.nbytes, stream()), "hdu_colsum")
 

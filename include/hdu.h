@@ -313,6 +313,15 @@ int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M, int C, con
                           const float* gamma, const float* beta, float eps, const float* sgamma, const float* sbeta,
                           float* a, float* b, float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream);
 
+/* hdu_bn_stats_finalize of a slab SEGMENT (channels [seg_c0, seg_c0 + Cseg) of the moment arrays mean_all / var_all; the
+ * epilogue's shift is mean_all + seg_c0 itself) followed by hdu_bn_fold of the NEXT BN over the whole slab [0, C_all) --
+ * layer l+1's first BatchNormalization of a dense block (denseunet.py:229-262) reads the concatenation that layer l's
+ * 3x3 conv has just extended.  One launch; results identical to the two separate calls. */
+int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, int Cseg, int seg_c0, int C_all,
+                                    float* mean_all, float* var_all, const float* gamma, const float* beta, float eps,
+                                    const float* sgamma, const float* sbeta, float* a, float* b, float* rstd,
+                                    float* mov_mean, float* mov_var, float momentum, void* stream);
+
 /* sync-BN over the depth shards of one volume: buf[0:C] = n_local*mean, buf[C:2C] = n_local*(var + mean^2) (the caller
  * all-reduces buf over the ranks), then mean = buf[0:C]/n_global, var = buf[C:2C]/n_global - mean^2 (clamped at 0) */
 int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, float* buf, void* stream);

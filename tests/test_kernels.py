@@ -234,6 +234,36 @@ def test_conv_epilogue_statistics(hdu, cs, dtype):
         assert float((u - v).abs().max()) <= tol, (nme, float((u - v).abs().max()))
 
 
+def test_bn_stats_finalize_fold_next(hdu):
+    """hdu_bn_stats_finalize_fold_next == hdu_bn_stats_finalize on the slab segment, then hdu_bn_fold of the next BN over
+    the whole slab (exact: same arithmetic, deterministic inputs)"""
+    ops = ops_mod()
+    dev_ = ops.device()
+    C_all, c0, Cseg, slots, M = 77, 48, 24, 5, 1000          # (the slab has 5 more channels after the segment's BN range)
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float32)
+    partial = (rn(slots, 2, Cseg).abs() * 50).to(dev_).reshape(-1)
+    mean0, var0 = rn(C_all + 5), rn(C_all + 5).abs() + 0.1
+    gamma, beta, sg, sb = (rn(C_all) * 0.2 + 1.0).to(dev_), rn(C_all).to(dev_), (rn(C_all) * 0.2 + 1.0).to(dev_), rn(C_all).to(dev_)
+    outs = []
+    for fused in (True, False):
+        mean, var = mean0.clone().to(dev_), var0.clone().to(dev_)
+        a, b, r = (torch.zeros(C_all, device=dev_) for _ in range(3))
+        mm, mv = torch.full((C_all,), 0.5, device=dev_), torch.full((C_all,), 2.0, device=dev_)
+        fold = (gamma, beta, 1.1e-5, sg, sb, a, b, r, mm, mv, 0.99)
+        if fused:
+            ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, c0, C_all, mean[:C_all], var[:C_all], fold)
+        else:
+            ops.bn_stats_finalize(partial, slots, M, Cseg, mean[c0:c0 + Cseg], mean[c0:c0 + Cseg], var[c0:c0 + Cseg])
+            ops.bn_fold(C_all, mean[:C_all], var[:C_all], gamma, beta, 1.1e-5, sg, sb, a, b, r, mm, mv, 0.99)
+        outs.append([t.cpu() for t in (mean, var, a, b, r, mm, mv)])
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert not torch.equal(outs[0][0][c0:c0 + Cseg], mean0[c0:c0 + Cseg]) and torch.equal(outs[0][0][C_all:], mean0[C_all:])
+    with pytest.raises(hdu.lib.HduError):
+        ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, C_all - 3, C_all, mean, var, fold)
+
+
 def test_conv_wgrad_batched_plan(hdu):
     """hdu_wgrad_plan_*: ONE launch per kernel family over many layers == hdu_conv_wgrad per layer (bf16,
     materialised inputs: every CONV_CASE without prologue / skip, plus extra 1x1 and 3x3 shapes)"""

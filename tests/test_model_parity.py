@@ -282,3 +282,30 @@ def test_bn_in_producer_epilogue_equals_materialize_pass(emu_lib, monkeypatch, k
     assert float(np.abs(p1 - p0).max()) <= 1e-5 * max(1.0, float(np.abs(p0).max()))
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     assert float((g1 - g0).norm() / g0.norm()) <= 1e-4
+
+
+@pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 2, 64, None), ("hybrid", "3dpart", 1, 32, 8)])
+def test_finalize_folds_next_bn_equals_two_launches(emu_lib, monkeypatch, kind, variant, b, size, cols):
+    """hdu_bn_stats_finalize_fold_next (the finalize launch of a dense layer's epilogue statistics also folds the next
+    layer's first BN over the whole slab) == finalize + bn_fold as two launches (HDU_FOLD_NEXT=0): same loss, logits,
+    gradients, weights and moving statistics after the second (primed) training step."""
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("HDU_FOLD_NEXT", on)
+        m = U.build_pair(kind, variant, b, size, cols, "f32", NB2D, NB3D, odtype=torch.float32)[0]
+        m.ctx.dropout_enabled = False
+        linked = [s for s in m.ctx.stats_sinks if s.fold_next is not None]
+        assert (len(linked) >= 4) == (on == "1")
+        m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True),
+                  loss=[U.pkg("loss").weighted_crossentropy if kind != "2d" else U.pkg("loss").weighted_crossentropy_2ddense])
+        x, y = U.synthetic_batch(kind, b, size, cols)
+        m.train_on_batch(x, y)
+        x2, y2 = U.synthetic_batch(kind, b, size, cols, seed=77)
+        loss = m.train_on_batch(x2, y2)
+        res.append((loss, m._download_logits().cpu().numpy(), m.ctx.G[:m.ctx.n_trainable].clone(), m.ctx.P.clone()))
+    (l1, z1, g1, p1), (l0, z0, g0, p0) = res
+    # (same arithmetic; the epilogue statistics themselves are float atomics, so two runs agree to roundoff only)
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    assert float(np.abs(z1 - z0).max()) <= 1e-4 * max(1.0, float(np.abs(z0).max()))
+    assert float((g1 - g0).norm() / g0.norm()) <= 2e-3
+    assert float((p1 - p0).abs().max()) <= 1e-5
