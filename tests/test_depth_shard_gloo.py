@@ -28,7 +28,12 @@ def test_depth_sharded_hybrid_world2_gloo(emu_lib, net, port):
     3D net with halo exchange / sync-BN, the HFF add + `fianl_conv` with a halo, loss.py's slices 1:7 split over the
     ranks; the sharded training step reproduces the unsharded one (logits, loss, all-reduced gradient, weights, moving
     statistics).  end2end also returns the stem's halo gradients (stride-2 7x7x7 data gradient) to the 2D branch."""
-    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net)
+    # HDU_SPLITK=1 (never split the K loops): the library picks the split count from the launch's tile count, which differs
+    # between the half-volume shards and the whole volume; the different float32 summation order alone moves the hybrid's
+    # logits (250 x logits2d feed the 3D stem) by 3e-4 of max|logit| -- above this test's 2e-4 gate, which is about the
+    # sharding logic.  (Measured: 2.97e-4 with the default splits, pass without; split-K itself: tests/test_kernels.py.)
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net,
+               HDU_SPLITK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)
