@@ -139,12 +139,27 @@ def instrumented_step(m):
         return f
 
     ops.conv_fprop, ops.conv_wgrad = wrap(orig_f, 0), wrap(orig_w, 1)
-    batched = ctx.wgrad_plan is not None
+    plan = ctx.wgrad_plan
+    if plan is not None:
+        # the deferred filter gradients stay batched (what the timed step runs): one event pair per kernel family, its
+        # algorithmic FLOPs = the sum over the layers of that launch
+        orig_run = plan.run
+
+        def timed_plan_run():
+            def around(variant, launch):
+                ds = plan.descs[variant]
+                Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
+                e0, e1 = Ev(enable_timing=True), Ev(enable_timing=True)
+                e0.record()
+                launch()
+                e1.record()
+                name = ops.conv_kernel_name(ds[0], 1).replace("_kernel<", "_batched_kernel<")
+                recs.append((name, sum(flops(d, 1) for d in ds), e0, e1, -len(ds), (0, 0, 0)))
+            orig_run(around)
+        plan.run = timed_plan_run
     try:
         g = m._graph
         m._graph = None
-        if batched:
-            ctx.set_batch_wgrad(False)     # per-layer filter-gradient launches so that each one can be timed
         # this extra step runs on rank 0 ONLY: it must not enter the gradient all-reduce (the other ranks are already
         # waiting in the final barrier)
         dp = (m._allreduce, m._allreduce_async, m._buckets)
@@ -154,8 +169,8 @@ def instrumented_step(m):
         finally:
             m._graph = g
             m._allreduce, m._allreduce_async, m._buckets = dp
-            if batched:
-                ctx.set_batch_wgrad(True)
+            if plan is not None:
+                del plan.run                 # back to the class method
         _sync()
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w

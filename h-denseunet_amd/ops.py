@@ -151,6 +151,7 @@ class WgradPlan:
     def __init__(self, target_wgs=0):
         self.target = target_wgs
         self.by_variant = {}
+        self.descs = {}
         self.tables = None
         self.keep = []            # descriptors (and the tensors they point to) must outlive the plan
 
@@ -162,6 +163,7 @@ class WgradPlan:
         check(lib.hdu_wgrad_plan_fill(ctypes.byref(d), fptr(dw), self.target, ctypes.cast(ent, ctypes.c_void_p),
                                       ctypes.byref(variant), ctypes.byref(nblk)), "hdu_wgrad_plan_fill")
         self.by_variant.setdefault(variant.value, []).append((bytes(ent), nblk.value))
+        self.descs.setdefault(variant.value, []).append(d)       # (bench.py: algorithmic FLOPs of a batched launch)
         self.keep.append((d, dw))
         self.tables = None
 
@@ -182,13 +184,19 @@ class WgradPlan:
             self.tables.append((variant, torch.from_numpy(raw).to(device()),
                                 torch.from_numpy(begins.view(np.int32)).to(device()), len(ents), tot))
 
-    def run(self):
+    def run(self, around=None):
+        """around(variant, launch): optional hook that performs the launch itself (bench.py brackets it with events)"""
         if self.tables is None:
             self.finalize()
         lib = _l.get()
         for variant, tab, begins, n, tot in self.tables:
-            check(lib.hdu_wgrad_plan_run(variant, ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(begins.data_ptr()), n,
-                                         tot, stream()), "hdu_wgrad_plan_run")
+            def launch(variant=variant, tab=tab, begins=begins, n=n, tot=tot):
+                check(lib.hdu_wgrad_plan_run(variant, ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(begins.data_ptr()), n,
+                                             tot, stream()), "hdu_wgrad_plan_run")
+            if around is None:
+                launch()
+            else:
+                around(variant, launch)
 
 
 def conv_dgrad_strided(d):
