@@ -26,6 +26,7 @@ struct ConvK {
   // ~30-instruction division sequences per row (measured: 2-3 us of a 10-15 us short-K launch).
   unsigned div_wo_mul, div_wo_shr, div_ho_mul, div_ho_shr, div_do_mul, div_do_shr;
   unsigned div_cin_mul, div_cin_shr, div_kw_mul, div_kw_shr, div_kh_mul, div_kh_shr;   // k -> (tap, channel), tap -> (kd, kh, kw)
+  unsigned x_bytes, w_bytes;   // extents of the input tensor (from x, FAST addressing only) and of the filter, for buffer loads
   unsigned sk_div_mul, sk_div_shr;     // split-K: division by the split count (set at launch)
   int pro_relu, accumulate;
   float drop_scale;           // 1/keep (0 => dropout disabled)

@@ -1034,11 +1034,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   int c, kd, kh, kw, tap_i;
   hdu_k_state(p, k, c, kd, kh, kw, tap_i);
   // filter rows of this lane
-  const T* wrow[B_IT];
+  // operands arrive through buffer resources (hdu_platform.h): 32-bit byte offsets, out-of-range = zeros
+  const hdu_bufsrd xsrd = hdu_make_srd(xp, p.x_bytes);
+  const hdu_bufsrd wsrd = hdu_make_srd(wp, p.w_bytes);
+  int wrow[B_IT];                    // element offset of this lane's filter row, -1 = no such row
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
     const int col = n0 + r0 + j * 32;
-    wrow[j] = (r0 + j * 32 < BN && col < p.Cout) ? wp + (long long)col * p.Ktot : nullptr;
+    wrow[j] = (r0 + j * 32 < BN && col < p.Cout) ? col * p.Ktot : -1;
   }
 
   auto issue_tile = [&](int buf) {
@@ -1051,8 +1054,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const bool ok = kvalid && ((rmask[i] >> tap_i) & 1u);
-        const char* g = ok ? (const char*)(xp + (rpix[i] + toff)) : zero;
-        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+        hdu_bufload_lds16(xsrd, ok ? (unsigned)(rpix[i] + toff) * (unsigned)sizeof(T) : HDU_OOB, As + (i * 32 + wave * 8) * 128);
       }
     } else {
 #pragma unroll
@@ -1069,8 +1071,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
       if (j * 32 + wave * 8 < BN) {   // wave-uniform
-        const char* g = (wrow[j] != nullptr && k < p.Ktot) ? (const char*)(wrow[j] + k) : zero;
-        hdu_glds16(g, Bs + (j * 32 + wave * 8) * 128);
+        hdu_bufload_lds16(wsrd, (wrow[j] >= 0 && k < p.Ktot) ? (unsigned)(wrow[j] + k) * (unsigned)sizeof(T) : HDU_OOB,
+                          Bs + (j * 32 + wave * 8) * 128);
       }
     }
   };
@@ -1281,11 +1283,14 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   int k = kt_begin * BK + kcl * CH;
   int c, kd, kh, kw, tap_i;
   hdu_k_state(p, k, c, kd, kh, kw, tap_i);
-  const T* wrow[B_IT];
+  // operands arrive through buffer resources (hdu_platform.h): 32-bit byte offsets, out-of-range = zeros
+  const hdu_bufsrd xsrd = hdu_make_srd(xp, p.x_bytes);
+  const hdu_bufsrd wsrd = hdu_make_srd(wp, p.w_bytes);
+  int wrow[B_IT];                    // element offset of this lane's filter row, -1 = no such row
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
     const int col = n0 + r0 + j * 32;
-    wrow[j] = (r0 + j * 32 < BN && col < p.Cout) ? wp + (long long)col * p.Ktot : nullptr;
+    wrow[j] = (r0 + j * 32 < BN && col < p.Cout) ? col * p.Ktot : -1;
   }
 
   auto issue_tile = [&](int slot) {
@@ -1298,8 +1303,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const bool ok = kvalid && ((rmask[i] >> tap_i) & 1u);
-        const char* g = ok ? (const char*)(xp + (rpix[i] + toff)) : zero;
-        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+        hdu_bufload_lds16(xsrd, ok ? (unsigned)(rpix[i] + toff) * (unsigned)sizeof(T) : HDU_OOB, As + (i * 32 + wave * 8) * 128);
       }
     } else {
 #pragma unroll
@@ -1315,8 +1319,8 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-      const char* g = (wrow[j] != nullptr && k < p.Ktot) ? (const char*)(wrow[j] + k) : zero;
-      hdu_glds16(g, Bs + (j * 32 + wave * 8) * 128);
+      hdu_bufload_lds16(wsrd, (wrow[j] >= 0 && k < p.Ktot) ? (unsigned)(wrow[j] + k) * (unsigned)sizeof(T) : HDU_OOB,
+                        Bs + (j * 32 + wave * 8) * 128);
     }
     // advance this lane's k state to the next tile
     k += BK;
@@ -2217,6 +2221,14 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   fastdiv_magic(d->KW, &k->div_kw_mul, &k->div_kw_shr);
   fastdiv_magic(d->KH, &k->div_kh_mul, &k->div_kh_shr);
   k->sk_div_mul = 0u; k->sk_div_shr = 0u;
+  {
+    const long long esz = d->dtype == HDU_BF16 ? 2 : 4;
+    const long long xb = (((long long)d->N * d->Di * d->Hi * d->Wi - 1) * d->ldx + d->Cin) * esz;
+    const long long wb = (long long)d->Cout * k->Ktot * esz;
+    k->x_bytes = xb > 0 && xb < (1ll << 32) ? (unsigned)xb : 0u;
+    if (!wgrad && wb >= (1ll << 32)) return hdu_set_error(HDU_ERR_ARG, "conv: filter larger than 4 GiB");
+    k->w_bytes = (unsigned)wb;
+  }
   k->pro_relu = d->pro_relu; k->accumulate = d->accumulate;
   if (d->drop_keep > 0.f && d->drop_keep < 1.f) {
     k->drop_scale = 1.f / d->drop_keep;
@@ -2259,7 +2271,7 @@ static bool igemm_fast_ok(const ConvK& k) {
   if (g_tuning[HDU_TUNE_NO_FAST]) return false;
   if ((k.ud | k.uh | k.uw) != 0 || k.KD * k.KH * k.KW > 32) return false;
   const long long span = ((long long)k.N * k.De * k.He * k.We + (long long)k.He * k.We * 8) * k.ldx;
-  return span < (1ll << 31);
+  return span < (1ll << 31) && k.x_bytes != 0;     // (x_bytes == 0: the tensor does not fit a 32-bit byte offset)
 }
 
 // Split-K factor of a small-grid launch (ring kernel).  A grid of <= 128 workgroups leaves half the chip idle and each
