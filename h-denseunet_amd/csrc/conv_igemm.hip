@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   // operands arrive through buffer resources (hdu_platform.h): 32-bit byte offsets, out-of-range = zeros
   const hdu_bufsrd xsrd = hdu_make_srd(xp, p.x_bytes);
   const hdu_bufsrd wsrd = hdu_make_srd(wp, p.w_bytes);
+  const bool small_x = p.x_bytes != 0u;
   int wrow[B_IT];                    // element offset of this lane's filter row, -1 = no such row
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
@@ -1064,8 +1065,13 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
                         (unsigned)iw < (unsigned)p.We;
         const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
                             : rpix[i] + tapoff;
-        const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
-        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+        if (small_x) {       // the stored tensor fits a 32-bit byte offset: buffer form (wave-uniform branch)
+          hdu_bufload_lds16(xsrd, ok ? ((unsigned)src * (unsigned)p.ldx + (unsigned)c) * (unsigned)sizeof(T) : HDU_OOB,
+                            As + (i * 32 + wave * 8) * 128);
+        } else {
+          const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+          hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+        }
       }
     }
 #pragma unroll
@@ -1286,6 +1292,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   // operands arrive through buffer resources (hdu_platform.h): 32-bit byte offsets, out-of-range = zeros
   const hdu_bufsrd xsrd = hdu_make_srd(xp, p.x_bytes);
   const hdu_bufsrd wsrd = hdu_make_srd(wp, p.w_bytes);
+  const bool small_x = p.x_bytes != 0u;
   int wrow[B_IT];                    // element offset of this lane's filter row, -1 = no such row
 #pragma unroll
   for (int j = 0; j < B_IT; ++j) {
@@ -1313,8 +1320,13 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
                         (unsigned)iw < (unsigned)p.We;
         const int src = ups ? ((rn[i] * p.Di + (id >> p.ud)) * p.Hi + (ih >> p.uh)) * p.Wi + (iw >> p.uw)
                             : rpix[i] + tapoff;
-        const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
-        hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+        if (small_x) {       // the stored tensor fits a 32-bit byte offset: buffer form (wave-uniform branch)
+          hdu_bufload_lds16(xsrd, ok ? ((unsigned)src * (unsigned)p.ldx + (unsigned)c) * (unsigned)sizeof(T) : HDU_OOB,
+                            As + (i * 32 + wave * 8) * 128);
+        } else {
+          const char* g = ok ? (const char*)(xp + (long long)src * p.ldx + c) : zero;
+          hdu_glds16(g, As + (i * 32 + wave * 8) * 128);
+        }
       }
     }
 #pragma unroll
