@@ -2238,6 +2238,7 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
     const long long xb = (((long long)d->N * d->Di * d->Hi * d->Wi - 1) * d->ldx + d->Cin) * esz;
     const long long wb = (long long)d->Cout * k->Ktot * esz;
     k->x_bytes = xb > 0 && xb < (1ll << 32) ? (unsigned)xb : 0u;
+    if (g_tuning[HDU_TUNE_DEBUG] & 16) k->x_bytes = 0u;      // tests: take the >= 4 GiB path (64-bit pointers, zero page)
     if (!wgrad && wb >= (1ll << 32)) return hdu_set_error(HDU_ERR_ARG, "conv: filter larger than 4 GiB");
     k->w_bytes = (unsigned)wb;
   }

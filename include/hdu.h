@@ -46,7 +46,8 @@ int hdu_abi_version(void);
 #define HDU_TUNE_HALO_TARGET_WGS 7    /* workgroups a halo-tile filter-gradient launch aims for */
 #define HDU_TUNE_MAX_BN 6            /* widest N tile the dispatcher may pick (default 128) */
 #define HDU_TUNE_NO_FAST 5           /* 1 = disable the bitmask/32-bit-offset addressing path (A/B) */
-#define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!) */
+#define HDU_TUNE_DEBUG 4             /* developer experiments: bit0 skip operand DMA, bit1 skip MFMA (wrong results!);
+                                        bit4 (16): treat every input tensor as >= 4 GiB (64-bit pointer path; tests) */
 #define HDU_TUNE_XCD_SWIZZLE 3       /* bit0 = XCD-aware tile order in the implicit GEMM (default on) */
 #define HDU_TUNE_RED_WGS 11          /* workgroups a per-channel reduction aims for (default 512) */
 #define HDU_TUNE_ROW_WGS 12          /* workgroups an element-wise row kernel aims for (default 2048) */

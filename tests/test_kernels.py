@@ -164,6 +164,28 @@ def test_conv_fprop(hdu, cs, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES
+                                if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "stem7x7s2")])
+def test_conv_fprop_large_tensor_path(hdu, cs, dtype):
+    """input tensors of 4 GiB and more cannot be addressed by the 32-bit byte offsets of the buffer-resource DMA: the
+    implicit GEMM then gathers through 64-bit pointers and a zero page.  HDU_TUNE_DEBUG bit 4 forces that path."""
+    import ctypes
+    ops = ops_mod()
+    b = build_conv_case(ops, cs, dtype)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    ya = ops.Act.alloc(N, Do, Ho, Wo, Cout, dtype)
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, None)
+    lib = hdu.lib.get()
+    try:
+        lib.hdu_set_tuning(4, 16)
+        ops.conv_fprop(d)
+    finally:
+        lib.hdu_set_tuning(4, 0)
+    xe = ref_xeff(b["x"], cs["up"], None, None, True, dtype)
+    assert_close(ya.to_torch().cpu(), ref_conv(xe, b["w"], cs["s"], cs["p"], None), dtype, what="fprop, 64-bit pointer path")
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES])
 def test_conv_wgrad(hdu, cs, dtype):
     ops = ops_mod()
