@@ -1,6 +1,6 @@
 """Where does a small implicit-GEMM launch spend its 10-20 us?  (developer tool)
 
-Builds nothing itself: `tools/gpu_r02_m.sh` compiles the same sources with -DHDU_TIMELINE into tools/libhdu_tl.so, whose
+`tools/build_timeline_lib.sh` compiles the same sources with -DHDU_TIMELINE into tools/libhdu_tl.so, whose
 conv_igemm_{dma,ring}_kernel stamp the shader clock at: 0 entry, 1 per-row state done, 2 prologue DMAs issued, 3 first
 tile landed (wait + barrier), 4 K loop done, 5 split-K combine done (or this split leaves), 6 epilogue done; plus the
 100 MHz constant clock at entry / exit.  Prints, per shape: the launch's event duration, the distribution of the
