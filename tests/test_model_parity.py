@@ -284,7 +284,7 @@ def test_bn_in_producer_epilogue_equals_materialize_pass(emu_lib, monkeypatch, k
     assert float((g1 - g0).norm() / g0.norm()) <= 1e-4
 
 
-@pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 2, 64, None), ("hybrid", "3dpart", 1, 32, 8)])
+@pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 2, 64, None)])     # (3D dense blocks: same StatsOp code)
 def test_finalize_folds_next_bn_equals_two_launches(emu_lib, monkeypatch, kind, variant, b, size, cols):
     """hdu_bn_stats_finalize_fold_next (the finalize launch of a dense layer's epilogue statistics also folds the next
     layer's first BN over the whole slab) == finalize + bn_fold as two launches (HDU_FOLD_NEXT=0): same loss, logits,
