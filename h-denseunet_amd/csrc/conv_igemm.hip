@@ -2292,7 +2292,7 @@ static bool igemm_fast_ok(const ConvK& k) {
 // the MFMA work), so the K steps are dealt to S workgroups per tile until ~256 workgroups run, keeping >= 4 K steps per
 // split and S <= 16 (the last arriver reads S-1 partial tiles).  `bytes`: scratch the launch needs.
 // bf16 64-row tiles run a 3-stage ring (<= 72 KB of LDS): two workgroups share a CU, so a split launch aims at 512
-static int ring_wgs_per_cu(int bm, bool bf16) { return (bm == 64 && bf16 && g_tuning[HDU_TUNE_RING_STAGES] != 6) ? 2 : 1; }
+static int ring_wgs_per_cu(int bm, bool bf16) { return (bm == 64 && bf16) ? 2 : 1; }
 
 static int choose_splitk(long long nblk, int nk, int bm, int bn, int per_cu, size_t* bytes) {
   *bytes = 0;
@@ -2332,18 +2332,12 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
         grid.z = (unsigned)S;
         fastdiv_magic(S, &kk.sk_div_mul, &kk.sk_div_shr);
       }
-      if constexpr (BM == 64 && sizeof(T) == 2 && NSD == 6) {
-        // 64-row bf16 tiles: THREE stages (<= 72 KB) so that two workgroups share a CU and the prologue issues 2 tiles,
-        // not 5, before the first MFMA (measured r02 call P: 3dpart 11.12 -> 10.68 ms with the 512-workgroup split
-        // target, 2D 21.62 -> 21.57; 4 stages in between).  HDU_TUNE_RING_STAGES = 6 restores the deep ring (A/B).
-        if (g_tuning[HDU_TUNE_RING_STAGES] != 6) {
-          if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3, true>), grid, dim3(256), 0, s, kk);
-          else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, 3, false>), grid, dim3(256), 0, s, kk);
-          return;
-        }
-      }
-      if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, true>), grid, dim3(256), 0, s, kk);
-      else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSD, false>), grid, dim3(256), 0, s, kk);
+      // 64-row bf16 tiles: THREE stages (<= 72 KB) so that two workgroups share a CU and the prologue issues 2 tiles,
+      // not 5, before the first MFMA (measured r02 calls P / Q against the 6-stage ring: 3dpart 11.09 -> 10.70 ms with
+      // the 512-workgroup split target, end2end 17.23 -> 16.81, 2D 21.62 -> 21.57; 4 stages in between)
+      constexpr int NSR = (BM == 64 && sizeof(T) == 2 && NSD == 6) ? 3 : NSD;
+      if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, true>), grid, dim3(256), 0, s, kk);
+      else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, false>), grid, dim3(256), 0, s, kk);
     } else {
       if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, false>), grid, dim3(256), 0, s, k);

@@ -167,8 +167,6 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(0, int(os.environ["HDU_DMA_STAGES"]))
     if "HDU_SPLITK" in os.environ:
         lib.hdu_set_tuning(13, int(os.environ["HDU_SPLITK"]))
-    if "HDU_RING_STAGES" in os.environ:
-        lib.hdu_set_tuning(19, int(os.environ["HDU_RING_STAGES"]))
     if "HDU_BM64_MAX_M" in os.environ:
         lib.hdu_set_tuning(18, int(os.environ["HDU_BM64_MAX_M"]))
     if "HDU_SPLITK_TARGET" in os.environ:

@@ -59,7 +59,6 @@ int hdu_abi_version(void);
 #define HDU_TUNE_SPLITK_TARGET 16     /* workgroups a split-K launch aims for (default 256 per co-resident workgroup) */
 #define HDU_TUNE_SPLITK_MIN_STEPS 17  /* K steps every split keeps at least (default 4) */
 #define HDU_TUNE_HALO_MIN_TILES 15   /* the halo-tile forward kernel needs this many 4x32-pixel tiles (default 128) */
-#define HDU_TUNE_RING_STAGES 19      /* 6 = deep LDS ring for 64-row bf16 tiles too (A/B); default: 3 stages, 2 workgroups / CU */
 #define HDU_TUNE_RING_MIN_K 14       /* small grids use the deep LDS ring when Ktot > this (default 0: always) */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
 int hdu_set_tuning(int key, int value);
