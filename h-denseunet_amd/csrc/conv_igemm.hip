@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 // NS-stage ring variant: tiles t+1 .. t+NS-1 stay in flight while tile t is multiplied.  Per iteration: counted
 // vmcnt (this wave's DMAs of tile t have landed) -> ONE raw barrier (everyone's have; everyone finished reading the
 // slot about to be refilled) -> issue tile t+NS-1 -> MFMAs on tile t.  Every wave issues exactly A_IT + B_IT DMAs
-// per tile (invalid rows fetch the zero page) so the vmcnt immediate is uniform.  Used for small grids (< 1
+// per tile (invalid rows read out of range = zeros, or the zero page) so the vmcnt immediate is uniform.  Used for small grids (< 1
 // workgroup per CU), where latency rather than occupancy limits the K loop and one workgroup may take the LDS.
 // split-K meeting point of the ring kernel (hdu_platform.h: hdu_store_wt16 / hdu_acquire_agent).  Every split stores its
 // accumulator fragments lane-linear ([wave][fragment][lane] x 16 B: one coalesced 1 KiB store per fragment and wave),
