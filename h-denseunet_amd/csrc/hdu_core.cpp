@@ -33,4 +33,5 @@ extern "C" const char* hdu_backend(void) {
   return "hip-gfx950";
 #endif
 }
-extern "C" int hdu_abi_version(void) { return 1; }
+extern "C" int hdu_abi_version(void) { return HDU_ABI_VERSION; }
+extern "C" size_t hdu_sizeof_conv_desc(void) { return sizeof(hdu_conv_desc); }

@@ -72,6 +72,7 @@ _SIGS = {
     "hdu_last_error": (ctypes.c_char_p, []),
     "hdu_backend": (ctypes.c_char_p, []),
     "hdu_abi_version": (c_int, []),
+    "hdu_sizeof_conv_desc": (c_sz, []),
     "hdu_set_tuning": (c_int, [c_int, c_int]),
     "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_bn_bwd_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -141,6 +142,9 @@ class HduError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3        # include/hdu.h HDU_ABI_VERSION
+
+
 def product_library_path():
     return os.path.join(_HERE, "libhdu.so")
 
@@ -158,6 +162,12 @@ def _bind(path):
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    # a library built from other sources than this binding (stale .so after a pull) must not be driven through structs
+    # of a different layout
+    if lib.hdu_abi_version() != ABI_VERSION or lib.hdu_sizeof_conv_desc() != ctypes.sizeof(ConvDesc):
+        raise HduError("%s has ABI version %d / hdu_conv_desc of %d bytes, this binding expects %d / %d -- rebuild it "
+                       "(python -c 'import __graft_entry__ as g; g.build()')" %
+                       (path, lib.hdu_abi_version(), lib.hdu_sizeof_conv_desc(), ABI_VERSION, ctypes.sizeof(ConvDesc)))
     return lib
 
 

@@ -40,7 +40,12 @@ extern "C" {
 const char* hdu_last_error(void);
 /* "hip-gfx950" for the product library; "emu-x86" for the CPU test build of the same sources. */
 const char* hdu_backend(void);
+/* Layout version of the structs in this header (hdu_conv_desc, hdu_fold_entry, hdu_aug_sample, hdu_prep_entry) and of the
+ * entry-point set.  A binding compares hdu_abi_version() and hdu_sizeof_conv_desc() with what it was written against and
+ * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*. */
+#define HDU_ABI_VERSION 3
 int hdu_abi_version(void);
+size_t hdu_sizeof_conv_desc(void);
 /* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES: 2 = two LDS stages, deep ring for small grids (default); 6 = deep ring everywhere */
 #define HDU_TUNE_DMA_STAGES 0
 #define HDU_TUNE_HALO_TARGET_WGS 7    /* workgroups a halo-tile filter-gradient launch aims for */

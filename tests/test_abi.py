@@ -58,3 +58,18 @@ def test_product_library_refuses_cpu_storage():
             ops.device()
     finally:
         lib.use_emulator_for_tests()
+
+
+def test_binding_refuses_a_library_of_another_abi(monkeypatch):
+    """hdu_abi_version() / hdu_sizeof_conv_desc() must match the ctypes mirror: a stale libhdu.so (built before a struct
+    gained a field) is refused at load time instead of being driven through a descriptor of another layout"""
+    import importlib
+    lib = importlib.import_module("h-denseunet_amd.lib")
+    so = ctypes.CDLL(lib.emulator_library_path())
+    so.hdu_sizeof_conv_desc.restype = ctypes.c_size_t
+    assert so.hdu_abi_version() == lib.ABI_VERSION and so.hdu_sizeof_conv_desc() == ctypes.sizeof(lib.ConvDesc)
+    hdr = open(os.path.join(ROOT, "include", "hdu.h")).read()
+    assert int(re.search(r"#define HDU_ABI_VERSION (\d+)", hdr).group(1)) == lib.ABI_VERSION
+    monkeypatch.setattr(lib, "ABI_VERSION", lib.ABI_VERSION + 1)
+    with pytest.raises(lib.HduError, match="rebuild"):
+        lib._bind(lib.emulator_library_path())
