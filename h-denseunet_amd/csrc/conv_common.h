@@ -25,6 +25,7 @@ struct ConvK {
   // divisor 1).  Filled on the host (fill_convk); the per-row state of a tile costs a few VALU ops instead of three
   // ~30-instruction division sequences per row (measured: 2-3 us of a 10-15 us short-K launch).
   unsigned div_wo_mul, div_wo_shr, div_ho_mul, div_ho_shr, div_do_mul, div_do_shr;
+  unsigned spread_h, spread_d;   // sum_{q<KH} 2^(q*KW), sum_{q<KD} 2^(q*KH*KW) when KD*KH*KW <= 32 (FAST tap masks)
   unsigned div_cin_mul, div_cin_shr, div_kw_mul, div_kw_shr, div_kh_mul, div_kh_shr;   // k -> (tap, channel), tap -> (kd, kh, kw)
   unsigned x_bytes, w_bytes;   // extents of the input tensor (from x, FAST addressing only) and of the filter, for buffer loads
   unsigned sk_div_mul, sk_div_shr;     // split-K: division by the split count (set at launch)
@@ -67,6 +68,11 @@ __device__ __forceinline__ void hdu_k_state(const ConvK& p, int k, int& c, int& 
   kd = (int)d;
 }
 
+// bits [lo, hi) of a 32-bit word, 0 <= lo < hi <= 32
+__device__ __forceinline__ unsigned hdu_bit_range(int lo, int hi) {
+  return (hi >= 32 ? 0xffffffffu : (1u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+
 // taps q in [0, K) of one axis whose input coordinate i0 + q lies inside [0, E): a contiguous bit range (K <= 32)
 __device__ __forceinline__ unsigned hdu_tap_range_mask(int i0, int K, int E) {
   const int lo = i0 < 0 ? -i0 : 0;
@@ -97,13 +103,16 @@ __device__ __forceinline__ void hdu_row_state(const ConvK& p, unsigned m, bool p
     riw = (int)ow * p.sw - p.pw;
     rpix = ((rn * p.De + rid) * p.He + rih) * p.We + riw;
     if (FAST) {
+      // tap-validity mask without loops: the valid taps of an axis are a contiguous range, so "one copy of the inner
+      // mask per valid outer tap" is a multiplication by the outer range's bits of the spread constant
+      // sum_q 2^(q * inner_taps) (from the host); the copies do not overlap and at most 32 taps exist: no carries
       const unsigned mw = hdu_tap_range_mask(riw, p.KW, p.We);
-      const unsigned mh = hdu_tap_range_mask(rih, p.KH, p.He);
-      const unsigned md = hdu_tap_range_mask(rid, p.KD, p.De);
-      unsigned mhw = 0u, mall = 0u;
-      for (int q = 0; q < p.KH; ++q) mhw |= ((mh >> q) & 1u ? mw : 0u) << (q * p.KW);
-      for (int q = 0; q < p.KD; ++q) mall |= ((md >> q) & 1u ? mhw : 0u) << (q * p.KH * p.KW);
-      rmask = mall;
+      const int lo_h = rih < 0 ? -rih : 0, hi_h = p.He - rih < p.KH ? p.He - rih : p.KH;
+      const int lo_d = rid < 0 ? -rid : 0, hi_d = p.De - rid < p.KD ? p.De - rid : p.KD;
+      const unsigned sh = hi_h > lo_h ? p.spread_h & hdu_bit_range(lo_h * p.KW, hi_h * p.KW) : 0u;
+      const int thw = p.KH * p.KW;
+      const unsigned sd = hi_d > lo_d ? p.spread_d & hdu_bit_range(lo_d * thw, hi_d * thw) : 0u;
+      rmask = mw * sh * sd;
       rpix *= (int)p.ldx;                               // element offset of tap (0,0,0), channel 0
     }
   } else {

@@ -2229,6 +2229,11 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   fastdiv_magic(d->Wo, &k->div_wo_mul, &k->div_wo_shr);
   fastdiv_magic(d->Ho, &k->div_ho_mul, &k->div_ho_shr);
   fastdiv_magic(d->Do, &k->div_do_mul, &k->div_do_shr);
+  k->spread_h = k->spread_d = 0u;
+  if (d->KD * d->KH * d->KW <= 32) {
+    for (int q = 0; q < d->KH; ++q) k->spread_h |= 1u << (q * d->KW);
+    for (int q = 0; q < d->KD; ++q) k->spread_d |= 1u << (q * d->KH * d->KW);
+  }
   fastdiv_magic(d->Cin, &k->div_cin_mul, &k->div_cin_shr);
   fastdiv_magic(d->KW, &k->div_kw_mul, &k->div_kw_shr);
   fastdiv_magic(d->KH, &k->div_kh_mul, &k->div_kh_shr);

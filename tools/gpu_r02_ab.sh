@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-2 GPU call AB: loop-free tap masks in the row state -- conv kernel tests + same-box A/B
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+timeout 100 python -m pytest tests/test_kernels.py -m gpu -x -q -k "conv_fprop or dgrad or splitk" > gpurun_out/ab_kernels.log 2>&1; tail -1 gpurun_out/ab_kernels.log
+run() { echo "== $1 / $2" ; timeout 100 python bench.py --config $2 --steps 12 --warmup 3 --no-cpu-baseline --no-roofline --extras none 2>&1 | grep -o '"ms_per_step": [0-9.]*' ; }
+cp h-denseunet_amd/libhdu.so /tmp/libhdu_new.so
+( run new 2d; run new 3dpart; run new end2end
+  cp tools/libhdu_prev.so h-denseunet_amd/libhdu.so
+  run prev 2d; run prev 3dpart; run prev end2end
+  cp /tmp/libhdu_new.so h-denseunet_amd/libhdu.so
+  run new 2d ) > gpurun_out/ab_ab.log 2>&1
+cat gpurun_out/ab_ab.log
