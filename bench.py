@@ -7,9 +7,11 @@
 BASELINE.json's metric is "CT slices/sec fwd+bwd (2D 512^2 & 3D 224x224x12)".  The JSON line's top-level `value` is the
 2D half on the configuration the metric is quoted on (configs[1]: 2D DenseUNet-161 training step, batch 8 x 512 x 512,
 bf16 storage / f32 accumulate, dropout ON, one hipGraph per step); the 3D half -- `denseunet_3d` (configs[2]) and
-`dense_rnn_net` end2end (configs[3]) at 224 x 224 x 12 -- and the float32 parity-mode 2D step are timed by the SAME
-function in the same process and reported under `config.extra_workloads`, each with its own value / ms_per_step /
-roofline.  Under N>1 every rank runs the same per-GPU batch (weak scaling) and gradients are summed with one flat RCCL
+`dense_rnn_net` end2end (configs[3]) at 224 x 224 x 12 --, the 512 x 512 x 64 per-GPU shard of configs[4] (single GPU
+only) and the float32 parity-mode 2D step are timed by the SAME function in the same process and reported, compacted,
+under `config.extra_workloads` (value / ms_per_step / roofline fraction each).  The line stays under 6 KB (the driver
+keeps 8 KB of stdout); the per-kernel tables go to gpurun_out/bench_details.json (stderr under HDU_BENCH_VERBOSE).
+Under N>1 every rank runs the same per-GPU batch (weak scaling) and gradients are summed with one flat RCCL
 all-reduce.  Inputs and labels are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -29,7 +31,8 @@ sys.path.insert(0, ROOT)
 # conv FLOPs (2*MAC) per slice, fwd + dgrad + wgrad (stem dgrad skipped)
 TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3d": 121.3}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
-PROFILE_ROUND = "r02"
+PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+PROFILE_ROUND = "r03"
 
 # HDU_BENCH_DRYRUN=1 (tests/test_bench_flow_gloo.py only): the same control flow on CPU -- x86 emulator build of the
 # kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
@@ -127,6 +130,18 @@ def instrumented_step(m):
         m_out = d.N * d.Do * d.Ho * d.Wo
         return 2.0 * m_out * d.Cout * d.KD * d.KH * d.KW * d.Cin * scale.get(d.w, 1.0)
 
+    def alg_bytes(d, op):
+        """algorithmic HBM bytes of one conv launch: every stored input element and every filter
+        element read once, every output element written once (and read once more in accumulate mode); the filter
+        gradient reads x and dy once and writes the float32 gradient once"""
+        esz = 2 if d.dtype == 0 else 4
+        m_in = d.N * d.Di * d.Hi * d.Wi
+        m_out = d.N * d.Do * d.Ho * d.Wo
+        taps = d.KD * d.KH * d.KW
+        if op == 1:
+            return (m_in * d.Cin + m_out * d.Cout) * esz + d.Cout * taps * d.Cin * 4.0
+        return (m_in * d.Cin + d.Cout * taps * d.Cin) * esz + m_out * d.Cout * esz * (2 if d.accumulate else 1)
+
     def wrap(fn, op):
         def f(d, *a):
             Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
@@ -135,7 +150,7 @@ def instrumented_step(m):
             fn(d, *a)
             e1.record()
             recs.append((ops.conv_kernel_name(d, op), flops(d, op), e0, e1, d.N * d.Do * d.Ho * d.Wo,
-                         (d.Cout, d.KD * d.KH * d.KW * d.Cin, d.KD * d.KH * d.KW)))
+                         (d.Cout, d.KD * d.KH * d.KW * d.Cin, d.KD * d.KH * d.KW), alg_bytes(d, op)))
         return f
 
     ops.conv_fprop, ops.conv_wgrad = wrap(orig_f, 0), wrap(orig_w, 1)
@@ -154,7 +169,7 @@ def instrumented_step(m):
                 launch()
                 e1.record()
                 name = ops.conv_kernel_name(ds[0], 1).replace("_kernel<", "_batched_kernel<")
-                recs.append((name, sum(flops(d, 1) for d in ds), e0, e1, -len(ds), (0, 0, 0)))
+                recs.append((name, sum(flops(d, 1) for d in ds), e0, e1, -len(ds), (0, 0, 0), sum(alg_bytes(d, 1) for d in ds)))
             orig_run(around)
         plan.run = timed_plan_run
     try:
@@ -177,11 +192,12 @@ def instrumented_step(m):
     agg = {}
     bym = {}
     detail = os.environ.get("HDU_BENCH_VERBOSE") == "2"      # one row per GEMM shape (N, K, taps) instead of per M
-    for name, fl, e0, e1, mm, shape in recs:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
+    for name, fl, e0, e1, mm, shape, nbytes in recs:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += fl
+        a[3] += nbytes
         b = bym.setdefault((mm, name + (" N=%d K=%d taps=%d" % shape if detail else "")), [0, 0.0, 0.0])
         b[0] += 1
         b[1] += e0.elapsed_time(e1)
@@ -255,8 +271,38 @@ WORKLOAD_TEXT = {
     "2d": "2D DenseUNet-161 train step, batch %(b)d x %(size)dx%(size)d per GPU (BASELINE configs[1])",
     "3dpart": "denseunet_3d train step, %(size)dx%(size)dx%(cols)d (BASELINE configs[2])",
     "end2end": "dense_rnn_net end2end train step, %(size)dx%(size)dx%(cols)d (BASELINE configs[3])",
-    "shard3d": "3D DenseNet train step on ONE %(size)dx%(size)dx%(gcols)d volume, depth-sharded (BASELINE configs[4] shape family)",
+    "shard3d": "3D DenseNet train step on ONE %(size)dx%(size)dx%(gcols)d volume, depth-sharded over %(world)d rank(s), "
+               "%(cols)d planes each (BASELINE configs[4]: 512^3 over 8 GPUs = 64 planes per GPU)",
 }
+
+DETAILS = {}          # per-workload conv-kernel tables: written to gpurun_out/ (and stderr under HDU_BENCH_VERBOSE), not the JSON line
+
+
+def roofline_record(agg, name, config, dtype):
+    """SURVEY.md section 8(d) / DESIGN.md section 3: the dominant conv kernel's algorithmic FLOPs and algorithmic HBM bytes per
+    launch over its HIP-event launch time.  `bound` is the roof its arithmetic intensity puts it under (ridge = MFMA
+    peak / HBM peak); `achieved` / `peak` / `frac` are in that roof's unit; both fractions are reported."""
+    n, tms, fl, nbytes = agg[name]
+    sec = tms * 1e-3
+    tf, gbs = fl / sec / 1e12, nbytes / sec / 1e9
+    peak_tf = PEAK_TFLOPS[dtype]
+    ai = fl / max(nbytes, 1.0)
+    ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+    hbm_bound = ai < ridge
+    traffic, rnd = pmc_traffic(name, config, dtype)
+    r = {"bound": "hbm" if hbm_bound else "mfma",
+         "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak_tf,
+         "unit": "GB/s" if hbm_bound else "TFLOP/s",
+         "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak_tf), 4),
+         "traffic": traffic, "kernel": name, "launches_per_step": n, "avg_launch_us": round(tms / n * 1e3, 2),
+         "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak_tf, 4),
+         "hbm_gbs_algorithmic": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+         "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+         "algorithmic_bytes_per_launch": int(nbytes / n), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+    if traffic is not None:
+        r["traffic_source"] = "profiles/%s_pmc_{FETCH,WRITE}_SIZE_%s_%s.txt (FETCH x2 + WRITE, per launch)" % (rnd, config, dtype)
+        r["hbm_gbs_counters"] = round(traffic / (sec / n) / 1e9, 1)
+    return r
 
 
 def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline):
@@ -267,10 +313,14 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
     gcols = cols
     if config == "shard3d":
         # ONE volume of `cols` depth planes split over the ranks (strong scaling); every rank builds the same phantom
-        # and keeps its own planes.  No hipGraph: the step contains the neighbour exchanges.
+        # and keeps its own planes.  world > 1: no hipGraph, the step contains the neighbour exchanges; world 1 (the
+        # per-shard shape on one GPU) has no exchange and is captured like every other workload.
         assert cols % (4 * world) == 0, "--cols must be a multiple of 4*world"
         gcols, cols = cols, cols // world
-        use_graph = False
+        if world > 1:
+            use_graph = False
+    if torch.cuda.is_available():
+        torch.cuda.reset_peak_memory_stats()
     m = build(config, dtype, b, size, cols)
     if (world > 1 or os.environ.get("HDU_FORCE_DP") == "1") and config != "shard3d":
         par.attach_data_parallel(m)
@@ -311,29 +361,29 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
     ms = dt / steps * 1e3
     slices_per_step = (b if kind == "2d" else cols) * world   # shard3d: cols is per rank -> the whole volume
     loss = m.loss_value()
+    gflop = TRAIN_GFLOP_PER_SLICE[config] * slices_per_step / world
+    if config == "shard3d":          # SURVEY.md section 8(d) quotes 121.3 GFLOP / slice at 224^2: conv FLOPs scale with the plane area
+        gflop *= (size * size) / (224.0 * 224.0)
     rec = {
-        "workload": WORKLOAD_TEXT[config] % dict(b=b, size=size, cols=cols or 0, gcols=gcols or 0),
+        "workload": WORKLOAD_TEXT[config] % dict(b=b, size=size, cols=cols or 0, gcols=gcols or 0, world=world),
         "value": round(slices_per_step / (ms / 1e3), 2), "unit": "slices/s", "ms_per_step": round(ms, 3),
         "steps": steps, "warmup": warmup, "dtype": dtype, "global_batch_slices": slices_per_step,
         "hipgraph": bool(use_graph), "loss": round(loss, 5),
-        "step_conv_tflops": round(TRAIN_GFLOP_PER_SLICE[config] * slices_per_step / world / ms, 2),
-        "step_frac_of_mfma_peak": round(TRAIN_GFLOP_PER_SLICE[config] * slices_per_step / world / ms / PEAK_TFLOPS[dtype], 4),
+        "step_conv_tflops": round(gflop / ms, 2),
+        "step_frac_of_mfma_peak": round(gflop / ms / PEAK_TFLOPS[dtype], 4),
     }
+    if torch.cuda.is_available():
+        rec["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2.0 ** 30, 2)
     # the instrumented step is rank-0-only and must not enter a collective: the depth-sharded step always does
     # (halo exchange, sync-BN), so it is skipped there when world > 1
     if rank == 0 and roofline and not (config == "shard3d" and world > 1):
         agg = instrumented_step(m)
-        name, (n, tms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
-        ach = fl / (tms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[dtype]
-        traffic, rnd = pmc_traffic(name, config, dtype)
-        rec["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 4), "traffic": traffic,
-                           "traffic_unit": "HBM bytes per launch, PMC (profiles/%s_pmc_*), avg over the layer shapes" % (rnd or PROFILE_ROUND),
-                           "kernel": name, "launches_per_step": n, "avg_launch_ms": round(tms / n, 4),
-                           "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1], 3),
-                                                    "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
-                                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+        name = max(agg.items(), key=lambda kv: kv[1][1])[0]
+        rec["roofline"] = roofline_record(agg, name, config, dtype)
+        DETAILS["%s:%s" % (config, dtype)] = {
+            k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                "alg_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1)}
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     del m
     gc.collect()
     if torch.cuda.is_available():
@@ -341,22 +391,38 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
     return rec
 
 
+def compact(rec):
+    """what the ONE JSON line carries per extra workload (the driver keeps 8 KB of stdout: the whole metric must fit)"""
+    out = {k: rec[k] for k in ("workload", "value", "unit", "ms_per_step", "steps", "dtype", "hipgraph", "global_batch_slices",
+                               "step_frac_of_mfma_peak", "peak_hbm_gib") if k in rec}
+    out["workload"] = rec["workload"][:120]
+    if "roofline" in rec:
+        r = rec["roofline"]
+        out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "mfma_frac",
+                                             "hbm_frac")}
+    if "cpu_baseline" in rec:
+        c = rec["cpu_baseline"]
+        out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="2d", choices=["2d", "3dpart", "end2end", "shard3d"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
-    ap.add_argument("--cols", type=int, default=12)
+    ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", default=None,
                     help="comma list of extra workloads timed after the main one (config[:dtype]); default for the "
-                         "default 2d/bf16 run: 3dpart,end2end,2d:f32; 'none' disables")
+                         "default 2d/bf16 run: 3dpart,end2end,shard3d,2d:f32 (shard3d = the 512x512x64 per-GPU shard of "
+                         "BASELINE configs[4], single GPU only); 'none' disables")
     a = ap.parse_args()
 
     pkg = importlib.import_module("h-denseunet_amd")
@@ -373,24 +439,34 @@ def main():
     if world == 1 and not DRYRUN:
         torch.cuda.set_device(0)
     b = a.batch or (8 if a.config == "2d" else 1)
-    size = a.size or (512 if a.config == "2d" else 224)
-    cols = a.cols if a.config != "2d" else None
+    size = a.size or (512 if a.config in ("2d", "shard3d") else 224)
+    cols = (a.cols or (64 * world if a.config == "shard3d" else 12)) if a.config != "2d" else None
 
     main_rec = run_workload(a.config, a.dtype, b, size, cols, a.steps, a.warmup, rank, world, not a.no_graph,
                             not a.no_roofline)
     extras = a.extras
     if extras is None:
         default_run = a.config == "2d" and a.dtype == "bf16" and a.batch is None and a.size is None
-        extras = "3dpart,end2end,2d:f32" if (default_run and not DRYRUN) else "none"
+        extras = "none"
+        if default_run and not DRYRUN:
+            # the 512x512x64 shard shape runs where a whole 512^3 volume cannot (one GPU); under N > 1 the driver's
+            # weak-scaling run keeps to the data-parallel workloads
+            extras = "3dpart,end2end,shard3d,2d:f32" if world == 1 else "3dpart,end2end,2d:f32"
     extra_recs = []
     if extras != "none":
         for spec in extras.split(","):
             cfg, _, dt = spec.partition(":")
             dt = dt or "bf16"
-            # the 3D half of the metric at the shape BASELINE names; fewer steps for the slow float32 parity mode
-            e_b, e_size, e_cols = (b, size, None) if cfg == "2d" else (1, 32 if DRYRUN else 224, 8 if DRYRUN else 12)
-            e_steps = max(2, min(a.steps, 10 if dt == "bf16" else 3))
-            e_warm = max(1, min(a.warmup, 3 if dt == "bf16" else 1))
+            # the 3D half of the metric at the shape BASELINE names; fewer steps for the slow workloads
+            if cfg == "2d":
+                e_b, e_size, e_cols = b, size, None
+            elif cfg == "shard3d":
+                e_b, e_size, e_cols = 1, 64 if DRYRUN else 512, (8 if DRYRUN else 64) * world
+            else:
+                e_b, e_size, e_cols = 1, 32 if DRYRUN else 224, 8 if DRYRUN else 12
+            cap = {"shard3d": 5}.get(cfg, 30 if dt == "bf16" else 3)
+            e_steps = max(2, min(a.steps, cap))
+            e_warm = max(1, min(a.warmup, 3 if (dt == "bf16" and cfg != "shard3d") else 1))
             extra_recs.append(run_workload(cfg, dt, e_b, e_size, e_cols, e_steps, e_warm, rank, world, not a.no_graph,
                                            not a.no_roofline))
 
@@ -403,12 +479,13 @@ def main():
         "scaling": "strong" if a.config == "shard3d" else "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on" + (" -- CPU DRY RUN, not a measurement" if DRYRUN else ""),
         "config": {"workload": main_rec["workload"], "global_batch_slices": main_rec["global_batch_slices"],
-                   "parallelism": "dp%d" % world, "hipgraph": main_rec["hipgraph"], "loss": main_rec["loss"],
+                   "parallelism": ("depth-shard%d" if a.config == "shard3d" else "dp%d") % world,
+                   "hipgraph": main_rec["hipgraph"], "loss": main_rec["loss"],
                    "step_conv_tflops": main_rec["step_conv_tflops"],
                    "step_frac_of_mfma_peak": main_rec["step_frac_of_mfma_peak"]},
     }
-    if extra_recs:
-        out["config"]["extra_workloads"] = extra_recs
+    if "peak_hbm_gib" in main_rec:
+        out["config"]["peak_hbm_gib"] = main_rec["peak_hbm_gib"]
     if rank == 0:
         if "roofline" in main_rec:
             out["roofline"] = main_rec["roofline"]
@@ -417,7 +494,24 @@ def main():
             for r in extra_recs:
                 if r["workload"].startswith("denseunet_3d"):      # the 3D half beside its own CPU baseline
                     r["cpu_baseline"] = cpu_baseline("3dpart", 224, 12, samples=1)
-        print(json.dumps(out))
+        if extra_recs:
+            out["config"]["extra_workloads"] = [compact(r) for r in extra_recs]
+        line = json.dumps(out)
+        if len(line) > 6000:            # the driver keeps 8 KB of stdout: never let the line outgrow it
+            for e in out["config"].get("extra_workloads", []):
+                e.pop("cpu_baseline", None)
+            line = json.dumps(out)
+        # full per-kernel tables and uncompacted records: scratch file (copied to profiles/ for the judged runs) + stderr
+        detail = {"main": main_rec, "extras": extra_recs, "conv_kernels": DETAILS}
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError:
+            pass
+        if os.environ.get("HDU_BENCH_VERBOSE"):
+            print(json.dumps(detail), file=sys.stderr)
+        print(line)
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     if dist_on:
         torch.distributed.barrier()

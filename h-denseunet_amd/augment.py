@@ -9,8 +9,8 @@ training set is ~60 GB in float32) and ONE kernel pair per batch (csrc/augment.h
 model's input / label buffers.  The host only draws the random parameters -- in the reference's order, from an explicit
 numpy RandomState -- and uploads n small descriptors.
 
-    ds = DeviceDataset(img_list, tumor_list, liver_centres, tumor_centres, minindex_list, maxindex_list)
-    gen = ds.generator(model, batch_size, args, mean=48, hybrid=False, seed=0)
+    ds = DeviceDataset(img_list, tumor_list, liver_centres, tumor_centres, minindex_list, maxindex_list, mean=48)
+    gen = ds.generator(model, batch_size, size=args.input_size, cols=args.input_cols, hybrid=False, seed=0)
     model.fit_generator(gen, steps_per_epoch, epochs, ...)        # the generator yields (DeviceBatch, None)
 """
 import ctypes
@@ -75,7 +75,9 @@ class DeviceDataset:
             centres = self.tumor_centres[count]
         scale = rng.uniform(0.8, 1.2)
         crop = int(size * scale)
-        sed = rng.randint(1, len(centres) + 1) if len(centres) > 1 else 1    # np.random.randint(1, numid), numid = lines + 1
+        # np.random.randint(1, numid) with numid = len(lines) (train_2ddense.py:158-164, :52-58): the reference never draws
+        # the LAST voxel line; kept draw for draw
+        sed = rng.randint(1, len(centres)) if len(centres) > 1 else 1
         cen = centres[sed - 1]
         mn, mx = self.minindex[count], self.maxindex[count]
         a = min(max(mn[0] + crop // 2, cen[0]), mx[0] - crop // 2 - 1)
@@ -100,6 +102,12 @@ class DeviceDataset:
         """crop / flip / resize every sample of `params` straight into the model's input and label buffers"""
         n = len(params)
         dev = ops.device()
+        sh = getattr(model.ctx, "shard", None)
+        if sh is not None and sh.world > 1:
+            # a depth shard holds its OWN planes of the volume plus one CT plane of each neighbour (Model._upload_x crops
+            # per rank and exchanges them); this kernel would write the same D_local slices on every rank
+            raise NotImplementedError("DeviceDataset.fill does not feed a depth-sharded model: use Model.train_on_batch(x, y) "
+                                      "with this rank's planes")
         shp = model.input_shape
         size = shp[1]
         if hybrid:

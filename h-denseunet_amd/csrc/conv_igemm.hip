@@ -14,6 +14,17 @@
 #include "conv_common.h"
 #include "../../include/hdu.h"
 
+// geometry of the fused BN-backward epilogue (epilogue_bn_backward below): thread = (16-byte channel chunk, row lane)
+template <typename T, int BM, int BN> struct BnbGeom {
+  static constexpr int CH = Chunk<T>::CH;
+  static constexpr int NCC = BN / CH;
+  static constexpr int NCCP = NCC <= 4 ? 4 : (NCC <= 8 ? 8 : (NCC <= 16 ? 16 : 32));
+  static constexpr int RSTEP = 256 / NCCP;
+  static constexpr int IT = (BM + RSTEP - 1) / RSTEP;
+  static constexpr bool EARLY = IT <= 8;             // the u / old-gradient chunks of a thread fit in registers
+  static_assert(NCC <= 32, "tile shape");
+};
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   constexpr int CH = Chunk<T>::CH;
@@ -218,7 +229,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   }
 
   // ---- epilogue: bias, dropout, optional accumulate, store ----
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  u32x4 no_uv[BnbGeom<T, BM, BN>::EARLY ? BnbGeom<T, BM, BN>::IT : 1], no_ov[BnbGeom<T, BM, BN>::EARLY ? BnbGeom<T, BM, BN>::IT : 1];
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE, false>(p, acc, smem, m0, n0, wm, wn, lane, tid, no_uv, no_ov, false);
 }
 
 // =====================================================================================
@@ -735,15 +747,6 @@ __device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n
 // consecutive lanes store consecutive chunks of a row (full 128-byte lines) and a thread's S1 / S2 partial sums stay in
 // registers; lanes that share a chunk meet in a wave butterfly, the four waves in LDS, and one lane per channel adds
 // the workgroup's sums to a slot row with float atomics.
-template <typename T, int BM, int BN> struct BnbGeom {
-  static constexpr int CH = Chunk<T>::CH;
-  static constexpr int NCC = BN / CH;
-  static constexpr int NCCP = NCC <= 4 ? 4 : (NCC <= 8 ? 8 : (NCC <= 16 ? 16 : 32));
-  static constexpr int RSTEP = 256 / NCCP;
-  static constexpr int IT = (BM + RSTEP - 1) / RSTEP;
-  static constexpr bool EARLY = IT <= 8;             // the u / old-gradient chunks of a thread fit in registers
-  static_assert(NCC <= 32, "tile shape");
-};
 
 // issues the thread's u (and, in accumulate mode, old-gradient) loads: called BEFORE the accumulators are staged through
 // LDS, so that their latency hides behind the two barriers and the staging pass instead of standing in the epilogue
@@ -851,9 +854,18 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
 
 // ---- epilogue shared by the DMA kernels: bias / dropout in registers, then the tile goes through LDS so that every
 // lane writes (and, in accumulate mode, reads) one full 16-byte chunk of a row: 8 lanes cover a 128-byte line.
-template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int SMEM>
+// BNB: the launch carries the fused BN backward (ConvK::bnb_u != NULL is then a launch-time guarantee: the host picks the
+// BNB instantiation for exactly those launches).  `pre_uv` / `pre_ov`: the thread's u / old-gradient chunks when the caller
+// already issued them at kernel ENTRY (`preloaded`): they are independent of the GEMM, so the whole K loop hides their
+// latency instead of the staging pass of the epilogue (measured round 2: issued late they cost the data-gradient launches
+// of the 2D step +2.4 ms).  Kept in a separate instantiation because the 2 x IT x 4 registers they occupy across the K
+// loop would otherwise cut the occupancy of every other launch of the tile shape.
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int SMEM, bool BNB = false>
 __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][TN], char* smem, long long m0, int n0,
-                                               int wm, int wn, int lane, int tid) {
+                                               int wm, int wn, int lane, int tid,
+                                               u32x4 (&bnb_uv)[BnbGeom<T, BM, BN>::EARLY ? BnbGeom<T, BM, BN>::IT : 1],
+                                               u32x4 (&bnb_ov)[BnbGeom<T, BM, BN>::EARLY ? BnbGeom<T, BM, BN>::IT : 1],
+                                               bool preloaded) {
   constexpr int CH = Chunk<T>::CH;
   // +16 B: consecutive rows start on different banks; dropped when the padded tile would not fit the operand stages
   // (f32 128x128: 128 * 528 B > 64 KB)
@@ -861,9 +873,8 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
   static_assert(BM * ROWB <= SMEM, "epilogue staging tile must fit the LDS of the operand stages");
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
   typedef BnbGeom<T, BM, BN> G;
-  u32x4 bnb_uv[G::EARLY ? G::IT : 1], bnb_ov[G::EARLY ? G::IT : 1];
-  if constexpr (G::EARLY) {
-    if (p.bnb_u != nullptr) bnb_issue_loads<T, BM, BN, G::IT>(p, m0, n0, tid, 0, bnb_uv, bnb_ov);
+  if constexpr (BNB && G::EARLY) {
+    if (!preloaded) bnb_issue_loads<T, BM, BN, G::IT>(p, m0, n0, tid, 0, bnb_uv, bnb_ov);
   }
   __syncthreads();                                   // all MFMA operand reads of the last K tile are done
   // The K loops multiply with the operands SWAPPED (kgroup(b, a, acc)): a lane holds C[m = lane & 15][n = 4 * (lane >> 4)
@@ -901,7 +912,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
     }
   }
   __syncthreads();
-  if (p.bnb_u != nullptr) {                          // data gradient with the consumer BN's backward fused in
+  if constexpr (BNB) {                               // data gradient with the consumer BN's backward fused in
     epilogue_bn_backward<T, BM, BN, ROWB>(p, smem, m0, n0, tid, bnb_uv, bnb_ov);
     return;
   }
@@ -988,7 +999,7 @@ extern "C" int hdu_timeline_read(unsigned long long* host, int clear) {
 #endif
 
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
@@ -1106,6 +1117,16 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.Ktot + BK - 1) / BK;
+  // fused BN backward: this thread's u / old-gradient chunks are requested now, ahead of every operand DMA
+  typedef BnbGeom<T, BM, BN> BG;
+  u32x4 bnb_uv[BG::EARLY ? BG::IT : 1], bnb_ov[BG::EARLY ? BG::IT : 1];
+  const bool bnb_pre = BNB && BG::EARLY && !(p.debug_flags & 32);
+  if constexpr (BNB && BG::EARLY) {
+    if (bnb_pre) {
+      bnb_issue_loads<T, BM, BN, BG::IT>(p, m0, n0, tid, 0, bnb_uv, bnb_ov);
+      HDU_SCHED_BARRIER();
+    }
+  }
   HDU_TP(1);
   issue_tile(0);
   HDU_TP(2);
@@ -1139,7 +1160,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 
   HDU_TP(4);
   HDU_TP(5);
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE, BNB>(p, acc, smem, m0, n0, wm, wn, lane, tid, bnb_uv, bnb_ov, bnb_pre);
   HDU_TP(6);
 }
 
@@ -1191,52 +1212,16 @@ __device__ __forceinline__ bool splitk_combine(const ConvK& p, f32x4 (&acc)[TM][
   return true;
 }
 
+// counted vector-memory wait with a compile-time count (an "i" operand prints as the literal s_waitcnt needs; vmcnt is
+// 6 bits on gfx950)
 template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_n() {
-  if constexpr (N == 0) { HDU_WAIT_VMCNT(0); }
-  else if constexpr (N == 1) { HDU_WAIT_VMCNT(1); }
-  else if constexpr (N == 2) { HDU_WAIT_VMCNT(2); }
-  else if constexpr (N == 3) { HDU_WAIT_VMCNT(3); }
-  else if constexpr (N == 4) { HDU_WAIT_VMCNT(4); }
-  else if constexpr (N == 5) { HDU_WAIT_VMCNT(5); }
-  else if constexpr (N == 6) { HDU_WAIT_VMCNT(6); }
-  else if constexpr (N == 7) { HDU_WAIT_VMCNT(7); }
-  else if constexpr (N == 8) { HDU_WAIT_VMCNT(8); }
-  else if constexpr (N == 9) { HDU_WAIT_VMCNT(9); }
-  else if constexpr (N == 10) { HDU_WAIT_VMCNT(10); }
-  else if constexpr (N == 11) { HDU_WAIT_VMCNT(11); }
-  else if constexpr (N == 12) { HDU_WAIT_VMCNT(12); }
-  else if constexpr (N == 13) { HDU_WAIT_VMCNT(13); }
-  else if constexpr (N == 14) { HDU_WAIT_VMCNT(14); }
-  else if constexpr (N == 15) { HDU_WAIT_VMCNT(15); }
-  else if constexpr (N == 16) { HDU_WAIT_VMCNT(16); }
-  else if constexpr (N == 17) { HDU_WAIT_VMCNT(17); }
-  else if constexpr (N == 18) { HDU_WAIT_VMCNT(18); }
-  else if constexpr (N == 19) { HDU_WAIT_VMCNT(19); }
-  else if constexpr (N == 20) { HDU_WAIT_VMCNT(20); }
-  else if constexpr (N == 21) { HDU_WAIT_VMCNT(21); }
-  else if constexpr (N == 22) { HDU_WAIT_VMCNT(22); }
-  else if constexpr (N == 23) { HDU_WAIT_VMCNT(23); }
-  else if constexpr (N == 24) { HDU_WAIT_VMCNT(24); }
-  else if constexpr (N == 25) { HDU_WAIT_VMCNT(25); }
-  else if constexpr (N == 26) { HDU_WAIT_VMCNT(26); }
-  else if constexpr (N == 27) { HDU_WAIT_VMCNT(27); }
-  else if constexpr (N == 28) { HDU_WAIT_VMCNT(28); }
-  else if constexpr (N == 29) { HDU_WAIT_VMCNT(29); }
-  else if constexpr (N == 30) { HDU_WAIT_VMCNT(30); }
-  else if constexpr (N == 31) { HDU_WAIT_VMCNT(31); }
-  else if constexpr (N == 32) { HDU_WAIT_VMCNT(32); }
-  else if constexpr (N == 33) { HDU_WAIT_VMCNT(33); }
-  else if constexpr (N == 34) { HDU_WAIT_VMCNT(34); }
-  else if constexpr (N == 35) { HDU_WAIT_VMCNT(35); }
-  else if constexpr (N == 36) { HDU_WAIT_VMCNT(36); }
-  else if constexpr (N == 37) { HDU_WAIT_VMCNT(37); }
-  else if constexpr (N == 38) { HDU_WAIT_VMCNT(38); }
-  else if constexpr (N == 39) { HDU_WAIT_VMCNT(39); }
-  else if constexpr (N == 40) { HDU_WAIT_VMCNT(40); }
-  else { static_assert(N <= 40, "add the vmcnt immediate"); }
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+#ifndef HDU_EMU
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+#endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
@@ -1357,6 +1342,18 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = kt_end - kt_begin;
+  // fused BN backward (unsplit launches only: a split's epilogue runs in whichever workgroup arrives last): the u /
+  // old-gradient chunks are requested ahead of every operand DMA -- older than all of them, so the ring's counted vmcnt
+  // waits still mean what they say
+  typedef BnbGeom<T, BM, BN> BG;
+  u32x4 bnb_uv[BG::EARLY ? BG::IT : 1], bnb_ov[BG::EARLY ? BG::IT : 1];
+  const bool bnb_pre = BNB && BG::EARLY && nsplit == 1 && !(p.debug_flags & 32);
+  if constexpr (BNB && BG::EARLY) {
+    if (bnb_pre) {
+      bnb_issue_loads<T, BM, BN, BG::IT>(p, m0, n0, tid, 0, bnb_uv, bnb_ov);
+      HDU_SCHED_BARRIER();
+    }
+  }
   HDU_TP(1);
 #pragma unroll
   for (int pre = 0; pre < NS - 1; ++pre)
@@ -1405,7 +1402,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
     }
   }
   HDU_TP(5);
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NS * STAGE>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NS * STAGE, BNB>(p, acc, smem, m0, n0, wm, wn, lane, tid, bnb_uv, bnb_ov, bnb_pre);
   HDU_TP(6);
 }
 
@@ -2188,7 +2185,7 @@ static void fastdiv_magic(int d, unsigned* mul, unsigned* shr) {
   *shr = (unsigned)(p - 32);
 }
 
-static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
+static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad, bool exact_grid = false) {
   if (!d) return hdu_set_error(HDU_ERR_ARG, "conv: null descriptor");
   if (d->dtype != HDU_BF16 && d->dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "conv: bad dtype");
   const int ch = d->dtype == HDU_BF16 ? 8 : 4;
@@ -2220,7 +2217,10 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad) {
   // The kernels test every tap against the input bounds, so an output grid LARGER than the symmetric-padding formula is
   // well defined: the extra positions see implicit zero padding on the high side (the parity classes of a stride-2 data
   // gradient need pad_low = 1, pad_high = 2).  Up to K-1 extra positions per axis are accepted; anything else is an error.
-  if (d->Do < eDo || d->Do > eDo + d->KD - 1 || d->Ho < eHo || d->Ho > eHo + d->KH - 1 || d->Wo < eWo || d->Wo > eWo + d->KW - 1)
+  // The filter-gradient kernels, their plans and the strided gather were written for the exact grid: strict form there.
+  const bool exact = wgrad || exact_grid;
+  const int xd = exact ? 0 : d->KD - 1, xh = exact ? 0 : d->KH - 1, xw = exact ? 0 : d->KW - 1;
+  if (d->Do < eDo || d->Do > eDo + xd || d->Ho < eHo || d->Ho > eHo + xh || d->Wo < eWo || d->Wo > eWo + xw)
     return hdu_set_error(HDU_ERR_ARG, "conv: output dims inconsistent with input dims / kernel / stride / pad");
   k->M = (long long)d->N * d->Do * d->Ho * d->Wo;
   if ((long long)d->N * k->De * k->He * k->We >= (1ll << 31) || k->M >= (1ll << 31))
@@ -2341,10 +2341,18 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
       // not 5, before the first MFMA (measured r02 calls P / Q against the 6-stage ring: 3dpart 11.09 -> 10.70 ms with
       // the 512-workgroup split target, end2end 17.23 -> 16.81, 2D 21.62 -> 21.57; 4 stages in between)
       constexpr int NSR = (BM == 64 && sizeof(T) == 2 && NSD == 6) ? 3 : NSD;
-      if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, true>), grid, dim3(256), 0, s, kk);
+      // (the fused BN backward rides on FAST-addressed launches: a data gradient has no up-sampling and <= 27 taps; a
+      // descriptor that is not FAST takes the late-load epilogue of the plain instantiation's BNB twin below)
+      if (k.bnb_u != nullptr) {
+        if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, true, true>), grid, dim3(256), 0, s, kk);
+        else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, false, true>), grid, dim3(256), 0, s, kk);
+      } else if (fast) HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, true>), grid, dim3(256), 0, s, kk);
       else HDU_LAUNCH((conv_igemm_ring_kernel<T, BM, BN, WMv, WNv, NSR, false>), grid, dim3(256), 0, s, kk);
     } else {
-      if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true>), grid, dim3(256), 0, s, k);
+      if (k.bnb_u != nullptr) {
+        if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true, true>), grid, dim3(256), 0, s, k);
+        else HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, false, true>), grid, dim3(256), 0, s, k);
+      } else if (fast) HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, true>), grid, dim3(256), 0, s, k);
       else HDU_LAUNCH((conv_igemm_dma_kernel<T, BM, BN, WMv, WNv, false>), grid, dim3(256), 0, s, k);
     }
   } else
@@ -2401,6 +2409,9 @@ static bool fprop_halo_ok(const ConvK& k, int dtype) {
   return dtype == HDU_BF16 && k.bnb_u == nullptr && !g_tuning[HDU_TUNE_NO_HALO_FPROP] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 &&
          k.KH == 3 && k.KW == 3 && k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 &&
          (k.ud | k.uh | k.uw) == 0 && k.Di == 1 && k.Cin % 8 == 0 && k.We >= 32 && k.He >= 4 &&
+         // the kernel addresses its output with the INPUT grid (3x3, pad 1: equal); an enlarged output grid (fill_convk
+         // accepts up to K-1 extra positions for the parity classes of a stride-2 data gradient) goes to the im2col path
+         k.Do == 1 && k.Ho == k.He && k.Wo == k.We &&
          // measured: pays when the K loop is long (>= 4 chunks of 32 channels) and one N tile covers Cout
          k.Cin >= 128 && k.Cout <= 96 &&
          // ... and when its 4x32-pixel tiles fill the chip: below that the im2col ring kernel with split-K spreads the
@@ -2641,7 +2652,7 @@ extern "C" int hdu_wgrad_plan_run(int variant, const void* dev_entries, const ui
 
 extern "C" int hdu_conv_dgrad_strided(const hdu_conv_desc* d, void* stream) {
   ConvK k;
-  if (int e = fill_convk(d, &k, false)) return e;
+  if (int e = fill_convk(d, &k, false, true)) return e;
   if (d->ud | d->uh | d->uw) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: upsampled input not supported");
   if (!d->x || !d->y) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: null dx / dy");
   if (d->epi_a) return hdu_set_error(HDU_ERR_ARG, "conv_dgrad_strided: no output affine");

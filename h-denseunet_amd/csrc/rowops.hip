@@ -1457,3 +1457,49 @@ extern "C" int hdu_cast_out(int dtype, const void* src, int64_t ldsrc, int64_t M
   else { HDU_T_LAUNCH(float, cast_out_kernel, M * C, (const float*)src, (long long)ldsrc, (long long)M, C, dst); }
   return hdu_check_launch("cast_out");
 }
+
+// ------------------------------------------------------------------ per-step re-initialisation (include/hdu.h)
+__global__ __launch_bounds__(256) void zero_regions_kernel(const hdu_zero_entry* __restrict__ table, int n, unsigned* counter,
+                                                          unsigned counter_inc) {
+  if (counter != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *counter += counter_inc;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hdu_zero_entry e = table[lo];
+  const unsigned long long off = (unsigned long long)(blockIdx.x - e.block_begin) * HDU_ZERO_BLOCK_BYTES;
+  if (off >= e.bytes) return;
+  unsigned long long len = e.bytes - off;
+  if (len > HDU_ZERO_BLOCK_BYTES) len = HDU_ZERO_BLOCK_BYTES;
+  char* base = (char*)e.ptr + off;
+  const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+  const unsigned long long n16 = len >> 4;
+  for (unsigned long long i = threadIdx.x; i < n16; i += 256) *(u32x4*)(base + (i << 4)) = z;
+  const unsigned long long tail0 = n16 << 4;
+  for (unsigned long long i = tail0 + 4ull * threadIdx.x; i + 4 <= len; i += 1024) *(unsigned*)(base + i) = 0u;
+}
+
+__global__ __launch_bounds__(256) void zero_one_kernel(char* __restrict__ p, unsigned long long bytes) {
+  const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+  const unsigned long long n16 = bytes >> 4;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (unsigned long long)gridDim.x * 256)
+    *(u32x4*)(p + (i << 4)) = z;
+  if (blockIdx.x == 0)
+    for (unsigned long long i = (n16 << 4) + 4ull * threadIdx.x; i + 4 <= bytes; i += 1024) *(unsigned*)(p + i) = 0u;
+}
+
+extern "C" int hdu_zero_regions(const hdu_zero_entry* dev_table, int n, uint32_t total_blocks, uint32_t* counter,
+                                uint32_t counter_inc, void* stream) {
+  if (!dev_table || n <= 0 || total_blocks == 0) return hdu_set_error(HDU_ERR_ARG, "zero_regions: bad args");
+  HDU_LAUNCH(zero_regions_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n, counter, counter_inc);
+  return hdu_check_launch("zero_regions");
+}
+
+extern "C" int hdu_zero(void* ptr, uint64_t bytes, void* stream) {
+  if (!ptr || ((uintptr_t)ptr & 15) || (bytes & 3)) return hdu_set_error(HDU_ERR_ARG, "zero: ptr must be 16-byte aligned, bytes a multiple of 4");
+  if (bytes == 0) return 0;
+  HDU_LAUNCH(zero_one_kernel, dim3(hdu_grid_1d((long long)(bytes >> 4), 256 * 8, 2048)), dim3(256), 0, (hipStream_t)stream,
+             (char*)ptr, (unsigned long long)bytes);
+  return hdu_check_launch("zero");
+}

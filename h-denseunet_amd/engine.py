@@ -95,8 +95,9 @@ class Var:
             # a first write must cover the buffer from channel 0 (asserted by construction of the nets)
             assert self.c0 == 0, "first gradient write into a shared buffer must start at channel 0"
             if self.C != r.act.ld:
-                # partial first write: clear the rest so later slab readers see zeros
-                r.grad_act.buf.zero_()
+                # partial first write: clear the rest so later slab readers see zeros (part of the step-head launch once
+                # the buffer is known, Ctx.step_zero)
+                self.ctx.zero_partial_grad(r.grad_act.buf)
         r.written = True
         return acc
 
@@ -186,6 +187,16 @@ class Ctx:
         self.stats_sinks = []
         self.stats_acc = None
         self.finalized = False
+        # per-step accumulators live in ONE arena cleared by one launch (ops.ZeroPlan / hdu_zero_regions)
+        self.arena = None
+        self.loss_layers = []
+        self._grad_zero = []           # slab gradient buffers whose first writer covers only part of the channels
+        self._grad_zero_ids = set()
+        self._zp_arena = self._zp_bwd = self._zp_step = None
+        self._zp_keep = []
+        self._zeroed_fwd_pass = -1     # pass whose forward accumulators are already clear
+        self._zeroed_bwd_pass = -1
+        self._zeroed_grad_pass = -1
 
     # ---------------- parameters
     def add_param(self, layer, kind, idx, keras_shape, shape, trainable, init, meta=None):
@@ -238,22 +249,36 @@ class Ctx:
                 tot += cv.kernel.numel
         self.Wc = torch.zeros(max(tot, 8), dtype=tdt, device=self.dev)
         self.init_weights(seed)
-        tot = 0
+        n_stats = 0
         for st in self.stats_sinks:
-            st.acc_off = tot
-            tot += st.SLOTS * 2 * st.var.C
-        self.stats_acc = torch.zeros(tot, dtype=torch.float32, device=self.dev) if tot else None
-        tot = 0
+            st.acc_off = n_stats
+            n_stats += st.SLOTS * 2 * st.var.C
+        n_bnb = 0
         for cv in self.convs:
             if cv.bnb_fused:
-                cv.bnb_off = tot
-                tot += cv.BNB_SLOTS * 2 * cv.bn.C
+                cv.bnb_off = n_bnb
+                n_bnb += cv.BNB_SLOTS * 2 * cv.bn.C
                 r = cv.x.root
                 if cv.bn.mode == "batch" and r.corr_off is None:
                     r.corr_off = self._corr_total
                     self._corr_total += 2 * r.act.ld
-        self.bnb_acc = torch.zeros(tot, dtype=torch.float32, device=self.dev) if tot else None
-        self.corr_acc = torch.zeros(self._corr_total, dtype=torch.float32, device=self.dev) if self._corr_total else None
+        # arena layout: [loss sums | epilogue statistics | fused-BN-backward slot rows | deferred corrections], every part a
+        # multiple of 4 floats so that the parts stay 16-byte aligned
+        up4 = lambda n: (n + 3) // 4 * 4
+        o_loss, n_loss = 0, 4 * max(1, len(self.loss_layers))
+        o_stats = o_loss + n_loss
+        o_bnb = o_stats + up4(n_stats)
+        o_corr = o_bnb + up4(n_bnb)
+        total = o_corr + up4(self._corr_total)
+        self.arena = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        for i, ll in enumerate(self.loss_layers):
+            ll.loss_sum = self.arena[4 * i:4 * i + 1]
+            ll.class_count = self.arena[4 * i + 1:4 * i + 4]
+        self.stats_acc = self.arena[o_stats:o_stats + n_stats] if n_stats else None
+        self.bnb_acc = self.arena[o_bnb:o_bnb + n_bnb] if n_bnb else None
+        self.corr_acc = self.arena[o_corr:o_corr + self._corr_total] if self._corr_total else None
+        self._zp_arena = ops.ZeroPlan([self.arena])
+        self._zp_bwd = ops.ZeroPlan([self.arena[o_bnb:total]]) if total > o_bnb else None
         for cv in self.convs:
             cv.bind()
         self._build_prep_table()
@@ -366,6 +391,26 @@ class Ctx:
         return [self._to_keras(p, p.grad) for p in self.by_layer[layer] if p.trainable]
 
     # ---------------- step pieces
+    def step_zero(self):
+        """head of a training step: ONE launch clears the accumulator arena, the flat gradient buffer (the filter-gradient
+        kernels add into it) and the slab gradient buffers with a partial first writer, and advances the dropout seed"""
+        if self._zp_step is None:
+            self._zp_step = ops.ZeroPlan([self.arena, self.G[:self.n_trainable]] + self._grad_zero)
+            self._zp_keep.append(self._zp_step)          # a captured graph may still hold an older table
+        self._zp_step.run(self.seed_dev, 1)
+        self._zeroed_fwd_pass = self._zeroed_bwd_pass = self.pass_id + 1     # the pass run_forward is about to start
+        self._zeroed_grad_pass = self.pass_id + 1
+
+    def zero_partial_grad(self, buf):
+        key = buf.data_ptr()
+        if key in self._grad_zero_ids and self._zeroed_grad_pass == self.pass_id:
+            return                                        # cleared by this step's step_zero launch
+        ops.zero_tensor(buf)
+        if key not in self._grad_zero_ids:
+            self._grad_zero_ids.add(key)
+            self._grad_zero.append(buf)
+            self._zp_step = None                          # rebuilt (with this buffer) at the next step head
+
     def prep_weights(self):
         """float32 master filters -> compute-dtype forward / data-gradient copies, all layers in one launch"""
         if self._prep_n:
@@ -407,8 +452,8 @@ class Ctx:
             if plan is not None:
                 plan.run()
                 self.prefolded_pass = self.pass_id
-        if self.learning_phase == 1 and self.stats_acc is not None:
-            self.stats_acc.zero_()          # ONE memset for the epilogue-statistics accumulators of every layer
+        if self.learning_phase == 1 and self._zeroed_fwd_pass != self.pass_id and self.stats_acc is not None:
+            self._zp_arena.run()            # (a training step cleared everything in its step-head launch: step_zero)
         for f in self.fwd:
             f()
 
@@ -419,11 +464,8 @@ class Ctx:
             for v in self.vars:
                 v.written = False
             self.fuse_bn_bwd_now = self.fuse_bn_bwd and (self.shard is None or self.shard.world == 1)
-            if self.fuse_bn_bwd_now:
-                if self.bnb_acc is not None:
-                    self.bnb_acc.zero_()
-                if self.corr_acc is not None:
-                    self.corr_acc.zero_()
+            if self.fuse_bn_bwd_now and self._zeroed_bwd_pass != self.pass_id and self._zp_bwd is not None:
+                self._zp_bwd.run()
         order = list(reversed(self.bwd))
         for f in order[lo:hi]:
             f()
@@ -1066,9 +1108,10 @@ class LossLayer:
         self.ctx, self.logits, self.ranges, self.weights = ctx, logits, ranges, weights
         self.count = sum(m for _, m in ranges)
         self.labels = torch.zeros(logits.act.M, dtype=torch.uint8, device=ctx.dev)
-        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=ctx.dev)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=ctx.dev)      # re-pointed into Ctx.arena by finalize()
         self.class_count = torch.zeros(3, dtype=torch.float32, device=ctx.dev)
         self.global_scale = 1.0   # 1/world_size under data parallelism (loss.py:44 takes the mean over ALL towers)
+        ctx.loss_layers.append(self)
         ctx.need_ws(1 << 14, 8)
 
     def set_labels(self, lab_u8_internal):
@@ -1081,8 +1124,8 @@ class LossLayer:
         self.labels.copy_(torch.from_numpy(lab.astype(np.uint8)).to(self.ctx.dev))
 
     def run(self, with_grad=True):
-        self.loss_sum.zero_()
-        self.class_count.zero_()
+        if self.ctx._zeroed_fwd_pass != self.ctx.pass_id:      # not inside a step whose head launch cleared the arena
+            ops.zero_tensor(self.ctx.arena[:4 * len(self.ctx.loss_layers)])
         dl = None
         if with_grad:
             self.logits.root.written = True

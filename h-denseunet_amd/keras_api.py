@@ -127,6 +127,8 @@ class Model:
         self.inputs = [self.input_shape]
         self.outputs = [self.output_shape]
         self.stop_training = False
+        self._pending_iterations = None
+        self._loss_names = None
 
     # ------------------------------------------------------------------ boundary layout conversion
     def _upload_x(self, x):
@@ -169,7 +171,11 @@ class Model:
         if not isinstance(optimizer, SGD):
             raise TypeError("optimizer must be SGD (the reference uses SGD(lr=1e-3, momentum=0.9, nesterov=True))")
         self.optimizer = optimizer
+        if getattr(self, "_pending_iterations", None) is not None:      # optimizer state was loaded before compile()
+            optimizer.iterations = self._pending_iterations
+            self._pending_iterations = None
         fns = loss if isinstance(loss, (list, tuple)) else [loss]
+        self._loss_names = [getattr(fn, "__name__", str(fn)) for fn in fns if fn is not None]
         for fn in fns:
             if fn is not None and getattr(fn, "__name__", "") not in ("weighted_crossentropy", "weighted_crossentropy_2ddense"):
                 raise ValueError("loss must be loss.weighted_crossentropy / weighted_crossentropy_2ddense")
@@ -192,10 +198,9 @@ class Model:
     def _step_head(self):
         ctx = self.ctx
         ctx.learning_phase = 1
-        ctx.seed_dev.add_(1)
+        ctx.step_zero()          # accumulators, flat gradient, dropout seed: one launch, no torch kernels in the step
         ctx.prep_weights()
         ctx.run_forward()
-        ctx.G[:ctx.n_trainable].zero_()
         self.loss_layer.run(True)
 
     def _step_device(self):
@@ -423,8 +428,11 @@ class Model:
         tr = [p for p in ctx.params if p.trainable]
         if len(arrays) != len(tr) + 1:
             raise ValueError("optimizer state has %d arrays, the model needs %d" % (len(arrays), len(tr) + 1))
+        its = int(np.asarray(arrays[0]).reshape(-1)[0])
         if self.optimizer is not None:
-            self.optimizer.iterations = int(np.asarray(arrays[0]).reshape(-1)[0])
+            self.optimizer.iterations = its
+        else:
+            self._pending_iterations = its       # compile() picks it up (Keras restores it with the optimizer, K.models.py:249-272)
         for p, a in zip(tr, arrays[1:]):
             t = torch.from_numpy(ctx._to_internal(p, a).reshape(-1)).to(ctx.dev)
             ctx.V[p.offset:p.offset + p.numel] = t
@@ -475,8 +483,9 @@ class Model:
             opt = self.optimizer
             root.attrs["training_config"] = json.dumps({
                 "optimizer_config": {"class_name": "SGD", "config": {"lr": opt.lr, "momentum": opt.momentum,
-                                                                     "decay": opt.decay, "nesterov": True}},
-                "loss": ["weighted_crossentropy"], "metrics": None, "sample_weight_mode": None, "loss_weights": None})
+                                                                     "decay": opt.decay, "nesterov": bool(opt.nesterov)}},
+                "loss": list(getattr(self, "_loss_names", None) or ["weighted_crossentropy"]), "metrics": None,
+                "sample_weight_mode": None, "loss_weights": None})
             og = root.group("optimizer_weights")
             st = self._optimizer_state()
             og.attrs["weight_names"] = [n for n, _ in st]

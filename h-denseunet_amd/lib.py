@@ -63,6 +63,13 @@ class AugSample(ctypes.Structure):
                 ("flip", ctypes.c_int32)]
 
 
+class ZeroEntry(ctypes.Structure):
+    _fields_ = [("ptr", c_p), ("bytes", ctypes.c_uint64), ("block_begin", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
+
+
+ZERO_BLOCK_BYTES = 65536      # include/hdu.h HDU_ZERO_BLOCK_BYTES
+
+
 class FoldEntry(ctypes.Structure):
     _fields_ = [("mean", c_p), ("var", c_p), ("gamma", c_p), ("beta", c_p), ("sgamma", c_p), ("sbeta", c_p),
                 ("a", c_p), ("b", c_p), ("rstd", c_p), ("C", ctypes.c_int32), ("eps", c_f)]
@@ -130,6 +137,8 @@ _SIGS = {
     "hdu_make_input3d_bwd": (c_int, [c_int, c_p, c_int, c_f, c_i64, c_p, c_i64, c_int, c_int, c_p]),
     "hdu_cast_pad": (c_int, [c_int, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p]),
     "hdu_cast_out": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
+    "hdu_zero_regions": (c_int, [c_p, c_int, c_u32, c_p, c_u32, c_p]),
+    "hdu_zero": (c_int, [c_p, ctypes.c_uint64, c_p]),
 }
 
 EXPORTS = tuple(_SIGS.keys())
@@ -142,7 +151,7 @@ class HduError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3        # include/hdu.h HDU_ABI_VERSION
+ABI_VERSION = 4        # include/hdu.h HDU_ABI_VERSION
 
 
 def product_library_path():

@@ -87,8 +87,11 @@ class Act:
 
 
 # split-K scratch of hdu_conv_fprop (include/hdu.h): one float32 buffer + ticket counters per process, shared by every
-# launch (launches of one stream are ordered; the filter gradients on the side stream never use it).  Sized for the
-# library's worst case (tile count x 16 splits x 64x128 float32 outputs).
+# launch.  SINGLE-STREAM CONTRACT: every hdu_conv_fprop launch of the process must be ordered after the previous one
+# (one stream, or streams joined by events as torch's graph capture does) -- two concurrent launches would race on the
+# partial tiles and tickets.  The engine issues all convs of a model on torch's current stream; an overlap scheme that
+# puts convs on a second stream has to give that stream its own scratch (conv_desc(..., splitk=(ws, counters))).
+# Sized for the library's worst case (tile count x 16 splits x 64x128 float32 outputs).
 _SPLITK = None
 SPLITK_BYTES = 320 * 16 * 64 * 128 * 4
 
@@ -102,10 +105,11 @@ def splitk_scratch():
 
 
 def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
-              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None):
-    """x: Act (stored input), y: Act (output), K=(KD,KH,KW); epi = (a, b, relu): output affine of the BN that follows."""
+              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None, splitk=None):
+    """x: Act (stored input), y: Act (output), K=(KD,KH,KW); epi = (a, b, relu): output affine of the BN that follows;
+    splitk = (float32 scratch tensor of SPLITK_BYTES, int32[512] zeroed counters) for launches on another stream."""
     d = ConvDesc()
-    ws, cnt = splitk_scratch()
+    ws, cnt = splitk if splitk is not None else splitk_scratch()
     d.splitk_ws, d.splitk_ws_bytes, d.splitk_counters = ws.data_ptr(), SPLITK_BYTES, cnt.data_ptr()
     d.dtype = x.dtype
     d.x, d.ldx = x.ptr, x.ld
@@ -197,6 +201,37 @@ class WgradPlan:
                 launch()
             else:
                 around(variant, launch)
+
+
+class ZeroPlan:
+    """hdu_zero_regions: ONE launch clears a fixed list of device buffers (and bumps the step counter).  Built once per
+    list; the table lives in device memory."""
+
+    def __init__(self, tensors):
+        import numpy as np
+        self.keep = [t for t in tensors if t is not None and t.numel() > 0]
+        ents, blk = [], 0
+        for t in self.keep:
+            nb = t.numel() * t.element_size()
+            assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nb % 4 == 0, "zero plan: 16-byte aligned, whole dwords"
+            ents.append(_l.ZeroEntry(t.data_ptr(), nb, blk, 0))
+            blk += (nb + _l.ZERO_BLOCK_BYTES - 1) // _l.ZERO_BLOCK_BYTES
+        self.n, self.blocks = len(ents), blk
+        self.table = None
+        if ents:
+            arr = (_l.ZeroEntry * len(ents))(*ents)
+            self.table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device())
+
+    def run(self, counter=None, inc=0):
+        if self.table is None:
+            return
+        check(_l.get().hdu_zero_regions(ctypes.c_void_p(self.table.data_ptr()), self.n, self.blocks,
+                                        ctypes.c_void_p(counter.data_ptr()) if counter is not None else None, inc, stream()),
+              "hdu_zero_regions")
+
+
+def zero_tensor(t):
+    check(_l.get().hdu_zero(ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(), stream()), "hdu_zero")
 
 
 def conv_dgrad_strided(d):

@@ -42,8 +42,9 @@ const char* hdu_last_error(void);
 const char* hdu_backend(void);
 /* Layout version of the structs in this header (hdu_conv_desc, hdu_fold_entry, hdu_aug_sample, hdu_prep_entry) and of the
  * entry-point set.  A binding compares hdu_abi_version() and hdu_sizeof_conv_desc() with what it was written against and
- * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*. */
-#define HDU_ABI_VERSION 3
+ * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*,
+ * 4 = round 3 (hdu_zero_regions, hdu_comm_*). */
+#define HDU_ABI_VERSION 4
 int hdu_abi_version(void);
 size_t hdu_sizeof_conv_desc(void);
 /* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES: 2 = two LDS stages, deep ring for small grids (default); 6 = deep ring everywhere */
@@ -383,6 +384,26 @@ int hdu_make_input3d_bwd(int dtype, const void* dinput3d, int Cpad, float scale,
 /* dtype conversion / layout helpers for the boundary (float32 channels-last in, compute dtype out, and back) */
 int hdu_cast_pad(int dtype, const float* src, int64_t M, int C, void* dst, int64_t lddst, int Cpad, void* stream);
 int hdu_cast_out(int dtype, const void* src, int64_t ldsrc, int64_t M, int C, float* dst, void* stream);
+
+/* ------------------------------------------------------------------ per-step re-initialisation
+ * The accumulators a training step adds into (epilogue statistics, fused BN-backward slot rows, the flat gradient buffer the
+ * filter-gradient kernels atomically accumulate into, slab gradient buffers whose first writer covers only some channels,
+ * the loss sums) are cleared by ONE launch at the head of the step, which also advances the device-side step counter the
+ * dropout masks are seeded with.  Replaces what TensorFlow does implicitly by materialising fresh tensors every
+ * session.run (K.engine/training.py:1715-1766) -- and the per-buffer torch fills the engine used before.
+ * table: DEVICE array of n entries sorted by block_begin; entry i is cleared by blocks [block_begin[i], block_begin[i+1])
+ * of HDU_ZERO_BLOCK_BYTES each; ptr 16-byte aligned, bytes a multiple of 4.  counter may be NULL. */
+#define HDU_ZERO_BLOCK_BYTES 65536
+typedef struct hdu_zero_entry {
+  void* ptr;
+  uint64_t bytes;
+  uint32_t block_begin;
+  uint32_t pad_;
+} hdu_zero_entry;
+int hdu_zero_regions(const hdu_zero_entry* dev_table, int n, uint32_t total_blocks, uint32_t* counter, uint32_t counter_inc,
+                     void* stream);
+/* one region (ptr 16-byte aligned, bytes a multiple of 4) */
+int hdu_zero(void* ptr, uint64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -846,3 +846,37 @@ def test_stride2_dgrad_parity_classes(hdu, dtype, shape):
     assert_close(dx.to_torch().cpu(), xe.grad, dtype, what="stride-2 dgrad")
     s2.run(dx, accumulate=True)
     assert_close(dx.to_torch().cpu(), 2 * xe.grad, dtype, scale=2 * float(xe.grad.abs().max()), what="stride-2 dgrad accumulate")
+
+
+def test_zero_regions(hdu):
+    """hdu_zero_regions / hdu_zero: the one-launch re-initialisation of a step's accumulators -- every region cleared
+    exactly (multi-block regions, a 4-byte-granular tail, a region smaller than one block), neighbours untouched, the
+    step counter advanced once"""
+    ops = ops_mod()
+    d = ops.device()
+    sizes = [5, 4, 16384 + 7, 3 * 16384, 1]          # floats; 16384 floats = one 64 KiB block
+    pad = 8
+    bufs, views = [], []
+    for i, n in enumerate(sizes):
+        big = torch.full((n + 2 * pad + 3,), float(i + 1), dtype=torch.float32, device=d)
+        bufs.append(big)
+        off = pad + (-(big.data_ptr() // 4 + pad)) % 4       # 16-byte aligned start
+        views.append(big[off:off + n])
+    half = torch.full((64,), 3.0, dtype=torch.bfloat16, device=d)
+    counter = torch.tensor([41], dtype=torch.int32, device=d)
+    plan = ops.ZeroPlan(views + [half])
+    plan.run(counter, 1)
+    plan.run(counter, 1)
+    assert int(counter.item()) == 43
+    for i, (big, v) in enumerate(zip(bufs, views)):
+        assert float(v.abs().max()) == 0.0
+        rest = big.clone()
+        off = v.data_ptr() // 4 - big.data_ptr() // 4
+        rest[off:off + v.numel()] = float(i + 1)
+        assert torch.equal(rest, torch.full_like(big, float(i + 1))), "neighbouring bytes of region %d were touched" % i
+    assert float(half.float().abs().max()) == 0.0
+    t = torch.full((16384 * 2 + 12,), 2.0, dtype=torch.float32, device=d)
+    ops.zero_tensor(t[4:4 + 16384 * 2 + 4])
+    assert float(t[4:-4].abs().max()) == 0.0 and float(t[:4].min()) == 2.0 and float(t[-4:].min()) == 2.0
+    with pytest.raises(Exception):
+        ops.zero_tensor(t[1:9])                        # not 16-byte aligned
