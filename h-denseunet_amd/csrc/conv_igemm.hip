@@ -718,10 +718,16 @@ __device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n
     float s1[CH], s2[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    if (cc < NCC && nbase < p.Cout) {
-      float sh[CH];
+    float sh[CH];
+    {
+      const int nc = (cc < NCC && nbase < p.Cout) ? nbase : 0;      // unconditional, clamped (see igemm_epilogue)
 #pragma unroll
-      for (int j = 0; j < CH; ++j) sh[j] = p.stats_shift[nbase + j];
+      for (int j = 0; j < CH; j += 4) {
+        const f32x4 v4 = *(const f32x4*)(p.stats_shift + nc + j);
+        sh[j] = v4[0]; sh[j + 1] = v4[1]; sh[j + 2] = v4[2]; sh[j + 3] = v4[3];
+      }
+    }
+    if (cc < NCC && nbase < p.Cout) {
       for (int row = rl; row < BM; row += 16) {
         if (!valid(row)) continue;
         float f[CH];
@@ -759,14 +765,16 @@ __device__ __forceinline__ void bnb_issue_loads(const ConvK& p, long long m0, in
   const bool col_ok = cc < G::NCC && n < p.Cout;
   const T* __restrict__ up = (const T*)p.bnb_u;
   const T* __restrict__ yp = (const T*)p.y;
-  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int q = 0; q < NIT; ++q) {
     const int row = r0 + (it0 + q) * G::RSTEP;
     const long long m = m0 + row;
     const bool ok = col_ok && row < BM && m < p.M;
-    uv[q] = ok ? *(const u32x4*)(up + m * p.bnb_ldu + n) : z4;
-    ov[q] = (ok && p.accumulate) ? *(const u32x4*)(yp + m * p.ldy + n) : z4;
+    // UNCONDITIONAL loads (a lane without work re-reads element 0 of the tensor and ignores it): a per-lane
+    // "load or zero" select makes hipcc branch around every load and wait vmcnt(0) behind it -- measured in the ISA of
+    // round 2's build: one full memory round trip per chunk, 4-8 of them in a row per tile epilogue
+    uv[q] = *(const u32x4*)(up + (ok ? m * p.bnb_ldu + n : 0));
+    ov[q] = *(const u32x4*)(yp + ((ok && p.accumulate) ? m * p.ldy + n : 0));
   }
 }
 
@@ -783,13 +791,21 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
   const bool col_ok = cc < NCC && n < p.Cout;
   const bool sums = p.bnb_partial != nullptr;
   float a[CH], b[CH], mu[CH], rs[CH], s1[CH], s2[CH];
+  {
+    // unconditional vector loads at a clamped channel index (see bnb_issue_loads): four loads in flight together instead
+    // of 4 x CH branch + wait sequences; values of lanes without a column are never used
+    const int nc = col_ok ? n : 0;
+    const float* pmu = sums ? p.bnb_mean : p.bnb_a;
+    const float* prs = sums ? p.bnb_rstd : p.bnb_a;
 #pragma unroll
-  for (int j = 0; j < CH; ++j) {
-    a[j] = col_ok ? p.bnb_a[n + j] : 0.f;
-    b[j] = col_ok ? p.bnb_b[n + j] : 0.f;
-    mu[j] = col_ok && sums ? p.bnb_mean[n + j] : 0.f;
-    rs[j] = col_ok && sums ? p.bnb_rstd[n + j] : 0.f;
-    s1[j] = 0.f; s2[j] = 0.f;
+    for (int j = 0; j < CH; j += 4) {
+      const f32x4 va = *(const f32x4*)(p.bnb_a + nc + j), vb = *(const f32x4*)(p.bnb_b + nc + j);
+      const f32x4 vm = *(const f32x4*)(pmu + nc + j), vr = *(const f32x4*)(prs + nc + j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[j + r] = va[r]; b[j + r] = vb[r]; mu[j + r] = sums ? vm[r] : 0.f; rs[j + r] = sums ? vr[r] : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   }
   T* __restrict__ yp = (T*)p.y;
   for (int it0 = 0; it0 < IT; it0 += UNR) {
@@ -881,6 +897,18 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
   // + r] of its 16x16 fragment, i.e. 4 consecutive output channels of one pixel -- one 8- / 16-byte LDS store per
   // fragment instead of four 2- / 4-byte ones.
   const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
+  // this lane's bias / output-affine vectors of its TN column groups: loaded ONCE, unconditionally (clamped channel index),
+  // all in flight together.  Round 2's per-fragment "if (n < Cout) v += bias[n]" compiled to a branch + load +
+  // s_waitcnt vmcnt(0) per fragment: up to 2 x TM x TN dependent L2 round trips in the epilogue of every biased conv.
+  f32x4 bias_v[TN], epa_v[TN], epb_v[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+    const int nc = n < p.Cout ? n : 0;               // Cout is a multiple of the 16-byte chunk: 4 channels are all-or-nothing
+    bias_v[j] = has_bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    epa_v[j] = has_epi ? *(const f32x4*)(p.epi_a + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    epb_v[j] = has_epi ? *(const f32x4*)(p.epi_b + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = wm * WM + i * 16 + (lane & 15);
@@ -890,9 +918,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
       const int col = wn * WN + j * 16 + (lane >> 4) * 4;
       const int n = n0 + col;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (has_bias && n < p.Cout) {                  // Cout is a multiple of the 16-byte chunk: 4 channels are all-or-nothing
+      if (has_bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.bias[n + r];
+        for (int r = 0; r < 4; ++r) v[r] += bias_v[j][r];
       }
       if (drop) {
 #pragma unroll
@@ -901,10 +929,10 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
           v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
         }
       }
-      if (has_epi && n < p.Cout) {                   // the BN(+Scale)(+ReLU) that follows this conv (stored statistics)
+      if (has_epi) {                                 // the BN(+Scale)(+ReLU) that follows this conv (stored statistics)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = p.epi_a[n + r] * v[r] + p.epi_b[n + r];
+          v[r] = epa_v[j][r] * v[r] + epb_v[j][r];
           if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
       }
@@ -929,8 +957,9 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
       const int row = q / NCC, cc = q % NCC;
       const long long m = m0 + row;
       const int n = n0 + cc * CH;
-      old[it] = u32x4{0u, 0u, 0u, 0u};
-      if (q < BM * NCC && m < p.M && n < p.Cout) old[it] = *(const u32x4*)(yp + m * p.ldy + n);
+      // unconditional (see bnb_issue_loads): lanes without a chunk re-read element 0 and ignore it below
+      const bool ok = q < BM * NCC && m < p.M && n < p.Cout;
+      old[it] = *(const u32x4*)(yp + (ok ? m * p.ldy + n : 0));
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1913,6 +1942,15 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
   constexpr int ROWB = BN * 2 + 16;
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
   const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
+  f32x4 bias_v[TN], epa_v[TN], epb_v[TN];            // loaded once, unconditionally (see igemm_epilogue)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + j * 16 + lg * 4;
+    const int nc = nn < p.Cout ? nn : 0;
+    bias_v[j] = has_bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    epa_v[j] = has_epi ? *(const f32x4*)(p.epi_a + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    epb_v[j] = has_epi ? *(const f32x4*)(p.epi_b + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {                      // (operands swapped in the K loop: lane = pixel li, 4 channels lg*4..)
     const int tx = i * 16 + li;
@@ -1923,9 +1961,9 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
       const int col = j * 16 + lg * 4;
       const int nn = n0 + col;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (has_bias && nn < p.Cout) {
+      if (has_bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p.bias[nn + r];
+        for (int r = 0; r < 4; ++r) v[r] += bias_v[j][r];
       }
       if (drop) {
 #pragma unroll
@@ -1934,10 +1972,10 @@ __global__ __launch_bounds__(256) void conv_halo_fprop_kernel(ConvK p) {
           v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
         }
       }
-      if (has_epi && nn < p.Cout) {
+      if (has_epi) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = p.epi_a[nn + r] * v[r] + p.epi_b[nn + r];
+          v[r] = epa_v[j][r] * v[r] + epb_v[j][r];
           if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
         }
       }
@@ -2272,6 +2310,10 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad, bool exact_g
     if (k->bnb_partial && (!k->bnb_mean || !k->bnb_rstd || k->bnb_slots <= 0))
       return hdu_set_error(HDU_ERR_ARG, "conv: bnb_partial needs bnb_mean, bnb_rstd and bnb_slots > 0");
   }
+  // the epilogues read the per-channel vectors as 16-byte float4s
+  if (((uintptr_t)k->bias | (uintptr_t)k->epi_a | (uintptr_t)k->epi_b | (uintptr_t)(k->stats_partial ? k->stats_shift : nullptr) |
+       (uintptr_t)k->bnb_a | (uintptr_t)k->bnb_b | (uintptr_t)k->bnb_mean | (uintptr_t)k->bnb_rstd) & 15)
+    return hdu_set_error(HDU_ERR_ARG, "conv: bias / epi_* / stats_shift / bnb_* vectors must be 16-byte aligned");
   k->sk_ws = wgrad ? nullptr : (float*)d->splitk_ws;
   k->sk_cnt = wgrad ? nullptr : d->splitk_counters;
   if (k->sk_ws && ((uintptr_t)k->sk_ws % 16 || !k->sk_cnt))
@@ -2772,8 +2814,9 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const bool ring = dma && igemm_ring_ok(nblk, k.Ktot, stage, nsd);
     const int nsr = (nsd == 6 && ring_wgs_per_cu(bm, d->dtype == HDU_BF16) == 2) ? 3 : nsd;     // (launch_igemm)
     const char* fast = igemm_fast_ok(k) ? "true" : "false";
-    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, nsr, fast);
-    else if (dma) snprintf(buf, buflen, "conv_igemm_dma_kernel<%s, %d, %d, %d, %d, %s>", t, bm, bn, wm, 4 / wm, fast);
+    const char* bnb = k.bnb_u != nullptr ? "true" : "false";
+    if (ring) snprintf(buf, buflen, "conv_igemm_ring_kernel<%s, %d, %d, %d, %d, %d, %s, %s>", t, bm, bn, wm, 4 / wm, nsr, fast, bnb);
+    else if (dma) snprintf(buf, buflen, "conv_igemm_dma_kernel<%s, %d, %d, %d, %d, %s, %s>", t, bm, bn, wm, 4 / wm, fast, bnb);
     else snprintf(buf, buflen, "conv_igemm_kernel<%s, %d, %d, %d, %d>", t, bm, bn, wm, 4 / wm);
   }
   return 0;

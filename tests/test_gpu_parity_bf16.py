@@ -53,8 +53,19 @@ def _train(m, x, y, steps):
     return l0, m.loss_value()
 
 
+_WCACHE = {}
+
+
 def trained_weights(kind, variant, b, size, cols, nb2d=FULL2D, nb3d=FULL3D, steps2d=200, steps3d=100):
-    """the recipe described in the module docstring; returns an OrderedDict layer -> Keras-shaped arrays"""
+    """the recipe described in the module docstring; returns an OrderedDict layer -> Keras-shaped arrays (cached per
+    process: tests/test_gpu_parity.py feeds the same weights to its float32 gates)"""
+    key = (kind, variant, b, size, cols, tuple(nb2d), tuple(nb3d), steps2d, steps3d)
+    if key not in _WCACHE:
+        _WCACHE[key] = _trained_weights(kind, variant, b, size, cols, nb2d, nb3d, steps2d, steps3d)
+    return _WCACHE[key]
+
+
+def _trained_weights(kind, variant, b, size, cols, nb2d, nb3d, steps2d, steps3d):
     if kind == "2d":
         mod = U.pkg("denseunet" if variant == "denseunet" else "densenet")
         m = mod.DenseUNet(reduction=0.5, args=U.make_args(b, size), dtype="f32", nb_layers=nb2d, seed=4321)
@@ -134,24 +145,49 @@ def flat_grads(gd_product):
     return {(n, i): g for n, gs in gd_product.items() for i, g in enumerate(gs)}
 
 
+# recipe lengths (steps of the 2D pre-training, steps of the hybrid / 3D stage): "trained" = a converged net (loss ~0.05:
+# gradients are small differences of large terms, bf16 storage alone moves them by tens of percent); "mid" = a
+# MID-TRAINING checkpoint (loss ~0.3-0.5) where the bf16 noise floor is a few percent, so the 3x slack of the gates below
+# resolves a real defect of a few percent
+RECIPES = {"trained": (200, 100), "mid": (30, 20)}
 CASES = [
-    ("2d", "denseunet", 2, 512, None),            # BASELINE configs[1] shape family (2 x 512 x 512)
-    ("hybrid", "3dpart", 1, 224, 12),             # configs[2]
-    ("hybrid", "end2end", 1, 224, 12),            # configs[3]
-    ("3d", "3dpart", 1, 224, 12),                 # the per-shard network of configs[4]
+    ("2d", "denseunet", 2, 512, None, "trained"),            # BASELINE configs[1] shape family (2 x 512 x 512)
+    ("hybrid", "3dpart", 1, 224, 12, "trained"),             # configs[2]
+    ("hybrid", "end2end", 1, 224, 12, "trained"),            # configs[3]
+    ("3d", "3dpart", 1, 224, 12, "trained"),                 # the per-shard network of configs[4]
+    ("2d", "denseunet", 2, 512, None, "mid"),
+    ("hybrid", "end2end", 1, 224, 12, "mid"),
+    ("hybrid", "3dpart", 1, 224, 12, "mid"),
 ]
+FIGURES = os.path.join(U.ROOT, "gpurun_out", "bf16_parity_figures.txt")
 
 
-@pytest.mark.parametrize("kind,variant,b,size,cols", CASES, ids=["2d-2x512", "3dpart", "end2end", "3d"])
-def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols):
+def _log(msg):
+    print(msg)
+    try:
+        os.makedirs(os.path.dirname(FIGURES), exist_ok=True)
+        with open(FIGURES, "a") as f:
+            f.write(msg + "\n")
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("kind,variant,b,size,cols,recipe", CASES,
+                         ids=["2d-2x512", "3dpart", "end2end", "3d", "2d-2x512-mid", "end2end-mid", "3dpart-mid"])
+def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols, recipe):
     small = os.environ.get("HDU_PARITY_SMALL") == "1"       # developer switch: same flow at reduced depth / size
     nb2d, nb3d = ((2, 2, 2, 2), (1, 1, 2, 1)) if small else (FULL2D, FULL3D)
     if small:
         size, cols = (64, None) if kind == "2d" else (32, 8)
     torch.manual_seed(0)
-    W = trained_weights(kind, variant, b, size, cols, nb2d, nb3d, *((8, 6) if small else (200, 100)))
-    x, y = U.synthetic_batch(kind, b, size, cols)
+    W = trained_weights(kind, variant, b, size, cols, nb2d, nb3d, *((8, 6) if small else RECIPES[recipe]))
+    # evaluation input: a fresh phantom (seed 1234) -- except for `denseunet_3d`, whose frozen 2D branch (x250 into the 3D
+    # stem) makes the net chaotic away from the sample it was fitted to (round 2: label agreement 0.984 even between the
+    # float32 and the bf16-storage ORACLES there); it is evaluated on the phantom it was trained on (seed 77), where its
+    # logits are decided.  The weights and the input are identical for oracle and product either way.
+    x, y = U.synthetic_batch(kind, b, size, cols, seed=77 if (kind, variant) == ("hybrid", "3dpart") else 1234)
     xt, yt = torch.tensor(x), torch.tensor(y)
+    kind_tag = "%s/%s/%s" % (kind, variant, recipe)
 
     # ---- oracle: predict, float32 step, bf16-storage step (calibration)
     P, fwd = oracle_with(W, kind, variant, b, size, cols, nb2d, nb3d)
@@ -180,9 +216,9 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols)
     agree = float((np.argmax(got_pred, -1) == np.argmax(ref_pred, -1)).mean())
     srt = np.sort(ref_pred, -1)
     margin = srt[..., -1] - srt[..., -2]
-    print("[%s/%s] predict: max|logit| %.3f, max abs err %.3e (%.2e relative), median top-2 margin %.3f, label agreement "
+    _log("[%s] predict: max|logit| %.3f, max abs err %.3e (%.2e relative), median top-2 margin %.3f, label agreement "
           "%.5f, Dice vs oracle %s (bf16-storage oracle vs oracle %s); Dice vs ground truth %s (oracle %s, bf16-storage oracle %s)" %
-          (kind, variant, scale, e_pred, e_pred / scale, float(np.median(margin)), agree, ["%.5f" % d for d in dice],
+          (kind_tag, scale, e_pred, e_pred / scale, float(np.median(margin)), agree, ["%.5f" % d for d in dice],
            ["%.5f" % d for d in dice_cal], ["%.4f" % d for d in dice_gt_got], ["%.4f" % d for d in dice_gt_ref], ["%.4f" % d for d in dice_gt_cal]))
     m.compile(optimizer=_sgd(), loss=[U.pkg("loss").weighted_crossentropy])
     assert m.ctx.wgrad_plan is not None and len(m.ctx.wgrad_plan) > 10, "deferred batched filter gradients must be on"
@@ -209,18 +245,37 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols)
         return num / sum(float((ref_g[k].astype(np.float64) ** 2).sum()) for k in ref_g)
     coef, cal_coef = regression(flat_grads(m.get_grads_dict())), regression(cal_g)
     worst = max(rows, key=lambda r: r[1] / max(BF16_SLACK * r[4], REL_FLOOR))
-    print("[%s/%s] train step: loss %.6f (oracle %.6f, bf16-storage oracle %.6f); train-mode logits max abs err %.3e "
-          "(bf16-storage oracle %.3e, max|logit| %.3f)" % (kind, variant, loss, ref_loss, cal_loss, e_train, e_cal,
-                                                          float(np.abs(rl).max())))
-    print("[%s/%s] gradients over %d tensors: rel-L2 worst %.4f / median %.4f (bf16-storage oracle: %.4f / %.4f); cosine "
+    _log("[%s] train step: loss %.6f (oracle %.6f, bf16-storage oracle %.6f); train-mode logits max abs err %.3e "
+         "(bf16-storage oracle %.3e, max|logit| %.3f)" % (kind_tag, loss, ref_loss, cal_loss, e_train, e_cal,
+                                                         float(np.abs(rl).max())))
+    _log("[%s] gradients over %d tensors: rel-L2 worst %.4f / median %.4f (bf16-storage oracle: %.4f / %.4f); cosine "
           "min %.5f / median %.6f (oracle-bf16: %.5f / %.6f); mean norm ratio %.4f (oracle-bf16 %.4f); pooled regression "
           "coefficient on the oracle gradient %.4f (oracle-bf16 %.4f); worst vs its bound: "
-          "%s rel %.4f noise %.4f" % (kind, variant, len(rows), rels.max(), float(np.median(rels)), cal_rels.max(),
+          "%s rel %.4f noise %.4f" % (kind_tag, len(rows), rels.max(), float(np.median(rels)), cal_rels.max(),
                                       float(np.median(cal_rels)), coss.min(), float(np.median(coss)), cal_coss.min(),
                                       float(np.median(cal_coss)), float(ratios.mean()), float(cal_ratios.mean()),
                                       coef, cal_coef, worst[0], worst[1], worst[4]))
 
+    # ---- DIRECT comparison with the bf16-storage oracle: that run rounds where the product rounds, so
+    # the product should sit much closer to it than either sits to the float32 oracle.  Independent errors of the size of
+    # the storage noise would put the product at sqrt(2) x noise from it; a shared rounding pattern puts it well inside.
+    got_g = flat_grads(m.get_grads_dict())
+    drows = grad_table(got_g, cal_g)
+    drels = np.array([r[1] for r in drows])
+    dcoss = np.array([r[2] for r in drows if r[2] is not None])
+    dcoef = (sum(float((got_g[k].astype(np.float64) * cal_g[k].astype(np.float64)).sum()) for k in cal_g) /
+             sum(float((cal_g[k].astype(np.float64) ** 2).sum()) for k in cal_g))
+    e_direct = float(np.abs(got_l - cal_logits.numpy()).max())
+    closer = float((drels < cal_rels).mean())
+    _log("[%s] product vs bf16-storage oracle DIRECTLY: gradients rel-L2 worst %.4f / median %.4f (that oracle vs float32: %.4f / "
+         "%.4f), cosine min %.5f / median %.6f, pooled regression coefficient %.4f, %.1f %% of the tensors closer to it than it "
+         "is to float32; train-mode logits max abs diff %.3e (it vs float32: %.3e); loss diff %.3e (it vs float32 %.3e)" %
+         (kind_tag, drels.max(), float(np.median(drels)), cal_rels.max(), float(np.median(cal_rels)), dcoss.min(),
+          float(np.median(dcoss)), dcoef, 100.0 * closer, e_direct, e_cal, abs(loss - cal_loss), abs(cal_loss - ref_loss)))
+
     # ---- gates
+    if os.environ.get("HDU_PARITY_MEASURE_ONLY") == "1":
+        return
     for c in range(3):
         assert 1.0 - dice[c] <= max(1e-3, BF16_SLACK * (1.0 - dice_cal[c])), \
             "predict Dice vs the float32 oracle on ALL voxels: %s (bf16-storage oracle %s)" % (dice, dice_cal)
