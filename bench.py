@@ -160,7 +160,7 @@ def instrumented_step(m):
         # algorithmic FLOPs = the sum over the layers of that launch
         orig_run = plan.run
 
-        def timed_plan_run(around=None, group=None):       # (the instrumented step runs with the overlap off: see below)
+        def timed_plan_run():
             def around(variant, launch):
                 ds = plan.descs[variant]
                 Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
@@ -172,10 +172,6 @@ def instrumented_step(m):
                 recs.append((name, sum(flops(d, 1) for d in ds), e0, e1, -len(ds), (0, 0, 0), sum(alg_bytes(d, 1) for d in ds)))
             orig_run(around)
         plan.run = timed_plan_run
-    cuts = ctx._wgrad_cuts
-    ngroups = plan.ngroups if plan is not None else 1
-    if plan is not None:
-        plan.ngroups = 1            # kernels are timed in isolation: the filter gradients run after the backward, as one group
     try:
         g = m._graph
         m._graph = None
@@ -190,7 +186,6 @@ def instrumented_step(m):
             m._allreduce, m._allreduce_async, m._buckets = dp
             if plan is not None:
                 del plan.run                 # back to the class method
-                plan.ngroups = ngroups
         _sync()
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w

@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 SRC=h-denseunet_amd/csrc
 what=${1:-all}
 if [ "$what" = hip ] || [ "$what" = all ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -Wno-c++20-extensions \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -Wno-c++20-extensions -mllvm -amdgpu-mfma-vgpr-form=1 \
     -x hip $SRC/conv_igemm.hip $SRC/rowops.hip $SRC/augment.hip -x hip $SRC/hdu_core.cpp \
     -o h-denseunet_amd/libhdu.so
   echo "built h-denseunet_amd/libhdu.so"

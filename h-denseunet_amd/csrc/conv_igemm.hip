@@ -1435,6 +1435,133 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   HDU_TP(6);
 }
 
+// =====================================================================================
+// Pointwise GEMM with a SHORT contraction and a WIDE output -- filter-stationary streaming form.
+// The data gradient of every dense-block bottleneck (denseunet.py:245-248 / denseunet3d.py:34-37 backward):
+//   dx[M x c] = dt[M x 192] . W^T,  c = 96 .. 2160 channels, K = 192 (2D) / 128 (3D) = 3 / 2 steps of 64.
+// In the tiled kernels above every 64 x 128 output tile is its own workgroup: row state, a 2-3 step K loop and an
+// epilogue -- ~11 us of fixed cost for ~1 us of multiplication (measured: 46 us per launch at M = 8192, 0.4 TB/s, 3.4 ms
+// of the 21 ms 2D step).  Here a workgroup OWNS 128 output channels: their filter rows (128 x K, 48 KB) go to LDS once,
+// then it streams its share of the pixel rows through a 3-slot ring of [64 rows x K] tiles (async buffer DMA, counted
+// vmcnt, one raw barrier per tile) and writes each 64 x 128 result through a per-wave LDS staging patch as full 128-byte
+// lines.  Waves: 2 (pixels) x 2 (channels), 32 x 64 outputs each -- a wave's staging rows are whole cache lines, so the
+// epilogue needs no workgroup barrier.  Traffic per output element: the activation tile once per 128 channels, the filter
+// once per workgroup.
+template <int KS, int BN>
+__global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_per_wg) {
+  typedef bf16_t T;
+  constexpr int CH = 8, BM = 64, NSA = 3;
+  constexpr int A_SLAB = BM * 128, A_STAGE = KS * A_SLAB;
+  constexpr int B_SLAB = BN * 128, B_BYTES = KS * B_SLAB;
+  constexpr int WM = 32, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int CROWB = WN * 2 + 16, CST = WM * CROWB;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32, LA = KS * A_IT;
+  static_assert(BN % 64 == 0 && KS >= 1 && KS <= 4, "shape");
+  static_assert(B_BYTES + NSA * A_STAGE + 4 * CST <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[B_BYTES + NSA * A_STAGE + 4 * CST];
+  char* Bsm = smem;
+  char* Aring = smem + B_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave >> 1, wn = wave & 1;
+  char* stg = smem + B_BYTES + NSA * A_STAGE + wave * CST;
+  const int r0 = tid >> 3;
+  const int kcl = (tid & 7) ^ (r0 & 7);          // logical 16-byte chunk of the 128-byte slab row this lane fetches
+  const int n0 = blockIdx.y * BN;
+  const long long m_begin = (long long)blockIdx.x * rows_per_wg;
+  long long m_end = m_begin + rows_per_wg;
+  if (m_end > p.M) m_end = p.M;
+  const int ntiles = (int)((m_end - m_begin + BM - 1) / BM);
+  if (ntiles <= 0) return;
+  const hdu_bufsrd xsrd = hdu_make_srd(p.x, p.x_bytes);
+  const hdu_bufsrd wsrd = hdu_make_srd(p.w, p.w_bytes);
+
+  // ---- the filter rows of this workgroup's channels: once
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int col = n0 + r0 + j * 32;
+      const unsigned off = col < p.Cout ? (unsigned)(col * p.Ktot + ks * 64 + kcl * CH) * 2u : HDU_OOB;
+      hdu_bufload_lds16(wsrd, off, Bsm + ks * B_SLAB + (j * 32 + wave * 8) * 128);
+    }
+  auto issue_tile = [&](int t) {
+    char* As = Aring + (t % NSA) * A_STAGE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const long long m = m_begin + (long long)t * BM + r0 + i * 32;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned off = m < m_end ? (unsigned)((unsigned long long)m * (unsigned long long)p.ldx + ks * 64 + kcl * CH) * 2u : HDU_OOB;
+        hdu_bufload_lds16(xsrd, off, As + ks * A_SLAB + (i * 32 + wave * 8) * 128);
+      }
+    }
+  };
+#pragma unroll
+  for (int pre = 0; pre < NSA - 1; ++pre)
+    if (pre < ntiles) issue_tile(pre);
+
+  T* __restrict__ yp = (T*)p.y;
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t (and, the first time, the filter rows: older than every tile) has landed once at most the DMAs of ONE
+    // younger tile are outstanding.  The epilogue's global stores share the counter: they only make the wait more
+    // conservative (the bound below holds whether or not stores retire in order with the loads).
+    if (t + 1 < ntiles) hdu_wait_vmcnt_n<LA>(); else hdu_wait_vmcnt_n<0>();
+    HDU_RAW_BARRIER();
+    if (t + NSA - 1 < ntiles) issue_tile(t + NSA - 1);      // refills the slot tile t-1 was read from (all reads are behind the barrier)
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* At = Aring + (t % NSA) * A_STAGE;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const char* As = At + ks * A_SLAB;
+      const char* Bs = Bsm + ks * B_SLAB;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        u32x4 af[TM], bf[TN];
+        const int chunk = kg * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(As + lds_chunk_off(wm * WM + i * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(Bs + lds_chunk_off(wn * WN + j * 16 + (lane & 15), chunk));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // swapped: a lane holds 4 channels of one pixel
+      }
+    }
+    // ---- epilogue of the tile: this wave's 32 x WN patch through its own LDS rows, out as 16-byte chunks of full lines
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        Chunk<T>::store4((T*)(stg + (i * 16 + (lane & 15)) * CROWB) + j * 16 + (lane >> 4) * 4, v);
+      }
+    HDU_WAVE_LDS_SYNC();
+    constexpr int NCC = WN / CH;                       // 16-byte chunks per patch row
+#pragma unroll
+    for (int it = 0; it < WM * NCC / 64; ++it) {
+      const int q = lane + it * 64;
+      const int row = q / NCC, cc = q % NCC;
+      const long long m = m_begin + (long long)t * BM + wm * WM + row;
+      const int n = n0 + wn * WN + cc * CH;
+      const u32x4 v = *(const u32x4*)(stg + row * CROWB + cc * 16);
+      if (m < m_end && n < p.Cout) *(u32x4*)(yp + m * p.ldy + n) = v;
+    }
+    HDU_WAVE_LDS_SYNC();                               // (the patch is rewritten only after the next tile's barrier + MFMAs)
+  }
+}
+
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
 // PW = point-wise (1x1x1, stride 1, no padding, no up-sampling): input pixel == output pixel, so the per-row
 // (n, d, h, w) decode, the tap bounds tests and the per-step carry loops disappear from the K loop.
@@ -2479,11 +2606,39 @@ static void launch_halo_fprop(const ConvK& k, hipStream_t s) {
   HDU_LAUNCH((conv_halo_fprop_kernel<BN>), dim3(tiles, (unsigned)((k.Cout + BN - 1) / BN)), dim3(256), 0, s, k);
 }
 
+// filter-stationary streaming form (conv_pw_bstat_kernel): plain pointwise launches with a 2- or 3-step contraction and at
+// least two 128-channel output groups -- the bottleneck data gradients
+static bool pw_bstat_ok(const ConvK& k, int dtype) {
+  return dtype == HDU_BF16 && !g_tuning[HDU_TUNE_NO_PW_BSTAT] && k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 &&
+         (k.pd | k.ph | k.pw) == 0 && (k.ud | k.uh | k.uw) == 0 && k.pro_a == nullptr && k.skip == nullptr && k.bias == nullptr &&
+         k.epi_a == nullptr && k.stats_partial == nullptr && k.bnb_u == nullptr && !k.accumulate && k.drop_scale == 0.f &&
+         (k.Ktot == 128 || k.Ktot == 192) && k.Cout >= 256 && k.M >= 64 && k.x_bytes != 0 &&
+         (long long)k.Cout * k.Ktot * 2 < (1ll << 31) && k.Do == k.De && k.Ho == k.He && k.Wo == k.We;
+}
+
+static void launch_pw_bstat(const ConvK& k, hipStream_t s) {
+  constexpr int BN = 128;
+  const unsigned ny = (unsigned)((k.Cout + BN - 1) / BN);
+  const int target = g_tuning[HDU_TUNE_PW_BSTAT_WGS] > 0 ? g_tuning[HDU_TUNE_PW_BSTAT_WGS] : 256;      // one workgroup per CU (138 KB of LDS)
+  long long splits = target / (long long)ny;
+  if (splits < 1) splits = 1;
+  const long long tiles = (k.M + 63) / 64;
+  if (splits > tiles) splits = tiles;
+  const long long rows = ((tiles + splits - 1) / splits) * 64;
+  const unsigned gx = (unsigned)((k.M + rows - 1) / rows);
+  if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+  else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+}
+
 extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
   ConvK k;
   if (int e = fill_convk(d, &k, false)) return e;
   if (!d->y) return hdu_set_error(HDU_ERR_ARG, "conv_fprop: null output");
   if (k.M == 0) return 0;
+  if (pw_bstat_ok(k, d->dtype)) {
+    launch_pw_bstat(k, (hipStream_t)stream);
+    return hdu_check_launch("conv_fprop(pointwise, filter-stationary)");
+  }
   if (fprop_halo_ok(k, d->dtype)) {
     switch (choose_halo_bn(k)) {
       case 96: launch_halo_fprop<96>(k, (hipStream_t)stream); break;
@@ -2501,7 +2656,7 @@ extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
 extern "C" size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d) {
   ConvK k;
   if (fill_convk(d, &k, false)) return 0;
-  if (k.M == 0 || fprop_halo_ok(k, d->dtype) || k.pro_a != nullptr || k.skip != nullptr) return 0;
+  if (k.M == 0 || pw_bstat_ok(k, d->dtype) || fprop_halo_ok(k, d->dtype) || k.pro_a != nullptr || k.skip != nullptr) return 0;
   int bm, bn;
   choose_igemm(k, &bm, &bn);
   const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
@@ -2800,6 +2955,8 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     else if (d->dtype == HDU_BF16 && dma) snprintf(buf, buflen, "conv_wgrad_dma_kernel<%d, %s>", choose_wgrad(k), pw ? "true" : "false");
     else if (d->dtype == HDU_BF16) snprintf(buf, buflen, "conv_wgrad_tr_kernel<%d>", choose_wgrad(k));
     else snprintf(buf, buflen, "conv_wgrad_kernel<float, %d>", choose_wgrad(k));
+  } else if (pw_bstat_ok(k, d->dtype)) {
+    snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 128>", k.Ktot / 64);
   } else if (fprop_halo_ok(k, d->dtype)) {
     snprintf(buf, buflen, "conv_halo_fprop_kernel<%d>", choose_halo_bn(k));
   } else {

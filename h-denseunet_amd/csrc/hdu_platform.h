@@ -222,6 +222,14 @@ __device__ __forceinline__ void hdu_bufload_lds16(const hdu_bufsrd& r, unsigned 
 #define HDU_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
 
+// LDS hand-off INSIDE one wave (lane A writes, lane B of the same wave reads): a wave's DS instructions execute in order, so
+// the data is there once the writes have been issued and counted down; no workgroup barrier needed
+#ifdef HDU_EMU
+#define HDU_WAVE_LDS_SYNC() hipemu::wave_barrier()
+#else
+#define HDU_WAVE_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 // keeps the instruction scheduler from sinking a group of hoisted loads back towards their uses
 #ifdef HDU_EMU
 #define HDU_SCHED_BARRIER() do { } while (0)

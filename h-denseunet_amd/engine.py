@@ -181,9 +181,6 @@ class Ctx:
         # (ops.WgradPlan); bf16 + materialised inputs only; off under depth sharding / bucketed data parallelism
         self.batch_wgrad = os.environ.get("HDU_BATCH_WGRAD", "1") == "1"
         self.wgrad_plan = None
-        self._wgrad_cuts = []
-        self.wgrad_overlap_default = "0"
-        self._side_stream = None
         # batch statistics of a conv output taken in the conv's epilogue (hdu_conv_desc.stats_*) instead of a separate
         # reduction pass; the StatsOp then only runs hdu_bn_stats_finalize over the 32 slot rows
         self.epilogue_stats = os.environ.get("HDU_EPILOGUE_STATS", "1") == "1"
@@ -296,15 +293,6 @@ class Ctx:
                 (self.shard is None or self.shard.world == 1)):
             return
         plan = ops.WgradPlan(int(os.environ.get("HDU_BATCH_WGRAD_TARGET", "0")))
-        # Overlap (HDU_WGRAD_OVERLAP = fractions of the backward pass, e.g. "0.35,0.7"; "0" = off): the backward pass is cut at
-        # those positions; when a segment has run, the filter gradients of ITS layers go out on a second stream and fill
-        # the compute units the next segment's chain of small dependent launches leaves idle (measured: the kernels of a
-        # 2D step run back to back -- sum of kernel times == step time -- while the dense blocks at 1/16 and 1/32
-        # resolution occupy a fraction of the chip)
-        n = len(self.bwd)
-        spec = os.environ.get("HDU_WGRAD_OVERLAP", self.wgrad_overlap_default)
-        fr = sorted(float(v) for v in spec.split(",") if v.strip() and float(v) > 0.0)
-        self._wgrad_cuts = sorted(set(min(n - 1, max(1, int(round(f * n)))) for f in fr if f < 1.0)) if n > 2 else []
         for cv in self.convs:
             if not (cv.trainable and cv.out.root.needs_grad):
                 continue
@@ -314,9 +302,7 @@ class Ctx:
                 d = ops.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up)
             else:
                 continue                    # fused prologue: per-layer launch
-            pos = n - 1 - cv.bwd_index                       # position of this layer's backward in execution order
-            grp = sum(1 for c in self._wgrad_cuts if c <= pos)   # launched at the first cut AFTER its backward has run
-            plan.add(d, cv.kernel.grad, grp)
+            plan.add(d, cv.kernel.grad)
             cv.in_plan = True
         if len(plan):
             plan.finalize()
@@ -482,31 +468,10 @@ class Ctx:
             if self.fuse_bn_bwd_now and self._zeroed_bwd_pass != self.pass_id and self._zp_bwd is not None:
                 self._zp_bwd.run()
         order = list(reversed(self.bwd))
-        plan = self.wgrad_plan
-        overlap = plan is not None and plan.ngroups > 1 and seg is None and not ops._l.is_emulator()
-        g = 0
-        for pos in range(lo, hi):
-            if overlap:
-                while g < len(self._wgrad_cuts) and self._wgrad_cuts[g] == pos:
-                    self._launch_wgrad_group(g)
-                    g += 1
-            order[pos]()
-        if hi == len(self.bwd) and plan is not None:
-            if overlap:
-                for gg in range(g, plan.ngroups):
-                    self._launch_wgrad_group(gg)
-                torch.cuda.current_stream().wait_stream(self._side_stream)      # join before the optimiser / all-reduce
-            else:
-                plan.run()
-
-    def _launch_wgrad_group(self, g):
-        """filter gradients of backward segment g on the second stream (fork: everything issued so far on the main stream)"""
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
-        side = self._side_stream
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self.wgrad_plan.run(group=g)
+        for f in order[lo:hi]:
+            f()
+        if hi == len(self.bwd) and self.wgrad_plan is not None:
+            self.wgrad_plan.run()
 
     def grad_buckets(self, fractions):
         """Cut the backward pass where the first-completed `fractions` of the trainable parameters have their final
@@ -731,7 +696,6 @@ class ConvLayer:
                 self._dz = ctx.scratch("dz", xa.N, xa.D + 2 * halo, xa.H, xa.W, cin_p)
         ctx.fwd.append(self.forward)
         ctx.bwd.append(self.backward)
-        self.bwd_index = len(ctx.bwd) - 1
 
     # ---- bound after Ctx.finalize()
     def bind(self):

@@ -216,6 +216,10 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(3, int(os.environ["HDU_XCD_SWIZZLE"]))
     if "HDU_WGRAD_TARGET" in os.environ:
         lib.hdu_set_tuning(2, int(os.environ["HDU_WGRAD_TARGET"]))
+    if "HDU_NO_PW_BSTAT" in os.environ:
+        lib.hdu_set_tuning(19, int(os.environ["HDU_NO_PW_BSTAT"]))
+    if "HDU_PW_BSTAT_WGS" in os.environ:
+        lib.hdu_set_tuning(20, int(os.environ["HDU_PW_BSTAT_WGS"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
         lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
 

@@ -149,30 +149,28 @@ def conv_wgrad(d, dw):
 
 
 class WgradPlan:
-    """Deferred, batched filter gradients (hdu_wgrad_plan_*): add(desc, dw[, group]) for every layer at build time, run()
-    once per backward pass.  One launch per kernel family (and group); tables live in device memory (uploaded once).
-    Groups: the engine may cut the backward pass into segments and launch the filter gradients of a finished segment on
-    a second stream while the next segment's (latency-bound) chain runs -- engine.Ctx.run_backward."""
+    """Deferred, batched filter gradients (hdu_wgrad_plan_*): add(desc, dw) for every layer at build time, run() once
+    per backward pass.  One launch per kernel family; tables live in device memory (uploaded once).  (Launching the plan in
+    groups on a second stream while the backward chain continues was measured slower in rounds 1 and 3:
+    profiles/r03_experiment_wgrad_side_stream_overlap.txt.)"""
 
     def __init__(self, target_wgs=0):
         self.target = target_wgs
-        self.by_variant = {}           # (group, variant) -> [(entry bytes, blocks)]
-        self.descs = {}                # variant -> descriptors of all groups (bench.py: FLOPs of a family)
+        self.by_variant = {}
+        self.descs = {}
         self.tables = None
         self.keep = []            # descriptors (and the tensors they point to) must outlive the plan
-        self.ngroups = 1
 
-    def add(self, d, dw, group=0):
+    def add(self, d, dw):
         lib = _l.get()
         nb = lib.hdu_wgrad_plan_entry_bytes()
         ent = (ctypes.c_ubyte * nb)()
         variant, nblk = ctypes.c_int(0), ctypes.c_uint32(0)
         check(lib.hdu_wgrad_plan_fill(ctypes.byref(d), fptr(dw), self.target, ctypes.cast(ent, ctypes.c_void_p),
                                       ctypes.byref(variant), ctypes.byref(nblk)), "hdu_wgrad_plan_fill")
-        self.by_variant.setdefault((group, variant.value), []).append((bytes(ent), nblk.value))
+        self.by_variant.setdefault(variant.value, []).append((bytes(ent), nblk.value))
         self.descs.setdefault(variant.value, []).append(d)       # (bench.py: algorithmic FLOPs of a batched launch)
         self.keep.append((d, dw))
-        self.ngroups = max(self.ngroups, group + 1)
         self.tables = None
 
     def __len__(self):
@@ -181,7 +179,7 @@ class WgradPlan:
     def finalize(self):
         import numpy as np
         self.tables = []
-        for (group, variant), ents in sorted(self.by_variant.items()):
+        for variant, ents in sorted(self.by_variant.items()):
             raw = np.frombuffer(b"".join(e for e, _ in ents), dtype=np.uint8).copy()
             begins = np.zeros(len(ents), dtype=np.uint32)
             tot = 0
@@ -189,19 +187,15 @@ class WgradPlan:
                 begins[i] = tot
                 tot += nb
             assert tot < 2 ** 31
-            self.tables.append((group, variant, torch.from_numpy(raw).to(device()),
+            self.tables.append((variant, torch.from_numpy(raw).to(device()),
                                 torch.from_numpy(begins.view(np.int32)).to(device()), len(ents), tot))
 
-    def run(self, around=None, group=None):
-        """around(variant, launch): optional hook that performs the launch itself (bench.py brackets it with events);
-        group: only that group's launches (None = all)"""
+    def run(self, around=None):
+        """around(variant, launch): optional hook that performs the launch itself (bench.py brackets it with events)"""
         if self.tables is None:
             self.finalize()
         lib = _l.get()
-        for grp, variant, tab, begins, n, tot in self.tables:
-            if group is not None and grp != group:
-                continue
-
+        for variant, tab, begins, n, tot in self.tables:
             def launch(variant=variant, tab=tab, begins=begins, n=n, tot=tot):
                 check(lib.hdu_wgrad_plan_run(variant, ctypes.c_void_p(tab.data_ptr()), ctypes.c_void_p(begins.data_ptr()), n,
                                              tot, stream()), "hdu_wgrad_plan_run")

@@ -67,6 +67,8 @@ size_t hdu_sizeof_conv_desc(void);
 #define HDU_TUNE_HALO_MIN_TILES 15   /* the halo-tile forward kernel needs this many 4x32-pixel tiles (default 128) */
 #define HDU_TUNE_RING_MIN_K 14       /* small grids use the deep LDS ring when Ktot > this (default 0: always) */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
+#define HDU_TUNE_NO_PW_BSTAT 19      /* 1 = disable the filter-stationary pointwise kernel (A/B) */
+#define HDU_TUNE_PW_BSTAT_WGS 20     /* workgroups that kernel aims for (default 256) */
 int hdu_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------ convolution

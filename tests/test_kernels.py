@@ -97,6 +97,10 @@ CONV_CASES = [
     dict(N=1, D=1, H=130, W=128, Cin=8, Cout=128, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="tile128x128_ragged_m"),
     dict(N=2, D=1, H=10, W=37, Cin=64, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=96, ldout=64, id="halo_tile_ragged_slab"),
     dict(N=1, D=1, H=8, W=64, Cin=32, Cout=64, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="halo_tile_exact"),
+    # the filter-stationary pointwise kernel (bf16: K = 192 / 128, no prologue / bias, >= 256 output channels): ragged pixel
+    # count, a channel count that is not a multiple of its 128-channel groups, slab input and output
+    dict(N=2, D=1, H=13, W=11, Cin=192, Cout=328, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=208, ldout=344, id="pw_bstat_k192_ragged"),
+    dict(N=1, D=3, H=9, W=10, Cin=128, Cout=256, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="pw_bstat_k128_3d"),
 ]
 
 
