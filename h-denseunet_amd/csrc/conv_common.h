@@ -50,6 +50,7 @@ struct ConvK {
   // split-K (ring kernel): gridDim.z workgroups share one output tile; partial accumulators meet in sk_ws
   float* sk_ws;               // [tile][split][wave][fragment][lane] f32x4, write-through stores
   unsigned* sk_cnt;           // [tile] arrival tickets, zero between launches
+  long long M_layer;          // hdu_conv_desc.layer_rows (>= M): output pixels of the whole layer this launch is part of (host-side decisions only)
 };
 
 __device__ __forceinline__ unsigned hdu_fastdiv(unsigned n, unsigned mul, unsigned shr) {

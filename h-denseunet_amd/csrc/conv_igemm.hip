@@ -2441,6 +2441,7 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad, bool exact_g
   if (((uintptr_t)k->bias | (uintptr_t)k->epi_a | (uintptr_t)k->epi_b | (uintptr_t)(k->stats_partial ? k->stats_shift : nullptr) |
        (uintptr_t)k->bnb_a | (uintptr_t)k->bnb_b | (uintptr_t)k->bnb_mean | (uintptr_t)k->bnb_rstd) & 15)
     return hdu_set_error(HDU_ERR_ARG, "conv: bias / epi_* / stats_shift / bnb_* vectors must be 16-byte aligned");
+  k->M_layer = d->layer_rows > 0 ? d->layer_rows : k->M;
   k->sk_ws = wgrad ? nullptr : (float*)d->splitk_ws;
   k->sk_cnt = wgrad ? nullptr : d->splitk_counters;
   if (k->sk_ws && ((uintptr_t)k->sk_ws % 16 || !k->sk_cnt))
@@ -2495,12 +2496,14 @@ static void launch_igemm(const ConvK& k, size_t sk_bytes_avail, hipStream_t s) {
     constexpr int STAGE = (BM + ((BN + 31) / 32) * 32) * 128;
     constexpr int NSD = STAGE * 6 <= 160 * 1024 ? 6 : 4;
     const long long nblk = (long long)grid.x * grid.y;
+    const long long nblk_layer = (long long)((k.M_layer + BM - 1) / BM) * grid.y;     // the whole (unsharded) layer's grid
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
     const bool fast = igemm_fast_ok(k);
-    if (igemm_ring_ok(nblk, k.Ktot, STAGE, NSD)) {
+    if (igemm_ring_ok(nblk_layer, k.Ktot, STAGE, NSD)) {
       constexpr int BK = 8 * Chunk<T>::CH;
       size_t need;
-      const int S = choose_splitk(nblk, (k.Ktot + BK - 1) / BK, BM, BN, ring_wgs_per_cu(BM, sizeof(T) == 2), &need);
+      const int S = choose_splitk(nblk_layer, (k.Ktot + BK - 1) / BK, BM, BN, ring_wgs_per_cu(BM, sizeof(T) == 2), &need);
+      need = need / (size_t)nblk_layer * (size_t)nblk;                  // scratch for THIS launch's tiles
       ConvK kk = k;
       if (S > 1 && k.sk_ws && k.sk_cnt && need <= sk_bytes_avail && nblk <= 512) {      // (512 ticket counters)
         grid.z = (unsigned)S;
@@ -2547,7 +2550,7 @@ static void choose_igemm(const ConvK& k, int* bm, int* bn) {
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
   }
   *bn = best;
-  *bm = (k.M <= (g_tuning[HDU_TUNE_BM64_MAX_M] > 0 ? (long long)g_tuning[HDU_TUNE_BM64_MAX_M] : 16384)) ? 64 : 128;
+  *bm = (k.M_layer <= (g_tuning[HDU_TUNE_BM64_MAX_M] > 0 ? (long long)g_tuning[HDU_TUNE_BM64_MAX_M] : 16384)) ? 64 : 128;
 }
 
 template <int BM, int BN> struct WaveLayout {           // (waves along M, waves along N)
@@ -2585,7 +2588,8 @@ static bool fprop_halo_ok(const ConvK& k, int dtype) {
          k.Cin >= 128 && k.Cout <= 96 &&
          // ... and when its 4x32-pixel tiles fill the chip: below that the im2col ring kernel with split-K spreads the
          // layer over more compute units (each halo workgroup has to pull the whole 9-tap filter tile)
-         (long long)k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32) >= (g_tuning[HDU_TUNE_HALO_MIN_TILES] > 0 ? g_tuning[HDU_TUNE_HALO_MIN_TILES] : 128);
+         // (a depth shard decides for the whole layer, like the split-K count: hdu_conv_desc.layer_rows)
+         (long long)k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32) * k.M_layer / k.M >= (g_tuning[HDU_TUNE_HALO_MIN_TILES] > 0 ? g_tuning[HDU_TUNE_HALO_MIN_TILES] : 128);
 }
 
 static int choose_halo_bn(const ConvK& k) {
@@ -2660,13 +2664,14 @@ extern "C" size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d) {
   int bm, bn;
   choose_igemm(k, &bm, &bn);
   const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
+  const long long nblk_layer = ((k.M_layer + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
   const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
   const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;
-  if (!igemm_ring_ok(nblk, k.Ktot, stage, nsd)) return 0;
+  if (!igemm_ring_ok(nblk_layer, k.Ktot, stage, nsd)) return 0;
   const int bk = d->dtype == HDU_BF16 ? 64 : 32;
   size_t need;
-  choose_splitk(nblk, (k.Ktot + bk - 1) / bk, bm, bn, ring_wgs_per_cu(bm, d->dtype == HDU_BF16), &need);
-  return need;
+  choose_splitk(nblk_layer, (k.Ktot + bk - 1) / bk, bm, bn, ring_wgs_per_cu(bm, d->dtype == HDU_BF16), &need);
+  return need / (size_t)nblk_layer * (size_t)nblk;
 }
 
 template <typename T, int BCO>
@@ -2964,7 +2969,7 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     choose_igemm(k, &bm, &bn);
     const int wm = (bn >= 128) ? 2 : ((bm == 64 && (bn == 64 || bn == 32)) ? 2 : 4);
     const bool dma = k.pro_a == nullptr && k.skip == nullptr && k.vec_out;
-    const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
+    const long long nblk = ((k.M_layer + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
     const int mode = g_tuning[HDU_TUNE_DMA_STAGES];
     const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
     const int nsd = stage * 6 <= 160 * 1024 ? 6 : 4;

@@ -24,6 +24,51 @@ struct FinK {
   const float* mean_in; float* corr3; float* corr4;
 };
 
+// Sum of (a1, a2) over the 32 "partial lanes" of a channel in the 8-channel x 32-lane finalize geometry (thread = pl * 8 + cl):
+// three xor-shuffles inside each wave (lanes 8 apart share a channel), then ONE barrier for the four waves -- the result is
+// valid in the threads with pl == 0.  (Round 2 used a 5-step LDS tree with 6 barriers: ~0.5 us of a 4.8 us launch.)
+__device__ __forceinline__ void fin_reduce32(double& a1, double& a2, double (*red)[4][8]) {
+  const int cl = threadIdx.x & 7, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int mask = 8; mask < 64; mask <<= 1) {
+    a1 += __shfl_xor(a1, mask);
+    a2 += __shfl_xor(a2, mask);
+  }
+  if ((threadIdx.x & 63) < 8) { red[0][wave][cl] = a1; red[1][wave][cl] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    a1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    a2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+
+// per-channel parameters of a finalize launch, requested at kernel ENTRY by the thread that will use them (pl == 0) so that
+// they travel together with the partial sums instead of behind them (one memory round trip less per launch)
+struct FinPre { float g, be, sg, sb, mm, mv, rs, mu; };
+__device__ __forceinline__ FinPre fin_prefetch(const FinK& fin, int c, bool use) {
+  FinPre q;
+  q.g = (use && fin.gamma) ? fin.gamma[c] : 1.f;
+  q.be = (use && fin.beta) ? fin.beta[c] : 0.f;
+  q.sg = (use && fin.sgamma) ? fin.sgamma[c] : 1.f;
+  q.sb = (use && fin.sbeta) ? fin.sbeta[c] : 0.f;
+  q.mm = (use && fin.mov_mean) ? fin.mov_mean[c] : 0.f;
+  q.mv = (use && fin.mov_var) ? fin.mov_var[c] : 0.f;
+  q.rs = (use && fin.rstd_in) ? fin.rstd_in[c] : 0.f;
+  q.mu = (use && fin.mean_in) ? fin.mean_in[c] : 0.f;
+  return q;
+}
+
+// bn_fold_channel with prefetched parameters
+__device__ __forceinline__ void bn_fold_channel_pre(int c, float mu, float v, const FinK& fin, const FinPre& q) {
+  const float r = 1.0f / sqrtf(v + fin.eps);
+  const float inv = q.g * r;
+  fin.a[c] = q.sg * inv;
+  fin.b[c] = q.sg * (q.be - mu * inv) + q.sb;
+  if (fin.rstd) fin.rstd[c] = r;
+  if (fin.mov_mean) fin.mov_mean[c] = q.mm - (q.mm - mu) * (1.f - fin.momentum);
+  if (fin.mov_var) fin.mov_var[c] = q.mv - (q.mv - v) * (1.f - fin.momentum);
+}
+
 // tf.nn.batch_normalization: x*(g*r) + (beta - mu*g*r); Scale on top: sg*y + sb
 __device__ __forceinline__ void bn_fold_coef(int c, float mu, float v, const float* gamma, const float* beta, float eps,
                                              const float* sgamma, const float* sbeta, float* a, float* b, float* r_out) {
@@ -72,7 +117,7 @@ __device__ __forceinline__ void bn_coef_channel(int c, float invM, int batch_sta
 // one channel's totals -> outputs (+ the optional BN fold / BN-backward-coefficient epilogue)
 template <typename T, int MODE>
 __device__ __forceinline__ void finalize_channel(int c, double a1, double a2, long long M, const void* x, float* o1,
-                                                 float* o2, const FinK& fin) {
+                                                 float* o2, const FinK& fin, const FinPre& pre) {
   if (MODE == 0) {   // RED_STATS
     const double shift = fin.shift_f32 ? (double)fin.shift_f32[c] : (double)Chunk<T>::load1((const T*)x + c);
     const double m1 = a1 / (double)M;
@@ -80,24 +125,25 @@ __device__ __forceinline__ void finalize_channel(int c, double a1, double a2, lo
     if (var < 0.0) var = 0.0;
     o1[c] = (float)(shift + m1);
     o2[c] = (float)var;
-    if (fin.kind == 1)
-      bn_fold_channel(c, (float)(shift + m1), (float)var, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a,
-                      fin.b, fin.rstd, fin.mov_mean, fin.mov_var, fin.momentum);
+    if (fin.kind == 1) bn_fold_channel_pre(c, (float)(shift + m1), (float)var, fin, pre);
   } else {
     if (o1) o1[c] = (float)a1;
     if (o2) o2[c] = (float)a2;
-    if (MODE == 1 && fin.kind == 2)   // RED_BNBWD
-      bn_coef_channel(c, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma, fin.beta, fin.sgamma, fin.rstd_in,
-                      fin.k1, fin.k2, fin.k3, fin.dgamma, fin.dbeta, fin.dsgamma, fin.dsbeta);
-    if (MODE == 1 && fin.kind == 3) {
-      float k1, k2, k3;
-      bn_coef_channel(0, fin.invM, fin.batch_stats, (float)a1, (float)a2, fin.gamma ? fin.gamma + c : nullptr,
-                      fin.beta ? fin.beta + c : nullptr, fin.sgamma ? fin.sgamma + c : nullptr, fin.rstd_in + c, &k1, &k2,
-                      &k3, fin.dgamma ? fin.dgamma + c : nullptr, fin.dbeta ? fin.dbeta + c : nullptr,
-                      fin.dsgamma ? fin.dsgamma + c : nullptr, fin.dsbeta ? fin.dsbeta + c : nullptr);
-      if (fin.batch_stats) {
+    if (MODE == 1 && (fin.kind == 2 || fin.kind == 3)) {   // RED_BNBWD: coefficients + parameter gradients (prefetched parameters)
+      const float S1 = (float)a1, S2 = (float)a2;
+      const float kk = pre.sg * pre.g * pre.rs;
+      const float k2 = fin.batch_stats ? kk * S1 * fin.invM : 0.f;
+      const float k3 = fin.batch_stats ? kk * pre.rs * S2 * fin.invM : 0.f;
+      // y = g*xhat + beta ; z = sg*y + sb :  d sg = sum g_s*y = g*S2 + beta*S1 ; d sb = S1 ; d g = sg*S2 ; d beta = sg*S1
+      if (fin.dgamma) fin.dgamma[c] = pre.sg * S2;
+      if (fin.dbeta) fin.dbeta[c] = pre.sg * S1;
+      if (fin.dsgamma) fin.dsgamma[c] = pre.g * S2 + pre.be * S1;
+      if (fin.dsbeta) fin.dsbeta[c] = S1;
+      if (fin.kind == 2) {
+        fin.k1[c] = kk; fin.k2[c] = k2; fin.k3[c] = k3;
+      } else if (fin.batch_stats) {      // kind 3: the deferred part of du, accumulated per stored channel
         fin.corr3[c] += k3;
-        fin.corr4[c] += k3 * fin.mean_in[c] - k2;
+        fin.corr4[c] += k3 * pre.mu - k2;
       }
     }
   }
@@ -210,9 +256,10 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                               long long M, const void* x, float* __restrict__ o1,
                                                               float* __restrict__ o2, FinK fin) {
-  __shared__ double red[2][32][8];
+  __shared__ double red[2][4][8];
   const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
+  const FinPre pre = fin_prefetch(fin, c < C ? c : 0, pl == 0 && c < C && fin.kind != 0);
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
     int b = pl;
@@ -232,21 +279,8 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __res
       if (MODE != RED_COLSUM) a2 += (double)partial[((long long)b * 2 + 1) * C + c];
     }
   }
-  red[0][pl][cl] = a1;
-  red[1][pl][cl] = a2;
-  __syncthreads();
-  for (int s = 16; s > 0; s >>= 1) {
-    if (pl < s) {
-      red[0][pl][cl] += red[0][pl + s][cl];
-      red[1][pl][cl] += red[1][pl + s][cl];
-    }
-    __syncthreads();
-  }
-  if (pl == 0 && c < C) {
-    a1 = red[0][0][cl];
-    a2 = red[1][0][cl];
-    finalize_channel<T, MODE>(c, a1, a2, M, x, o1, o2, fin);
-  }
+  fin_reduce32(a1, a2, red);
+  if (pl == 0 && c < C) finalize_channel<T, MODE>(c, a1, a2, M, x, o1, o2, fin, pre);
 }
 
 static int red_cols_for(int nchunks) {
@@ -367,13 +401,18 @@ __global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __
                                                                  int seg_c0, int C_all, long long M,
                                                                  float* __restrict__ mean_all, float* __restrict__ var_all,
                                                                  FinK fin) {
-  __shared__ double red[2][32][8];
+  __shared__ double red[2][4][8];
   const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   const bool in_seg = c >= seg_c0 && c < seg_c0 + Cseg;
   const bool wg_has_seg = (int)blockIdx.x * 8 + 7 >= seg_c0 && (int)blockIdx.x * 8 < seg_c0 + Cseg;   // workgroup-uniform
+  const bool mine = pl == 0 && c < C_all;
+  // everything this thread will need is requested up front: parameters, the stored moments, its slot rows
+  const FinPre pre = fin_prefetch(fin, mine ? c : 0, mine);
+  const float mean_old = mine ? mean_all[c] : 0.f;
+  const float var_old = mine ? var_all[c] : 0.f;
+  double a1 = 0.0, a2 = 0.0;
   if (wg_has_seg) {
-    double a1 = 0.0, a2 = 0.0;
     if (in_seg) {
       const int cs = c - seg_c0;
       for (int b = pl; b < slots; b += 32) {
@@ -381,33 +420,23 @@ __global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __
         a2 += (double)partial[((long long)b * 2 + 1) * Cseg + cs];
       }
     }
-    red[0][pl][cl] = a1;
-    red[1][pl][cl] = a2;
-    __syncthreads();
-    for (int s = 16; s > 0; s >>= 1) {
-      if (pl < s) {
-        red[0][pl][cl] += red[0][pl + s][cl];
-        red[1][pl][cl] += red[1][pl + s][cl];
-      }
-      __syncthreads();
-    }
+    fin_reduce32(a1, a2, red);
   }
-  if (pl != 0 || c >= C_all) return;
+  if (!mine) return;
   float mu, v;
   if (in_seg) {
-    const double m1 = red[0][0][cl] / (double)M;
-    double var = red[1][0][cl] / (double)M - m1 * m1;
+    const double m1 = a1 / (double)M;
+    double var = a2 / (double)M - m1 * m1;
     if (var < 0.0) var = 0.0;
-    mu = (float)((double)mean_all[c] + m1);          // the epilogue's shift is the previous pass's mean (same array)
+    mu = (float)((double)mean_old + m1);             // the epilogue's shift is the previous pass's mean (same array)
     v = (float)var;
     mean_all[c] = mu;
     var_all[c] = v;
   } else {
-    mu = mean_all[c];
-    v = var_all[c];
+    mu = mean_old;
+    v = var_old;
   }
-  bn_fold_channel(c, mu, v, fin.gamma, fin.beta, fin.eps, fin.sgamma, fin.sbeta, fin.a, fin.b, fin.rstd, fin.mov_mean,
-                  fin.mov_var, fin.momentum);
+  bn_fold_channel_pre(c, mu, v, fin, pre);
 }
 
 extern "C" int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, int Cseg, int seg_c0, int C_all,
@@ -539,33 +568,53 @@ extern "C" int hdu_bn_bwd_coef(int C, int64_t M, int batch_stats, const float* s
   return hdu_check_launch("bn_bwd_coef");
 }
 
-// sync-BN of a depth-sharded volume (shard.py): local (mean, biased var) over n_local pixels -> (n*mean, n*(var+mean^2))
-// for the all-reduce, and back to the statistics of the whole volume
-__global__ __launch_bounds__(256) void stats_pack_kernel(int C, const float* mean, const float* var, float n_local, float* buf) {
+// sync-BN of a depth-sharded volume (shard.py).  Every rank writes (n_i, mean_i, var_i) into ITS slot of a zeroed
+// [world][1 + 2C] table; a sum all-reduce of the table is then an all-gather (x + 0 is exact), and every rank combines the
+// slots in rank order with the pairwise-moments formula
+//     mean = sum n_i mean_i / N,    var = sum n_i (var_i + (mean_i - mean)^2) / N
+// -- no E[x^2] - E[x]^2: round 2 all-reduced (n mean, n (var + mean^2)) and subtracted mean^2 afterwards, which loses
+// mean^2 / var relative precision in float32 (a channel with |mean| = 30 sigma: 1e-4 of its variance, amplified by every
+// BatchNormalization behind it -- found by tests/test_depth_shard_gloo.py[3dpart] in round 3).
+__global__ __launch_bounds__(256) void stats_pack_kernel(int C, const float* mean, const float* var, float n_local, int rank,
+                                                         int world, float* buf) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int SL = 1 + 2 * C;
   if (c >= C) return;
-  const float m = mean[c];
-  buf[c] = m * n_local;
-  buf[C + c] = (var[c] + m * m) * n_local;
+  for (int r = 0; r < world; ++r) {
+    const bool mine = r == rank;
+    if (c == 0) buf[r * SL] = mine ? n_local : 0.f;
+    buf[r * SL + 1 + c] = mine ? mean[c] : 0.f;
+    buf[r * SL + 1 + C + c] = mine ? var[c] : 0.f;
+  }
 }
-__global__ __launch_bounds__(256) void stats_unpack_kernel(int C, const float* buf, float inv_n_global, float* mean, float* var) {
+__global__ __launch_bounds__(256) void stats_unpack_kernel(int C, const float* buf, int world, float* mean, float* var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int SL = 1 + 2 * C;
   if (c >= C) return;
-  const float m = buf[c] * inv_n_global;
-  const float v = buf[C + c] * inv_n_global - m * m;
+  float N = 0.f, m = 0.f;
+  for (int r = 0; r < world; ++r) { N += buf[r * SL]; m += buf[r * SL] * buf[r * SL + 1 + c]; }
+  m /= N;
+  float v = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float d = buf[r * SL + 1 + c] - m;
+    v += buf[r * SL] * (buf[r * SL + 1 + C + c] + d * d);
+  }
   mean[c] = m;
-  var[c] = v > 0.f ? v : 0.f;
+  var[c] = v / N;
 }
-extern "C" int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, float* buf, void* stream) {
-  if (C <= 0 || !mean || !var || !buf || n_local <= 0) return hdu_set_error(HDU_ERR_ARG, "stats_pack: bad args");
+extern "C" size_t hdu_stats_sync_floats(int C, int world) { return (size_t)world * (1 + 2 * (size_t)C); }
+extern "C" int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, int rank, int world, float* buf,
+                              void* stream) {
+  if (C <= 0 || !mean || !var || !buf || n_local <= 0 || world <= 0 || rank < 0 || rank >= world)
+    return hdu_set_error(HDU_ERR_ARG, "stats_pack: bad args");
   HDU_LAUNCH(stats_pack_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, mean, var,
-             (float)n_local, buf);
+             (float)n_local, rank, world, buf);
   return hdu_check_launch("stats_pack");
 }
-extern "C" int hdu_stats_unpack(int C, const float* buf, int64_t n_global, float* mean, float* var, void* stream) {
-  if (C <= 0 || !mean || !var || !buf || n_global <= 0) return hdu_set_error(HDU_ERR_ARG, "stats_unpack: bad args");
-  HDU_LAUNCH(stats_unpack_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, buf,
-             1.0f / (float)n_global, mean, var);
+extern "C" int hdu_stats_unpack(int C, const float* buf, int world, float* mean, float* var, void* stream) {
+  if (C <= 0 || !mean || !var || !buf || world <= 0) return hdu_set_error(HDU_ERR_ARG, "stats_unpack: bad args");
+  HDU_LAUNCH(stats_unpack_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, buf, world, mean,
+             var);
   return hdu_check_launch("stats_unpack");
 }
 

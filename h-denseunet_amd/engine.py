@@ -279,6 +279,7 @@ class Ctx:
         self.corr_acc = self.arena[o_corr:o_corr + self._corr_total] if self._corr_total else None
         self._zp_arena = ops.ZeroPlan([self.arena])
         self._zp_bwd = ops.ZeroPlan([self.arena[o_bnb:total]]) if total > o_bnb else None
+        self._desc_scope()
         for cv in self.convs:
             cv.bind()
         self._build_prep_table()
@@ -446,7 +447,12 @@ class Ctx:
             self._fold_plans[phase] = ops.FoldPlan(ents) if ents else None
         return self._fold_plans[phase]
 
+    def _desc_scope(self):
+        """descriptors built from here on belong to this model: a depth shard computes 1/world of every layer"""
+        ops.SHARD_WORLD = self.shard.world if (self.shard is not None and self.shard.world > 1) else 1
+
     def run_forward(self):
+        self._desc_scope()
         self.pass_id += 1
         if self.batch_fold and self.finalized:
             plan = self._fold_plan(self.learning_phase)
@@ -461,6 +467,7 @@ class Ctx:
     def run_backward(self, seg=None):
         """the whole backward pass, or positions [seg[0], seg[1]) of it (in execution order) -- see grad_buckets"""
         lo, hi = seg if seg is not None else (0, len(self.bwd))
+        self._desc_scope()
         if lo == 0:
             for v in self.vars:
                 v.written = False
@@ -921,7 +928,7 @@ def _conv_backward_halo(self, dy):
         ops.conv_dgrad_strided(d)
     else:
         d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
-                          (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]))
+                          (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), halo_out=(2 * h) << self.up[0])
         ops.conv_fprop(d)
     dz = tgt
     if self.up != (0, 0, 0):
@@ -951,7 +958,8 @@ class StatsOp:
         self.ctx, self.var = ctx, var
         self.fused = None
         self.fold_next = None
-        self.sync_buf = ctx.fvec(2 * var.C)
+        world = ctx.shard.world if ctx.shard is not None else 1
+        self.sync_buf = ctx.fvec(world * (1 + 2 * var.C)) if world > 1 else None      # hdu_stats_sync_floats
         ctx.need_ws(var.act.M, var.C)
         var.stats()
         # produced by the conv that was just built?  then its epilogue takes the moments (no reduction pass)
@@ -989,7 +997,7 @@ class StatsOp:
         if ctx.shard is not None and ctx.shard.world > 1:
             # local moments -> global moments over all depth shards (equal shard sizes), then the consumers fold
             ops.bn_stats(self.var.act, mean, var, ctx.ws)
-            _sh.sync_stats(ctx.shard, mean, var, self.var.act.M, self.var.act.M * ctx.shard.world, self.sync_buf)
+            _sh.sync_stats(ctx.shard, mean, var, self.var.act.M, self.sync_buf)
             return
         fold = None
         if bn is not None:

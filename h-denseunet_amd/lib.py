@@ -49,6 +49,7 @@ class ConvDesc(ctypes.Structure):
         ("splitk_ws", c_p),
         ("splitk_ws_bytes", c_sz),
         ("splitk_counters", c_p),
+        ("layer_rows", ctypes.c_int64),
     ]
 
 
@@ -120,8 +121,9 @@ _SIGS = {
                                                 c_p, c_p, c_p, c_p, c_f, c_p]),
     "hdu_bn_stats_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                       c_f, c_p]),
-    "hdu_stats_pack": (c_int, [c_int, c_p, c_p, c_i64, c_p, c_p]),
-    "hdu_stats_unpack": (c_int, [c_int, c_p, c_i64, c_p, c_p, c_p]),
+    "hdu_stats_sync_floats": (c_sz, [c_int, c_int]),
+    "hdu_stats_pack": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_p, c_p]),
+    "hdu_stats_unpack": (c_int, [c_int, c_p, c_int, c_p, c_p, c_p]),
     "hdu_colsum": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_sz, c_p]),
     "hdu_maxpool3s2_fwd": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_p, c_int, c_p]),
     "hdu_maxpool3s2_bwd": (c_int, [c_int, c_p, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_i64, c_int, c_int, c_p]),
@@ -139,6 +141,11 @@ _SIGS = {
     "hdu_cast_out": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
     "hdu_zero_regions": (c_int, [c_p, c_int, c_u32, c_p, c_u32, c_p]),
     "hdu_zero": (c_int, [c_p, ctypes.c_uint64, c_p]),
+    "hdu_comm_unique_id": (c_int, [c_p]),
+    "hdu_comm_init": (c_int, [ctypes.POINTER(c_p), c_int, c_int, c_p]),
+    "hdu_comm_destroy": (c_int, [c_p]),
+    "hdu_comm_allreduce_f32": (c_int, [c_p, c_p, c_i64, c_p]),
+    "hdu_comm_sendrecv": (c_int, [c_p, c_int, c_p, c_p, c_int, c_p, c_p, c_sz, c_p]),
 }
 
 EXPORTS = tuple(_SIGS.keys())

@@ -94,6 +94,9 @@ class Act:
 # Sized for the library's worst case (tile count x 16 splits x 64x128 float32 outputs).
 _SPLITK = None
 SPLITK_BYTES = 320 * 16 * 64 * 128 * 4
+# Number of depth shards the layers of the descriptors built next are split over: the engine sets it while it builds / runs a
+# depth-sharded model (engine.Ctx._desc_scope), 1 otherwise.  conv_desc turns it into hdu_conv_desc.layer_rows.
+SHARD_WORLD = 1
 
 
 def splitk_scratch():
@@ -105,10 +108,13 @@ def splitk_scratch():
 
 
 def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
-              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None, splitk=None):
+              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None, splitk=None, halo_out=0):
     """x: Act (stored input), y: Act (output), K=(KD,KH,KW); epi = (a, b, relu): output affine of the BN that follows;
-    splitk = (float32 scratch tensor of SPLITK_BYTES, int32[512] zeroed counters) for launches on another stream."""
+    splitk = (float32 scratch tensor of SPLITK_BYTES, int32[512] zeroed counters) for launches on another stream;
+    halo_out = depth planes of y that a neighbouring depth shard computes too (data gradient w.r.t. an input with halos)."""
     d = ConvDesc()
+    if SHARD_WORLD > 1:      # the unsharded layer's output pixels: the library decides tiles / split-K for those
+        d.layer_rows = y.N * (y.D - halo_out) * SHARD_WORLD * y.H * y.W
     ws, cnt = splitk if splitk is not None else splitk_scratch()
     d.splitk_ws, d.splitk_ws_bytes, d.splitk_counters = ws.data_ptr(), SPLITK_BYTES, cnt.data_ptr()
     d.dtype = x.dtype

@@ -40,6 +40,15 @@ def attach_data_parallel(model, expected_world=None):
     if world == 1 and os.environ.get("HDU_FORCE_DP") != "1":
         return model
 
+    if os.environ.get("HDU_COMM") == "rccl_abi":
+        # the gradient sum as an hdu_comm_allreduce_f32 call (include/hdu.h) on the compute stream instead of a
+        # torch.distributed collective; the process group is only the rendezvous that carried the RCCL id
+        from .comm import Comm
+        model._comm = Comm.from_process_group()
+        model.set_data_parallel(world, model._comm.allreduce_)
+        broadcast_parameters(model)
+        return model
+
     def allreduce(t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
@@ -83,7 +92,11 @@ def depth_shard_info(backend=None):
     """ShardInfo of this process (one process per GPU / per depth shard)"""
     from .shard import ShardInfo
     rank, world = init_process_group_from_env(backend)
-    return ShardInfo(rank, world)
+    comm = None
+    if world > 1 and os.environ.get("HDU_COMM") == "rccl_abi":      # halo / sync-BN / gradient exchanges as hdu_comm_* calls
+        from .comm import Comm
+        comm = Comm.from_process_group()
+    return ShardInfo(rank, world, comm=comm)
 
 
 def attach_depth_shard(model):
@@ -94,7 +107,10 @@ def attach_depth_shard(model):
         return model
 
     def allreduce(t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
+        if sh.comm is not None:
+            sh.comm.allreduce_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
 
     model.set_data_parallel(sh.world, allreduce)
     broadcast_parameters(model)

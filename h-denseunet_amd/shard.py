@@ -19,8 +19,10 @@ import torch.distributed as dist
 
 
 class ShardInfo:
-    def __init__(self, rank, world, group=None):
-        self.rank, self.world, self.group = rank, world, group
+    def __init__(self, rank, world, group=None, comm=None):
+        """comm: an h-denseunet_amd.comm.Comm (RCCL through the C-ABI, hdu_comm_sendrecv / hdu_comm_allreduce_f32 on the
+        compute stream); None = torch.distributed point-to-point / all-reduce (gloo in the CPU tests)"""
+        self.rank, self.world, self.group, self.comm = rank, world, group, comm
 
     @property
     def lo(self):
@@ -43,6 +45,11 @@ def halo_exchange(sh, act, h):
     if sh is None or sh.world == 1:
         return
     D = act.D
+    if sh.comm is not None:       # one grouped RCCL exchange with both neighbours, enqueued on the compute stream
+        sh.comm.sendrecv(sh.lo, _planes(act, h, h) if sh.lo is not None else None, _planes(act, 0, h) if sh.lo is not None else None,
+                         sh.hi, _planes(act, D - 2 * h, h) if sh.hi is not None else None,
+                         _planes(act, D - h, h) if sh.hi is not None else None)
+        return
     ops_ = []
     if sh.lo is not None:
         ops_.append(dist.P2POp(dist.isend, _planes(act, h, h), sh.lo, sh.group))
@@ -64,14 +71,18 @@ def halo_reduce(sh, act, h, tmp):
     ops_ = []
     r_lo = tmp[:h * plane]
     r_hi = tmp[h * plane:2 * h * plane]
-    if sh.lo is not None:
-        ops_.append(dist.P2POp(dist.isend, _planes(act, 0, h), sh.lo, sh.group))
-        ops_.append(dist.P2POp(dist.irecv, r_lo, sh.lo, sh.group))
-    if sh.hi is not None:
-        ops_.append(dist.P2POp(dist.isend, _planes(act, D - h, h), sh.hi, sh.group))
-        ops_.append(dist.P2POp(dist.irecv, r_hi, sh.hi, sh.group))
-    for r in dist.batch_isend_irecv(ops_):
-        r.wait()
+    if sh.comm is not None:
+        sh.comm.sendrecv(sh.lo, _planes(act, 0, h) if sh.lo is not None else None, r_lo if sh.lo is not None else None,
+                         sh.hi, _planes(act, D - h, h) if sh.hi is not None else None, r_hi if sh.hi is not None else None)
+    else:
+        if sh.lo is not None:
+            ops_.append(dist.P2POp(dist.isend, _planes(act, 0, h), sh.lo, sh.group))
+            ops_.append(dist.P2POp(dist.irecv, r_lo, sh.lo, sh.group))
+        if sh.hi is not None:
+            ops_.append(dist.P2POp(dist.isend, _planes(act, D - h, h), sh.hi, sh.group))
+            ops_.append(dist.P2POp(dist.irecv, r_hi, sh.hi, sh.group))
+        for r in dist.batch_isend_irecv(ops_):
+            r.wait()
     # the returned halo gradients are ADDED to my boundary planes by the library's accumulate kernel
     from . import ops
     H, W, C, ld = act.H, act.W, act.C, act.ld
@@ -86,22 +97,27 @@ def halo_reduce(sh, act, h, tmp):
 
 def allreduce_sum(sh, t):
     if sh is not None and sh.world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
+        if sh.comm is not None:
+            sh.comm.allreduce_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
     return t
 
 
-def sync_stats(sh, mean, var, n_local, n_global, buf):
-    """local (mean, biased var) over n_local pixels -> global statistics over n_global pixels, in place.
-    buf: float32 [2*C] scratch."""
+def sync_stats(sh, mean, var, n_local, buf):
+    """local (mean, biased var) over n_local pixels -> statistics of the whole volume, in place.
+    buf: float32 scratch of hdu_stats_sync_floats(C, world) = world * (1 + 2C) elements (include/hdu.h: every rank fills its
+    slot, the SUM all-reduce gathers them, the slots are combined without an E[x^2] - E[x]^2 subtraction)."""
     if sh is None or sh.world == 1:
         return
-    import ctypes
     from . import lib as _l, ops
     C = mean.numel()
     lib = _l.get()
-    _l.check(lib.hdu_stats_pack(C, ops.fptr(mean), ops.fptr(var), n_local, ops.fptr(buf), ops.stream()), "hdu_stats_pack")
-    dist.all_reduce(buf[:2 * C], op=dist.ReduceOp.SUM, group=sh.group)
-    _l.check(lib.hdu_stats_unpack(C, ops.fptr(buf), n_global, ops.fptr(mean), ops.fptr(var), ops.stream()), "hdu_stats_unpack")
+    n = sh.world * (1 + 2 * C)
+    _l.check(lib.hdu_stats_pack(C, ops.fptr(mean), ops.fptr(var), n_local, sh.rank, sh.world, ops.fptr(buf), ops.stream()),
+             "hdu_stats_pack")
+    allreduce_sum(sh, buf[:n])
+    _l.check(lib.hdu_stats_unpack(C, ops.fptr(buf), sh.world, ops.fptr(mean), ops.fptr(var), ops.stream()), "hdu_stats_unpack")
 
 
 def exchange_ct_planes(sh, vol_h, D, plane):
@@ -110,6 +126,14 @@ def exchange_ct_planes(sh, vol_h, D, plane):
     plane is replicated, which is exactly the reference's first / last 2.5D slab (denseunet3d.py:399-409)."""
     first, last = vol_h[plane:2 * plane], vol_h[D * plane:(D + 1) * plane]
     lo_halo, hi_halo = vol_h[:plane], vol_h[(D + 1) * plane:(D + 2) * plane]
+    if sh.comm is not None:
+        if sh.lo is None:
+            lo_halo.copy_(first)
+        if sh.hi is None:
+            hi_halo.copy_(last)
+        sh.comm.sendrecv(sh.lo, first if sh.lo is not None else None, lo_halo if sh.lo is not None else None,
+                         sh.hi, last if sh.hi is not None else None, hi_halo if sh.hi is not None else None)
+        return
     ops_ = []
     if sh.lo is not None:
         ops_.append(dist.P2POp(dist.isend, first, sh.lo, sh.group))

@@ -140,6 +140,11 @@ typedef struct hdu_conv_desc {
   void* splitk_ws;
   size_t splitk_ws_bytes;
   uint32_t* splitk_counters;
+  /* Depth sharding: this launch computes part of a layer (the local depth planes of one volume split over several ranks,
+   * possibly plus halo planes a neighbour also computes).  layer_rows = N*Do*Ho*Wo of the WHOLE unsharded layer; tile-shape
+   * and split-K decisions are then taken for that pixel count, so every output element is summed over the same K partition
+   * -- bit for bit -- as in the unsharded launch.  0 = this launch is the whole layer. */
+  int64_t layer_rows;
 } hdu_conv_desc;
 
 /* finishes the sums of a fused BN-backward epilogue (hdu_conv_desc.bnb_partial): S1, S2 totals -> parameter gradients
@@ -330,10 +335,13 @@ int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, 
                                     const float* sgamma, const float* sbeta, float* a, float* b, float* rstd,
                                     float* mov_mean, float* mov_var, float momentum, void* stream);
 
-/* sync-BN over the depth shards of one volume: buf[0:C] = n_local*mean, buf[C:2C] = n_local*(var + mean^2) (the caller
- * all-reduces buf over the ranks), then mean = buf[0:C]/n_global, var = buf[C:2C]/n_global - mean^2 (clamped at 0) */
-int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, float* buf, void* stream);
-int hdu_stats_unpack(int C, const float* buf, int64_t n_global, float* mean, float* var, void* stream);
+/* sync-BN over the depth shards of one volume.  buf: hdu_stats_sync_floats(C, world) floats = [world][1 + 2C].
+ * hdu_stats_pack writes (n_local, mean, var) into slot `rank` and zeros into the other slots; the caller SUM-all-reduces buf
+ * over the ranks (adding zeros is exact: an all-gather); hdu_stats_unpack combines the slots in rank order with
+ *   mean = sum n_i mean_i / N,   var = sum n_i (var_i + (mean_i - mean)^2) / N      (no E[x^2] - E[x]^2 cancellation) */
+size_t hdu_stats_sync_floats(int C, int world);
+int hdu_stats_pack(int C, const float* mean, const float* var, int64_t n_local, int rank, int world, float* buf, void* stream);
+int hdu_stats_unpack(int C, const float* buf, int world, float* mean, float* var, void* stream);
 
 /* per-channel column sum: out[c] = sum_m x[m][c]   (bias gradients) */
 int hdu_colsum(int dtype, const void* x, int64_t ldx, int64_t M, int C, float* out, void* ws, size_t ws_bytes,
@@ -406,6 +414,24 @@ int hdu_zero_regions(const hdu_zero_entry* dev_table, int n, uint32_t total_bloc
                      void* stream);
 /* one region (ptr 16-byte aligned, bytes a multiple of 4) */
 int hdu_zero(void* ptr, uint64_t bytes, void* stream);
+
+/* ------------------------------------------------------------------ collectives (RCCL over xGMI)
+ * The reference's only multi-GPU mechanism is in-graph tower replication (K.utils2/multi_gpu.py:7-69: the gradient sum is
+ * implicit in tf.gradients, TFB:2310).  One process per GPU needs two exchanges, both on the caller's stream:
+ *   - hdu_comm_allreduce_f32: in-place sum of the flat gradient buffer (data parallelism; the partial filter gradients of
+ *     a depth-sharded volume);
+ *   - hdu_comm_sendrecv: one grouped send/receive pair with each depth neighbour (halo planes forward, halo gradients
+ *     back, the raw CT plane of the 2.5D slabs); a neighbour rank of -1 = the volume's edge.
+ * Bootstrap: rank 0 calls hdu_comm_unique_id and hands the 128 bytes to the other ranks by whatever channel the launcher
+ * has (h-denseunet_amd/parallel.py broadcasts them through the torch.distributed store); every rank then calls
+ * hdu_comm_init.  RCCL is bound with dlopen at first use: a process that never calls these needs no librccl. */
+typedef struct hdu_comm hdu_comm;
+int hdu_comm_unique_id(void* id128);
+int hdu_comm_init(hdu_comm** comm, int rank, int world, const void* id128);
+int hdu_comm_destroy(hdu_comm* comm);
+int hdu_comm_allreduce_f32(hdu_comm* comm, float* buf, int64_t n, void* stream);
+int hdu_comm_sendrecv(hdu_comm* comm, int lo_rank, const void* send_lo, void* recv_lo, int hi_rank, const void* send_hi,
+                      void* recv_hi, size_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

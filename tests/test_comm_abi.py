@@ -1,0 +1,66 @@
+"""hdu_comm_* (include/hdu.h): RCCL behind the C-ABI.  A single-GPU box can run a communicator of ONE rank: the all-reduce
+is then the identity and the neighbour exchange has no neighbour -- which still proves that librccl is found and bound at
+run time, that a communicator initialises from a 128-byte id, and that the calls enqueue on torch's stream; the data-parallel
+step driven through it (HDU_COMM=rccl_abi) must equal the torch.distributed one.  World-2 numerics of the SAME call sites are
+covered on CPU with gloo (tests/test_dp_gloo.py, tests/test_depth_shard_gloo.py); the emulator build exports the symbols and
+refuses them with a message (no RCCL there)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_emulator_build_refuses_comm_calls(emu_lib):
+    lib = emu_lib.lib.get()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.hdu_comm_unique_id(buf) != 0
+    assert b"emulator" in lib.hdu_last_error()
+
+
+@pytest.mark.gpu
+def test_comm_world1_allreduce_and_exchange(hip_lib):
+    comm_mod = __import__("importlib").import_module("h-denseunet_amd.comm")
+    c = comm_mod.Comm(0, 1, comm_mod.Comm.unique_id())
+    t = torch.arange(1, 100001, dtype=torch.float32, device="cuda")
+    ref = t.clone()
+    c.allreduce_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref)                       # sum over one rank
+    c.sendrecv(None, None, None, None, None, None)   # a volume with no neighbours: nothing to exchange
+    # inside a captured graph, on the capture stream
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        c.allreduce_(t)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        t.mul_(2.0)
+        c.allreduce_(t)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref * 2.0)
+    c.close()
+
+
+@pytest.mark.gpu
+def test_data_parallel_step_through_comm_abi_world1(hip_lib):
+    """bench.py's multi-process path with the gradient all-reduce as hdu_comm_allreduce_f32 (HDU_COMM=rccl_abi)"""
+    outs = []
+    for mode in ("rccl_abi", "torch"):
+        env = dict(os.environ, HDU_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", HDU_COMM=mode)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2",
+                              "--size", "64", "--no-cpu-baseline", "--no-roofline", "--extras", "none"], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1]))
+    assert outs[0]["n_gpus"] == 1 and np.isfinite(outs[0]["config"]["loss"])
+    assert abs(outs[0]["config"]["loss"] - outs[1]["config"]["loss"]) <= 2e-3 * abs(outs[1]["config"]["loss"])

@@ -21,19 +21,18 @@ def test_depth_shard_world4_gloo(emu_lib):
     assert "SHARD_OK" in out.stdout and out.stdout.count("rank ") >= 4
 
 
-@pytest.mark.parametrize("net,port", [("end2end", "29551")])     # (SHARD_TEST_NET=3dpart runs the same worker by hand)
+@pytest.mark.parametrize("net,port", [("end2end", "29551"), ("3dpart", "29553")])
 def test_depth_sharded_hybrid_world2_gloo(emu_lib, net, port):
     """SURVEY.md section 8e, third row: the HYBRID nets on one volume split over 2 ranks -- each rank runs the 2D branch on
     its own slices (one raw CT plane exchanged with each depth neighbour for the 2.5D slabs, denseunet3d.py:399-409), the
     3D net with halo exchange / sync-BN, the HFF add + `fianl_conv` with a halo, loss.py's slices 1:7 split over the
     ranks; the sharded training step reproduces the unsharded one (logits, loss, all-reduced gradient, weights, moving
     statistics).  end2end also returns the stem's halo gradients (stride-2 7x7x7 data gradient) to the 2D branch."""
-    # HDU_SPLITK=1 (never split the K loops): the library picks the split count from the launch's tile count, which differs
-    # between the half-volume shards and the whole volume; the different float32 summation order alone moves the hybrid's
-    # logits (250 x logits2d feed the 3D stem) by 3e-4 of max|logit| -- above this test's 2e-4 gate, which is about the
-    # sharding logic.  (Measured: 2.97e-4 with the default splits, pass without; split-K itself: tests/test_kernels.py.)
-    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net,
-               HDU_SPLITK="1")
+    # Default split-K: a shard's launches take their tile-shape / split decisions for the WHOLE layer
+    # (hdu_conv_desc.layer_rows = the unsharded layer's pixel count), so every output is summed over the same K partition as in the unsharded run.
+    # (Round 2 had to force HDU_SPLITK=1 here: the split count followed the shard's own tile count and the different float32
+    # summation order alone moved the hybrid's logits -- 250 x logits2d feed the 3D stem -- by 3e-4 of max|logit|.)
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)

@@ -98,18 +98,18 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols, primed):
 
 @pytest.mark.parametrize("kind,variant,b,size,cols", [
     ("2d", "denseunet", 2, 512, None),             # BASELINE configs[0] / [1] network at 512 x 512
-    ("2d", "densenet", 6, 224, None),              # the hybrids' 2D branch as a stand-alone net (densenet.py)
-    ("hybrid", "3dpart", 1, 224, 12),              # configs[2]
+    ("hybrid", "3dpart", 1, 224, 12),              # configs[2] (its 2D branch is densenet.py's DenseNet)
     ("hybrid", "end2end", 1, 224, 12),             # configs[3]
     ("3d", "3dpart", 1, 224, 12),                  # per-shard network of configs[4]
-], ids=["2d-denseunet", "2d-densenet", "3dpart", "end2end", "3d"])
+], ids=["2d-denseunet", "3dpart", "end2end", "3d"])
 def test_f32_absolute_logit_error_from_trained_weights(hip_lib, kind, variant, b, size, cols):
     """north_star: per-voxel logits within 1e-4 ABSOLUTE of the reference's.  On random-init weights the logits of a
     161-layer net reach |3.5e3| and only a relative statement is possible (test_full_forward_parity_f32); here the nets are
-    first trained with the reference's recipe (tests/test_gpu_parity_bf16.py: trained_weights), so max|logit| <= ~10-17,
-    and the float32 product is held to  max|got - oracle| <= 1e-4 * max(1, max|logit|)  on every voxel -- predict AND the
-    training-phase forward.  Calibration printed beside it: the float32 oracle's own distance from the SAME graph run in
-    float64 (what float32 accumulation order alone moves)."""
+    first trained with the reference's recipe (tests/test_gpu_parity_bf16.py: trained_weights), so max|logit| is 2-14, and
+    the float32 product is held to  max|got - oracle| <= 1e-4 ABSOLUTE  on every voxel of predict (measured on MI355X,
+    profiles/r03_bf16_parity_figures.txt: 3.6e-6 ... 3.8e-5, the same size as the float32 oracle's own distance from the
+    SAME graph run in float64, printed beside it), and to max(1e-4, 2.5e-5 * max|logit|) on the training-phase forward
+    (batch statistics: measured 2.6e-5 ... 1.25e-4 at max|logit| 5 ... 14)."""
     import os
     from test_gpu_parity_bf16 import trained_weights, oracle_with, product_with, _log
     W = trained_weights(kind, variant, b, size, cols)
@@ -146,8 +146,8 @@ def test_f32_absolute_logit_error_from_trained_weights(hip_lib, kind, variant, b
     if os.environ.get("HDU_PARITY_MEASURE_ONLY") == "1":
         return
     assert mx <= 40.0, "the recipe is meant to give O(10) logits"
-    assert e_got <= 1e-4 * max(1.0, mx), "predict logits: max abs err %.3e at max|logit| %.3f" % (e_got, mx)
-    assert e_t <= 2e-4 * max(1.0, mx_t), "training-phase logits: max abs err %.3e at max|logit| %.3f" % (e_t, mx_t)
+    assert e_got <= 1e-4, "predict logits: max abs err %.3e at max|logit| %.3f" % (e_got, mx)
+    assert e_t <= max(1e-4, 2.5e-5 * mx_t), "training-phase logits: max abs err %.3e at max|logit| %.3f" % (e_t, mx_t)
     assert min(dice) >= 1 - 1e-3
 
 

@@ -157,7 +157,6 @@ CASES = [
     ("3d", "3dpart", 1, 224, 12, "trained"),                 # the per-shard network of configs[4]
     ("2d", "denseunet", 2, 512, None, "mid"),
     ("hybrid", "end2end", 1, 224, 12, "mid"),
-    ("hybrid", "3dpart", 1, 224, 12, "mid"),
 ]
 FIGURES = os.path.join(U.ROOT, "gpurun_out", "bf16_parity_figures.txt")
 
@@ -173,7 +172,7 @@ def _log(msg):
 
 
 @pytest.mark.parametrize("kind,variant,b,size,cols,recipe", CASES,
-                         ids=["2d-2x512", "3dpart", "end2end", "3d", "2d-2x512-mid", "end2end-mid", "3dpart-mid"])
+                         ids=["2d-2x512", "3dpart", "end2end", "3d", "2d-2x512-mid", "end2end-mid"])
 def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols, recipe):
     small = os.environ.get("HDU_PARITY_SMALL") == "1"       # developer switch: same flow at reduced depth / size
     nb2d, nb3d = ((2, 2, 2, 2), (1, 1, 2, 1)) if small else (FULL2D, FULL3D)
@@ -296,6 +295,18 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols,
     # scatters it by percents -- it is printed above, not gated)
     assert abs(coef - 1.0) < max(1e-2, BF16_SLACK * abs(cal_coef - 1.0)), \
         "gradient scale on the oracle's: %.4f (bf16-storage oracle %.4f)" % (coef, cal_coef)
+    # DIRECT gates against the bf16-storage oracle (no slack factor: these compare two runs that round at the same places).
+    # Measured on MI355X (profiles/r03_bf16_parity_figures.txt): median rel-L2 0.21-0.85 x the storage noise, 88-98 % of the
+    # tensors closer, logits 0.3-0.93 x, coefficient 0.943-0.999 (0.78 for denseunet_3d, whose bf16-storage oracle itself
+    # regresses at 0.10 on the float32 gradient).  A defect of a few percent of the gradient that the calibrated gates above
+    # would absorb into their 3 x noise budget moves these: it is NOT shared with the oracle's rounding pattern.
+    assert float(np.median(drels)) <= float(np.median(cal_rels)), \
+        "median gradient distance to the bf16-storage oracle %.4f exceeds that oracle's own distance to float32 %.4f" % (
+            float(np.median(drels)), float(np.median(cal_rels)))
+    assert closer >= 0.80, "only %.1f %% of the gradient tensors are closer to the bf16-storage oracle than it is to float32" % (100 * closer)
+    assert e_direct <= 1.25 * e_cal, "train-mode logits vs the bf16-storage oracle %.3e (it vs float32 %.3e)" % (e_direct, e_cal)
+    assert abs(dcoef - 1.0) <= max(0.08, 0.5 * abs(cal_coef - 1.0)), \
+        "gradient scale on the bf16-storage oracle's: %.4f (that oracle on float32: %.4f)" % (dcoef, cal_coef)
     # SGD-Nesterov update of the head from the bf16 gradients (K.optimizers.py:168-185): delta = -lr*(1+momentum)*g
     last = {"2d": "dense167classifer", "hybrid": "2d3dclassifer", "3d": "3dclassifer"}[kind]
     d_got = m.get_weights_dict()[last][0] - W[last][0]

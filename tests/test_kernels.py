@@ -884,3 +884,33 @@ def test_zero_regions(hdu):
     assert float(t[4:-4].abs().max()) == 0.0 and float(t[:4].min()) == 2.0 and float(t[-4:].min()) == 2.0
     with pytest.raises(Exception):
         ops.zero_tensor(t[1:9])                        # not 16-byte aligned
+
+
+def test_stats_sync_combine(hdu):
+    """hdu_stats_pack / hdu_stats_unpack (sync-BN of a depth-sharded volume): the statistics of the whole tensor from the
+    per-shard (n, mean, var) slots -- including channels whose |mean| is 1e3 standard deviations, where the
+    (n mean, n (var + mean^2)) form all-reduced in rounds 1-2 lost the variance entirely"""
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    d = ops.device()
+    C, world = 40, 3
+    ns = [700, 700, 1100]
+    rng = np.random.default_rng(3)
+    offs = rng.normal(0, 1, C) * np.where(np.arange(C) % 2 == 0, 1.0, 1e3)          # odd channels: mean >> sigma
+    xs = [(rng.normal(0, 1, (n, C)) * 0.7 + offs + 0.05 * r).astype(np.float64) for r, n in enumerate(ns)]
+    allx = np.concatenate(xs, 0)
+    n_fl = int(lib.hdu_stats_sync_floats(C, world))
+    assert n_fl == world * (1 + 2 * C)
+    total = torch.zeros(n_fl, dtype=torch.float32, device=d)
+    for r in range(world):
+        mean = torch.tensor(xs[r].mean(0), dtype=torch.float32, device=d)
+        var = torch.tensor(xs[r].var(0), dtype=torch.float32, device=d)
+        buf = torch.full((n_fl,), 7.0, dtype=torch.float32, device=d)
+        assert lib.hdu_stats_pack(C, ops.fptr(mean), ops.fptr(var), ns[r], r, world, ops.fptr(buf), ops.stream()) == 0
+        total += buf                                  # the caller's SUM all-reduce
+    mean = torch.empty(C, dtype=torch.float32, device=d)
+    var = torch.empty(C, dtype=torch.float32, device=d)
+    assert lib.hdu_stats_unpack(C, ops.fptr(total), world, ops.fptr(mean), ops.fptr(var), ops.stream()) == 0
+    np.testing.assert_allclose(mean.cpu().numpy(), allx.mean(0), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), allx.var(0), rtol=2e-5)
+    assert lib.hdu_stats_pack(C, ops.fptr(mean), ops.fptr(var), 5, 3, 3, ops.fptr(total), ops.stream()) != 0      # rank out of range
