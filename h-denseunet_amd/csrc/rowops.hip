@@ -159,7 +159,8 @@ struct RedK {
   const float* b;
   const float* mean;
   const float* rstd;
-  float* partial;  // [gridDim.x][2][C]
+  float* partial;  // [gridDim.x][2][C]; slots > 0: a ZEROED [slots][2][C] table, row (blockIdx.x % slots), float atomics
+  int slots;
 };
 
 template <typename T, int MODE, int COLS>
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(RedK p) {
       float t = 0.f;
 #pragma unroll 4
       for (int r = 0; r < ROWS; ++r) t += red[s][r][col];
-      float* dst = p.partial + ((long long)blockIdx.x * 2 + s) * p.C + c;
-      *dst = t;
+      if (p.slots > 0) atomicAdd(p.partial + ((long long)(blockIdx.x % (unsigned)p.slots) * 2 + s) * p.C + c, t);
+      else p.partial[((long long)blockIdx.x * 2 + s) * p.C + c] = t;
     }
   }
 }
@@ -399,6 +400,7 @@ extern "C" int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M,
 // the others read the stored moments; every channel then folds -- no cross-channel dependency, one launch instead of two.
 __global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __restrict__ partial, int slots, int Cseg,
                                                                  int seg_c0, int C_all, long long M,
+                                                                 const float* __restrict__ shift_all,
                                                                  float* __restrict__ mean_all, float* __restrict__ var_all,
                                                                  FinK fin) {
   __shared__ double red[2][4][8];
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __
   const bool mine = pl == 0 && c < C_all;
   // everything this thread will need is requested up front: parameters, the stored moments, its slot rows
   const FinPre pre = fin_prefetch(fin, mine ? c : 0, mine);
-  const float mean_old = mine ? mean_all[c] : 0.f;
+  const float mean_old = mine ? (in_seg ? shift_all[c] : mean_all[c]) : 0.f;
   const float var_old = mine ? var_all[c] : 0.f;
   double a1 = 0.0, a2 = 0.0;
   if (wg_has_seg) {
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __
     const double m1 = a1 / (double)M;
     double var = a2 / (double)M - m1 * m1;
     if (var < 0.0) var = 0.0;
-    mu = (float)((double)mean_old + m1);             // the epilogue's shift is the previous pass's mean (same array)
+    mu = (float)((double)mean_old + m1);             // the epilogue's shift (the mean of an earlier pass)
     v = (float)var;
     mean_all[c] = mu;
     var_all[c] = v;
@@ -440,16 +442,18 @@ __global__ __launch_bounds__(256) void finalize_fold_next_kernel(const float* __
 }
 
 extern "C" int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, int Cseg, int seg_c0, int C_all,
-                                               float* mean_all, float* var_all, const float* gamma, const float* beta,
+                                               const float* shift_all, float* mean_all, float* var_all, const float* gamma,
+                                               const float* beta,
                                                float eps, const float* sgamma, const float* sbeta, float* a, float* b,
                                                float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream) {
-  if (!partial || slots <= 0 || M <= 0 || Cseg <= 0 || seg_c0 < 0 || C_all < seg_c0 + Cseg || !mean_all || !var_all || !a || !b)
+  if (!partial || slots <= 0 || M <= 0 || Cseg <= 0 || seg_c0 < 0 || C_all < seg_c0 + Cseg || !shift_all || !mean_all ||
+      !var_all || !a || !b)
     return hdu_set_error(HDU_ERR_ARG, "bn_stats_finalize_fold_next: bad args");
   FinK f{};
   f.kind = 1; f.gamma = gamma; f.beta = beta; f.sgamma = sgamma; f.sbeta = sbeta; f.eps = eps; f.momentum = momentum;
   f.a = a; f.b = b; f.rstd = rstd; f.mov_mean = mov_mean; f.mov_var = mov_var;
   HDU_LAUNCH(finalize_fold_next_kernel, dim3((unsigned)((C_all + 7) / 8)), dim3(256), 0, (hipStream_t)stream, partial, slots,
-             Cseg, seg_c0, C_all, (long long)M, mean_all, var_all, f);
+             Cseg, seg_c0, C_all, (long long)M, shift_all, mean_all, var_all, f);
   return hdu_check_launch("bn_stats_finalize_fold_next");
 }
 
@@ -635,7 +639,47 @@ struct RowK {
   float drop_scale;
   unsigned drop_thresh, drop_seed;
   const unsigned* drop_seed_dev;
+  // bn_bwd_apply_kernel<.., SUMS = true> (hdu_bn_bwd_fused): the coefficients come from the reduction's slot sums
+  const float* sums;          // [slots][2][C]
+  int slots, batch_stats;
+  float invM;
+  const float* gamma; const float* beta; const float* sgamma; const float* rstd;
+  float* dgamma; float* dbeta; float* dsgamma; float* dsbeta;
 };
+
+// Column totals of a [slots][2][C] slot table for the thread's own CH channels.  The ROWS row lanes of a column chunk split
+// the slot rows (one memory round trip for the whole table part of the workgroup), meet in LDS, and every lane then adds the
+// per-lane partials in a fixed order.  ALL 256 threads call it (barrier inside); lanes without a column pass active = false.
+template <int CH, int COLS>
+__device__ __forceinline__ void slot_sums(const float* __restrict__ tbl, int slots, int C, int c0, bool active, int cc, int rl,
+                                          float (&s1)[CH], float (&s2)[CH]) {
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[ROWS][2][COLS * CH];
+  float t1[CH], t2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+  if (active) {
+    for (int sl = rl; sl < slots; sl += ROWS) {
+#pragma unroll
+      for (int j = 0; j < CH; j += 4) {
+        const f32x4 v1 = *(const f32x4*)(tbl + ((long long)sl * 2 + 0) * C + c0 + j);
+        const f32x4 v2 = *(const f32x4*)(tbl + ((long long)sl * 2 + 1) * C + c0 + j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t1[j + r] += v1[r]; t2[j + r] += v2[r]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { red[rl][0][cc * CH + j] = t1[j]; red[rl][1][cc * CH + j] = t2[j]; }
+  __syncthreads();
+  const int nr = slots < ROWS ? slots : ROWS;
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  for (int r = 0; r < nr; ++r) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += red[r][0][cc * CH + j]; s2[j] += red[r][1][cc * CH + j]; }
+  }
+}
 
 // Row kernels: thread (cc, rl) owns 16-byte channel chunk cc of its column group for the whole launch (coefficients
 // live in registers) and strides over the rows of its row block.
@@ -677,28 +721,72 @@ __global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
   for (; m < r_end; m += ROWS) body(m, *(const u32x4*)(xp + m * p.ldx + c0));
 }
 
-template <typename T, int COLS>
+template <typename T, int COLS, bool SUMS = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int ROWS = 256 / COLS;
   const int cc = threadIdx.x % COLS, rl = threadIdx.x / COLS;
   const int c0 = (blockIdx.y * COLS + cc) * CH;
-  if (c0 >= p.C) return;
+  const bool active = c0 < p.C;
+  if (!SUMS && !active) return;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ dzp = (const T*)p.dz;
   T* __restrict__ op = (T*)p.out;
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-  // dx = k1*g - k2 - k3*(x-mean) = k1*g - k3*x + k4,  k4 = k3*mean - k2
-  float a[CH], b[CH], k1[CH], k3[CH], k4[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) {
-    const int c = c0 + j;
-    a[j] = p.a[c]; b[j] = p.b[c]; k1[j] = p.k1[c]; k3[j] = p.k3[c];
-    k4[j] = p.k3[c] * p.mean[c] - p.k2[c];
-  }
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
   long long r_end = r_begin + p.rows_per_block;
   if (r_end > p.M) r_end = p.M;
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  long long m = r_begin + rl;
+  // dx = k1*g - k2 - k3*(x-mean) = k1*g - k3*x + k4,  k4 = k3*mean - k2
+  float a[CH], b[CH], k1[CH], k3[CH], k4[CH];
+  if constexpr (SUMS) {
+    // hdu_bn_bwd_fused: no finalize launch -- this workgroup sums the reduction's slot rows for its own channels and derives
+    // the coefficients in registers (bn_coef_channel's formulas); its first row block also writes the parameter gradients
+    const int cq = active ? c0 : 0;
+    float g[CH], be[CH], sg[CH], rs[CH], mu[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j += 4) {                // parameters requested before the slot rows: one round trip together
+      const f32x4 va = *(const f32x4*)(p.a + cq + j), vb = *(const f32x4*)(p.b + cq + j);
+      const f32x4 vr = *(const f32x4*)(p.rstd + cq + j), vm = *(const f32x4*)(p.mean + cq + j);
+      const f32x4 vg = p.gamma ? *(const f32x4*)(p.gamma + cq + j) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 ve = p.beta ? *(const f32x4*)(p.beta + cq + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 vs = p.sgamma ? *(const f32x4*)(p.sgamma + cq + j) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[j + r] = va[r]; b[j + r] = vb[r]; rs[j + r] = vr[r]; mu[j + r] = vm[r];
+        g[j + r] = vg[r]; be[j + r] = ve[r]; sg[j + r] = vs[r];
+      }
+    }
+    float S1[CH], S2[CH];
+    slot_sums<CH, COLS>(p.sums, p.slots, p.C, cq, active, cc, rl, S1, S2);
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float kk = sg[j] * g[j] * rs[j];
+      const float k2 = p.batch_stats ? kk * S1[j] * p.invM : 0.f;
+      k1[j] = kk;
+      k3[j] = p.batch_stats ? kk * rs[j] * S2[j] * p.invM : 0.f;
+      k4[j] = k3[j] * mu[j] - k2;
+    }
+    if (blockIdx.x == 0 && rl == 0) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int c = c0 + j;
+        if (p.dgamma) p.dgamma[c] = sg[j] * S2[j];
+        if (p.dbeta) p.dbeta[c] = sg[j] * S1[j];
+        if (p.dsgamma) p.dsgamma[c] = g[j] * S2[j] + be[j] * S1[j];
+        if (p.dsbeta) p.dsbeta[c] = S1[j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = c0 + j;
+      a[j] = p.a[c]; b[j] = p.b[c]; k1[j] = p.k1[c]; k3[j] = p.k3[c];
+      k4[j] = p.k3[c] * p.mean[c] - p.k2[c];
+    }
+  }
   auto body = [&](long long m, const u32x4& xv, const u32x4& gv, const u32x4& ov) {
     float f[CH], g[CH], o[CH];
     Chunk<T>::unpack(xv, f);
@@ -722,8 +810,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
     }
     *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(o);
   };
-  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
-  long long m = r_begin + rl;
   for (; m + (ROW_UNROLL - 1) * ROWS < r_end; m += ROW_UNROLL * ROWS) {
     u32x4 xv[ROW_UNROLL], gv[ROW_UNROLL], ov[ROW_UNROLL];
 #pragma unroll
@@ -814,21 +900,29 @@ struct MatK {
   long long ldx, ldskip, ldo, Mo, rows_per_block;
   int N, D, H, W, C;
   int ud, uh, uw, relu;
+  // materialize_kernel<.., STATS = true> (hdu_materialize_stats): the BatchNormalization is folded HERE from the epilogue sums
+  // of the conv that wrote the segment [seg_c0, seg_c0 + Cseg) of its input channels (the other channels: stored moments)
+  const float* st_partial;    // [st_slots][2][Cseg]
+  int st_slots, Cseg, seg_c0;
+  long long st_M;
+  const float* st_shift;      // [C]
+  float* st_mean; float* st_var;   // [C]
+  const float* gamma; const float* beta; const float* sgamma; const float* sbeta;
+  float eps, momentum;
+  float* fa; float* fb; float* frstd; float* mov_mean; float* mov_var;
 };
 
-template <typename T, int COLS>
+template <typename T, int COLS, bool STATS = false>
 __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int ROWS = 256 / COLS;
   const int cc = threadIdx.x % COLS, rl = threadIdx.x / COLS;
   const int c0 = (blockIdx.y * COLS + cc) * CH;
-  if (c0 >= p.C) return;
+  const bool active = c0 < p.C;
+  if (!STATS && !active) return;
   const T* __restrict__ xp = (const T*)p.x;
   const T* __restrict__ sp = (const T*)p.skip;
   T* __restrict__ op = (T*)p.out;
-  float a[CH], b[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
   const int We = p.W << p.uw, He = p.H << p.uh, De = p.D << p.ud;
   const bool ups = (p.ud | p.uh | p.uw) != 0;
   const long long r_begin = (long long)blockIdx.x * p.rows_per_block;
@@ -863,6 +957,63 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
       }
     }
   };
+  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  float a[CH], b[CH];
+  if constexpr (STATS) {
+    // (Requesting the thread's first rows BEFORE this prologue, so that its round trip overlaps the main loop's first one, was
+    // measured slower on the 2D step in both forms tried -- branch-guarded and unconditional: 20.41 -> 20.58 ms, round 3.)
+    // No finalize launch between the producing conv and this pass: every workgroup turns the slot sums of its own segment
+    // channels into (mean, var) -- or reads the stored moments of the other channels --, folds the BN(+Scale) in registers,
+    // and the first row block publishes a / b / rstd / the moments / the moving averages for the backward pass and the
+    // later layers.  Segment bounds are multiples of the 16-byte chunk: a thread's channels are all inside or all outside.
+    const int cq = active ? c0 : 0;
+    const bool in_seg = active && c0 >= p.seg_c0 && c0 < p.seg_c0 + p.Cseg;
+    float g[CH], be[CH], sg[CH], sb[CH], mu[CH], vv[CH], mm[CH], mv[CH];
+    const bool pub = blockIdx.x == 0 && rl == 0;
+#pragma unroll
+    for (int j = 0; j < CH; j += 4) {                  // everything requested up front: one memory round trip with the slot rows
+      const f32x4 one = f32x4{1.f, 1.f, 1.f, 1.f}, zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 vg = p.gamma ? *(const f32x4*)(p.gamma + cq + j) : one, ve = p.beta ? *(const f32x4*)(p.beta + cq + j) : zero;
+      const f32x4 vs = p.sgamma ? *(const f32x4*)(p.sgamma + cq + j) : one, vb = p.sbeta ? *(const f32x4*)(p.sbeta + cq + j) : zero;
+      const f32x4 vm = *(const f32x4*)((in_seg ? p.st_shift : (const float*)p.st_mean) + cq + j);
+      const f32x4 vr = *(const f32x4*)(p.st_var + cq + j);
+      const f32x4 v1 = (pub && p.mov_mean) ? *(const f32x4*)(p.mov_mean + cq + j) : zero;
+      const f32x4 v2 = (pub && p.mov_var) ? *(const f32x4*)(p.mov_var + cq + j) : zero;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        g[j + r] = vg[r]; be[j + r] = ve[r]; sg[j + r] = vs[r]; sb[j + r] = vb[r]; mu[j + r] = vm[r]; vv[j + r] = vr[r];
+        mm[j + r] = v1[r]; mv[j + r] = v2[r];
+      }
+    }
+    float S1[CH], S2[CH];
+    slot_sums<CH, COLS>(p.st_partial, p.st_slots, p.Cseg, in_seg ? c0 - p.seg_c0 : 0, in_seg, cc, rl, S1, S2);
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      if (in_seg) {                                    // sums of (y - shift), (y - shift)^2: shift = the previous pass's mean
+        const double m1 = (double)S1[j] / (double)p.st_M;
+        double var = (double)S2[j] / (double)p.st_M - m1 * m1;
+        if (var < 0.0) var = 0.0;
+        mu[j] = (float)((double)mu[j] + m1);
+        vv[j] = (float)var;
+      }
+      const float r = 1.0f / sqrtf(vv[j] + p.eps);
+      const float inv = g[j] * r;
+      a[j] = sg[j] * inv;
+      b[j] = sg[j] * (be[j] - mu[j] * inv) + sb[j];
+      if (pub) {
+        const int c = c0 + j;
+        p.fa[c] = a[j]; p.fb[c] = b[j];
+        if (p.frstd) p.frstd[c] = r;
+        if (in_seg) { p.st_mean[c] = mu[j]; p.st_var[c] = vv[j]; }
+        if (p.mov_mean) p.mov_mean[c] = mm[j] - (mm[j] - mu[j]) * (1.f - p.momentum);
+        if (p.mov_var) p.mov_var[c] = mv[j] - (mv[j] - vv[j]) * (1.f - p.momentum);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { a[j] = p.a ? p.a[c0 + j] : 1.f; b[j] = p.a ? p.b[c0 + j] : 0.f; }
+  }
   auto body = [&](long long mo, const u32x4& xv, const u32x4& sv) {
     float f[CH];
     Chunk<T>::unpack(xv, f);
@@ -880,7 +1031,6 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
     }
     *(u32x4*)(op + mo * p.ldo + c0) = Chunk<T>::pack(f);
   };
-  const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
   while (m + (ROW_UNROLL - 1) * ROWS < r_end) {
     u32x4 xv[ROW_UNROLL], sv[ROW_UNROLL];
     long long mo[ROW_UNROLL];
@@ -947,6 +1097,42 @@ extern "C" int hdu_materialize(int dtype, const void* x, int64_t ldx, int N, int
   return hdu_check_launch("materialize");
 }
 
+extern "C" int hdu_materialize_stats(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C,
+                                     const hdu_stats_fold_desc* f, int relu, int ud, int uh, int uw, const void* skip,
+                                     int64_t ldskip, void* out, int64_t ldout, void* stream) {
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "materialize_stats: bad dtype");
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if (!x || !out || !f || ((ud | uh | uw) & ~1)) return hdu_set_error(HDU_ERR_ARG, "materialize_stats: bad pointers / upsample shifts");
+  if (C <= 0 || C % ch || ldx % ch || ldout % ch || (skip && ldskip % ch) || N <= 0 || D <= 0 || H <= 0 || W <= 0)
+    return hdu_set_error(HDU_ERR_ARG, "materialize_stats: C / strides must be multiples of the 16-byte chunk");
+  if (!f->partial || f->slots <= 0 || f->slots > 64 || f->M <= 0 || f->Cseg <= 0 || f->Cseg % ch || f->seg_c0 < 0 ||
+      f->seg_c0 % ch || f->seg_c0 + f->Cseg > C || !f->shift || !f->mean || !f->var || !f->a || !f->b)
+    return hdu_set_error(HDU_ERR_ARG, "materialize_stats: bad statistics block (segment bounds are multiples of the 16-byte chunk)");
+  if (((uintptr_t)f->partial | (uintptr_t)f->shift | (uintptr_t)f->mean | (uintptr_t)f->var | (uintptr_t)f->gamma |
+       (uintptr_t)f->beta | (uintptr_t)f->sgamma | (uintptr_t)f->sbeta | (uintptr_t)f->mov_mean | (uintptr_t)f->mov_var) & 15)
+    return hdu_set_error(HDU_ERR_ARG, "materialize_stats: per-channel vectors must be 16-byte aligned");
+  MatK k{};
+  k.x = x; k.skip = skip; k.out = out; k.ldx = ldx; k.ldskip = ldskip; k.ldo = ldout;
+  k.N = N; k.D = D; k.H = H; k.W = W; k.C = C; k.ud = ud; k.uh = uh; k.uw = uw; k.relu = relu;
+  k.Mo = (long long)N * (D << ud) * (H << uh) * (W << uw);
+  k.st_partial = f->partial; k.st_slots = f->slots; k.Cseg = f->Cseg; k.seg_c0 = f->seg_c0; k.st_M = f->M;
+  k.st_shift = f->shift; k.st_mean = f->mean; k.st_var = f->var;
+  k.gamma = f->gamma; k.beta = f->beta; k.sgamma = f->sgamma; k.sbeta = f->sbeta; k.eps = f->eps; k.momentum = f->momentum;
+  k.fa = f->a; k.fb = f->b; k.frstd = f->rstd; k.mov_mean = f->mov_mean; k.mov_var = f->mov_var;
+  int cols; unsigned gx, gy;
+  row_geometry(dtype, k.Mo, C, &cols, &gx, &gy, &k.rows_per_block);
+#define HDU_MAT_STATS(T)                                                                                                   \
+  switch (cols) {                                                                                                          \
+    case 4: HDU_LAUNCH((materialize_kernel<T, 4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
+    case 8: HDU_LAUNCH((materialize_kernel<T, 8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
+    case 16: HDU_LAUNCH((materialize_kernel<T, 16, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;     \
+    default: HDU_LAUNCH((materialize_kernel<T, 32, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;     \
+  }
+  if (dtype == HDU_BF16) { HDU_MAT_STATS(bf16_t) } else { HDU_MAT_STATS(float) }
+#undef HDU_MAT_STATS
+  return hdu_check_launch("materialize_stats");
+}
+
 extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M,
                                 int C, const float* a, const float* b, int relu, const float* mean, const float* k1,
                                 const float* k2, const float* k3, void* dx, int64_t lddx, int accumulate,
@@ -968,6 +1154,55 @@ extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const v
   if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(bn_bwd_apply_kernel, bf16_t, cols, gx, gy, stream, k); }
   else { HDU_ROW_LAUNCH(bn_bwd_apply_kernel, float, cols, gx, gy, stream, k); }
   return hdu_check_launch("bn_bwd_apply");
+}
+
+extern "C" int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                                const float* a, const float* b, int relu, const float* mean, const float* rstd,
+                                int batch_stats, const float* gamma, const float* beta, const float* sgamma, float* sums,
+                                int slots, float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* dx,
+                                int64_t lddx, int accumulate, float drop_keep, uint32_t drop_seed,
+                                const uint32_t* drop_seed_dev, void* stream) {
+  if (!dz || !x || !a || !b || !mean || !rstd || !sums || !dx) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: null pointer");
+  if (slots <= 0 || slots > 64) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: 1 <= slots <= 64");
+  if (((uintptr_t)sums | (uintptr_t)a | (uintptr_t)b | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta |
+       (uintptr_t)sgamma) & 15)
+    return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: per-channel vectors must be 16-byte aligned");
+  RowK k{};
+  k.x = x; k.ldx = ldx; k.dz = dz; k.lddz = lddz; k.out = dx; k.ldo = lddx; k.M = M; k.C = C;
+  k.a = a; k.b = b; k.relu = relu; k.mean = mean; k.accumulate = accumulate;
+  if (drop_keep > 0.f && drop_keep < 1.f) {
+    k.drop_scale = 1.f / drop_keep;
+    k.drop_thresh = (unsigned)((double)drop_keep * 4294967296.0);
+  }
+  k.drop_seed = drop_seed;
+  k.drop_seed_dev = drop_seed_dev;
+  k.sums = sums; k.slots = slots; k.batch_stats = batch_stats; k.invM = 1.0f / (float)M;
+  k.gamma = gamma; k.beta = beta; k.sgamma = sgamma; k.rstd = rstd;
+  k.dgamma = dgamma; k.dbeta = dbeta; k.dsgamma = dsgamma; k.dsbeta = dsbeta;
+  if (int e = rowk_check(dtype, k, "bn_bwd_fused: C / strides must be multiples of the 16-byte chunk")) return e;
+  if (M == 0) return 0;
+  // launch 1: column sums of (g, g * xhat) into the slot rows
+  RedK r{};
+  r.x = x; r.ldx = ldx; r.dz = dz; r.lddz = lddz; r.M = M; r.C = C;
+  r.a = a; r.b = b; r.mean = mean; r.rstd = rstd; r.relu = relu;
+  r.partial = sums; r.slots = slots;
+  int rcols; unsigned rgx, rgy;
+  red_geometry(dtype, M, C, &rcols, &rgx, &rgy, &r.rows_per_block);
+  if (dtype == HDU_BF16) run_reduce<bf16_t, RED_BNBWD>(r, rcols, rgx, rgy, (hipStream_t)stream);
+  else run_reduce<float, RED_BNBWD>(r, rcols, rgx, rgy, (hipStream_t)stream);
+  // launch 2: coefficients from the sums + dx
+  int cols; unsigned gx, gy;
+  row_geometry(dtype, M, C, &cols, &gx, &gy, &k.rows_per_block);
+#define HDU_APPLY_SUMS(T)                                                                                                    \
+  switch (cols) {                                                                                                            \
+    case 4: HDU_LAUNCH((bn_bwd_apply_kernel<T, 4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;        \
+    case 8: HDU_LAUNCH((bn_bwd_apply_kernel<T, 8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;        \
+    case 16: HDU_LAUNCH((bn_bwd_apply_kernel<T, 16, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;      \
+    default: HDU_LAUNCH((bn_bwd_apply_kernel<T, 32, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;      \
+  }
+  if (dtype == HDU_BF16) { HDU_APPLY_SUMS(bf16_t) } else { HDU_APPLY_SUMS(float) }
+#undef HDU_APPLY_SUMS
+  return hdu_check_launch("bn_bwd_fused");
 }
 
 extern "C" int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t M, int C, const float* corr3,
@@ -1522,10 +1757,16 @@ __global__ __launch_bounds__(256) void zero_regions_kernel(const hdu_zero_entry*
   unsigned long long len = e.bytes - off;
   if (len > HDU_ZERO_BLOCK_BYTES) len = HDU_ZERO_BLOCK_BYTES;
   char* base = (char*)e.ptr + off;
-  const u32x4 z = u32x4{0u, 0u, 0u, 0u};
   const unsigned long long n16 = len >> 4;
-  for (unsigned long long i = threadIdx.x; i < n16; i += 256) *(u32x4*)(base + (i << 4)) = z;
   const unsigned long long tail0 = n16 << 4;
+  if (e.src != nullptr) {                              // a COPY region (the statistics shifts <- last step's means)
+    const char* sb = (const char*)e.src + off;
+    for (unsigned long long i = threadIdx.x; i < n16; i += 256) *(u32x4*)(base + (i << 4)) = *(const u32x4*)(sb + (i << 4));
+    for (unsigned long long i = tail0 + 4ull * threadIdx.x; i + 4 <= len; i += 1024) *(unsigned*)(base + i) = *(const unsigned*)(sb + i);
+    return;
+  }
+  const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+  for (unsigned long long i = threadIdx.x; i < n16; i += 256) *(u32x4*)(base + (i << 4)) = z;
   for (unsigned long long i = tail0 + 4ull * threadIdx.x; i + 4 <= len; i += 1024) *(unsigned*)(base + i) = 0u;
 }
 

@@ -54,6 +54,7 @@ class Var:
             self.written = False
             self.mean = None
             self.var = None
+            self.shift = None
             self.needs_grad = False
             self.drop = None  # (keep, seed) if produced through dropout
             self.corr_off = None   # offset of this tensor's [2][ld] deferred-BN-backward accumulators in Ctx.corr_acc
@@ -108,7 +109,16 @@ class Var:
             dev = ops.device()
             r.mean = torch.zeros(r.act.ld, dtype=torch.float32, device=dev)
             r.var = torch.ones(r.act.ld, dtype=torch.float32, device=dev)
+            # shift of the conv-epilogue statistics (sums of y - shift): last step's mean, copied by the step-head launch --
+            # a separate array because the launch that finalizes a segment's moments reads the shift in every workgroup
+            # while one of them publishes the new mean (hdu_materialize_stats)
+            r.shift = torch.zeros(r.act.ld, dtype=torch.float32, device=dev)
+            r.ctx.stat_roots.append(r)
         return r.mean[self.c0:self.c0 + self.C], r.var[self.c0:self.c0 + self.C]
+
+    def stats_shift(self):
+        self.stats()
+        return self.root.shift[self.c0:self.c0 + self.C]
 
 
 class _BwdList(list):
@@ -158,6 +168,8 @@ class Ctx:
         # of data-gradient epilogues (the u / gradient-slab loads are exposed: 2-3 workgroups per CU cannot hide them
         # the way the 2048-workgroup streaming kernels do) and +1.0 ms of correction launches: neutral (23.1 vs 23.2 ms).
         # Default 1 = inference-mode BNs only; 2 = every BN (tests cover both); 0 = off.
+        self.absorb_stats = os.environ.get("HDU_ABSORB_STATS", "1") == "1"     # BN fold inside the consumer's materialize pass
+        self.bn_bwd_fused = os.environ.get("HDU_BN_BWD_FUSED", "1") == "1"      # two-launch BN backward (hdu_bn_bwd_fused)
         self.fuse_bn_bwd_mode = int(os.environ.get("HDU_FUSE_BN_BWD", "1"))
         self.fuse_bn_bwd = self.fuse_bn_bwd_mode > 0
         self.fuse_bn_bwd_now = False
@@ -185,6 +197,7 @@ class Ctx:
         # reduction pass; the StatsOp then only runs hdu_bn_stats_finalize over the 32 slot rows
         self.epilogue_stats = os.environ.get("HDU_EPILOGUE_STATS", "1") == "1"
         self.stats_sinks = []
+        self.stat_roots = []        # tensors with batch moments: their statistics shifts are refreshed at every step head
         self.stats_acc = None
         self.finalized = False
         # per-step accumulators live in ONE arena cleared by one launch (ops.ZeroPlan / hdu_zero_regions)
@@ -262,14 +275,23 @@ class Ctx:
                 if cv.bn.mode == "batch" and r.corr_off is None:
                     r.corr_off = self._corr_total
                     self._corr_total += 2 * r.act.ld
-        # arena layout: [loss sums | epilogue statistics | fused-BN-backward slot rows | deferred corrections], every part a
-        # multiple of 4 floats so that the parts stay 16-byte aligned
+        # slot tables of the two-launch BN backward (hdu_bn_bwd_fused): every BN that will need its sums
+        n_bsum = 0
+        bsum_off = {}
+        if self.bn_bwd_fused and self.grad_enabled:
+            for bn in self.bns:
+                if bn.mode == "batch" or bn.any_trainable():
+                    bsum_off[bn] = n_bsum
+                    n_bsum += bn.BSUM_SLOTS * 2 * bn.C
+        # arena layout: [loss sums | epilogue statistics | fused-BN-backward slot rows | deferred corrections | BN-backward
+        # slot tables], every part a multiple of 4 floats so that the parts stay 16-byte aligned
         up4 = lambda n: (n + 3) // 4 * 4
         o_loss, n_loss = 0, 4 * max(1, len(self.loss_layers))
         o_stats = o_loss + n_loss
         o_bnb = o_stats + up4(n_stats)
         o_corr = o_bnb + up4(n_bnb)
-        total = o_corr + up4(self._corr_total)
+        o_bsum = o_corr + up4(self._corr_total)
+        total = o_bsum + up4(n_bsum)
         self.arena = torch.zeros(total, dtype=torch.float32, device=self.dev)
         for i, ll in enumerate(self.loss_layers):
             ll.loss_sum = self.arena[4 * i:4 * i + 1]
@@ -277,7 +299,10 @@ class Ctx:
         self.stats_acc = self.arena[o_stats:o_stats + n_stats] if n_stats else None
         self.bnb_acc = self.arena[o_bnb:o_bnb + n_bnb] if n_bnb else None
         self.corr_acc = self.arena[o_corr:o_corr + self._corr_total] if self._corr_total else None
-        self._zp_arena = ops.ZeroPlan([self.arena])
+        for bn, o in bsum_off.items():
+            bn.bsum = self.arena[o_bsum + o:o_bsum + o + bn.BSUM_SLOTS * 2 * bn.C]
+        self._shift_copies = [(r.shift, r.mean) for r in self.stat_roots] if self.stats_sinks else []
+        self._zp_arena = ops.ZeroPlan([self.arena], self._shift_copies)
         self._zp_bwd = ops.ZeroPlan([self.arena[o_bnb:total]]) if total > o_bnb else None
         self._desc_scope()
         for cv in self.convs:
@@ -397,7 +422,7 @@ class Ctx:
         """head of a training step: ONE launch clears the accumulator arena, the flat gradient buffer (the filter-gradient
         kernels add into it) and the slab gradient buffers with a partial first writer, and advances the dropout seed"""
         if self._zp_step is None:
-            self._zp_step = ops.ZeroPlan([self.arena, self.G[:self.n_trainable]] + self._grad_zero)
+            self._zp_step = ops.ZeroPlan([self.arena, self.G[:self.n_trainable]] + self._grad_zero, self._shift_copies)
             self._zp_keep.append(self._zp_step)          # a captured graph may still hold an older table
         self._zp_step.run(self.seed_dev, 1)
         self._zeroed_fwd_pass = self._zeroed_bwd_pass = self.pass_id + 1     # the pass run_forward is about to start
@@ -472,8 +497,9 @@ class Ctx:
             for v in self.vars:
                 v.written = False
             self.fuse_bn_bwd_now = self.fuse_bn_bwd and (self.shard is None or self.shard.world == 1)
-            if self.fuse_bn_bwd_now and self._zeroed_bwd_pass != self.pass_id and self._zp_bwd is not None:
-                self._zp_bwd.run()
+            if self._zeroed_bwd_pass != self.pass_id and self._zp_bwd is not None:
+                self._zp_bwd.run()         # (a training step's head launch has already cleared the whole arena)
+                self._zeroed_bwd_pass = self.pass_id
         order = list(reversed(self.bwd))
         for f in order[lo:hi]:
             f()
@@ -515,6 +541,7 @@ class Ctx:
 class BNLayer:
     """BatchNormalization (+ optional Scale) + optional ReLU folded to a per-channel affine that the consumer
     applies on load.  K.layers/normalization.py:126-190, lib/custom_layers.py:63-69."""
+    BSUM_SLOTS = 16      # slot rows the backward reduction spreads its float atomics over (workgroup % slots)
 
     def __init__(self, ctx, name, C, eps=1e-3, momentum=0.99, mode="batch", trainable=True, scale_name=None,
                  scale_trainable=True, relu=True):
@@ -537,6 +564,10 @@ class BNLayer:
         self.folded_pass = -1
         ctx.bns.append(self)
         self.s12 = v(2 * C)
+        self.stats_src = None       # the StatsOp whose finalize folds this BN (fuse / then_fold)
+        self.pending_stats = None   # (pass, StatsOp): the consumer's materialize pass of this pass folds it (hdu_materialize_stats)
+        self.bsum = None            # [BSUM_SLOTS][2][C] slot table of hdu_bn_bwd_fused, a slice of Ctx.arena (finalize)
+        self._bsum_pass = -1
 
     def any_trainable(self):
         return self.trainable or (self.sg is not None and self.scale_trainable)
@@ -589,6 +620,18 @@ class BNLayer:
                 ops.bn_bwd_coef(self.C, x.M * ctx.shard.world, True, self.s12[:self.C], self.s12[self.C:],
                                 self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.rstd, self.k1,
                                 self.k2, self.k3)
+        elif (need_sums and self.bsum is not None and xvar.root.needs_grad and ctx._zeroed_bwd_pass == ctx.pass_id
+              and self._bsum_pass != ctx.pass_id):
+            # reduction into the (zeroed) slot table, then coefficients + parameter gradients + dx in ONE launch: no finalize
+            self._bsum_pass = ctx.pass_id
+            acc = xvar.grad_mode()
+            drop = xvar.root.drop if (ctx.dropout_enabled and ctx.learning_phase == 1) else None
+            ops.bn_bwd_fused(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.batch_now,
+                             self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.bsum, self.BSUM_SLOTS,
+                             self.gamma.grad if tr_bn else None, self.beta.grad if tr_bn else None,
+                             self.sg.grad if tr_sc else None, self.sb.grad if tr_sc else None, xvar.grad, acc,
+                             drop[0] if drop else 1.0, drop[1] if drop else 0, ctx.seed_dev if drop else None)
+            return
         elif need_sums:   # reduction + coefficients + parameter gradients: two launches
             ops.bn_bwd_reduce_coef(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.batch_now,
                                    self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.s1,
@@ -672,6 +715,10 @@ class ConvLayer:
                 self.conv_up = (0, 0, 0)
             else:
                 self.xin = ctx.new_var(xa.N, xa.D, xa.H, xa.W, cin_p)
+        st = getattr(bn, "stats_src", None) if bn is not None else None
+        if (st is not None and self.xin is not None and not halo and st.producer is not None and st.absorber is None
+                and x.root is st.var.root and bn.C == x.C and x.c0 == (0 if bn is st.fold_next else st.var.c0)):
+            st.absorber = self
         self.need_input_grad = need_input_grad
         self.epi_consumer = None          # set by the conv that consumes self.out through a foldable BN (see `producer`)
         self.epi_producer = None
@@ -746,7 +793,7 @@ class ConvLayer:
         self.d_f_st = self.d_f_drop_st = None
         sink = getattr(self, "stats_sink", None)
         if sink is not None:
-            mean, _ = sink.var.stats()
+            shift = sink.var.stats_shift()
             part = ctypes.c_void_p(ctx.stats_acc.data_ptr() + 4 * sink.acc_off)
 
             def with_stats(d):
@@ -754,7 +801,7 @@ class ConvLayer:
                     return None
                 c = type(d)()
                 ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(d))
-                c.stats_partial, c.stats_shift, c.stats_slots = part, ctypes.c_void_p(mean.data_ptr()), sink.SLOTS
+                c.stats_partial, c.stats_shift, c.stats_slots = part, ctypes.c_void_p(shift.data_ptr()), sink.SLOTS
                 return c
             self.d_f_st, self.d_f_drop_st = with_stats(self.d_f), with_stats(self.d_f_drop)
 
@@ -785,7 +832,11 @@ class ConvLayer:
             up = self.up if self.skip is not None else (0, 0, 0)
             skip = self.skip.act if self.skip is not None else None
             dst = self.xin_interior if self.halo else self.xin.act
-            ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False, up, skip, dst)
+            pend = bn.pending_stats if bn is not None else None
+            if pend is not None and pend[0] == ctx.pass_id and pend[1].absorber is self:
+                ops.materialize_stats(self.x.act, pend[1].stats_block(bn), bn.relu, up, skip, dst)
+            else:
+                ops.materialize(self.x.act, bn.a if bn else None, bn.b if bn else None, bn.relu if bn else False, up, skip, dst)
             if self.halo:
                 _sh.halo_exchange(ctx.shard, self.xin.act, self.halo)
         self._forward_conv()
@@ -958,6 +1009,7 @@ class StatsOp:
         self.ctx, self.var = ctx, var
         self.fused = None
         self.fold_next = None
+        self.absorber = None        # the ConvLayer whose materialize pass folds the BN of this segment (no finalize launch)
         world = ctx.shard.world if ctx.shard is not None else 1
         self.sync_buf = ctx.fvec(world * (1 + 2 * var.C)) if world > 1 else None      # hdu_stats_sync_floats
         ctx.need_ws(var.act.M, var.C)
@@ -979,6 +1031,7 @@ class StatsOp:
     def fuse(self, bn):
         assert bn.C == self.var.C and bn.mode == "batch"
         self.fused = bn
+        bn.stats_src = self
         return self
 
     def then_fold(self, bn):
@@ -986,7 +1039,21 @@ class StatsOp:
         epilogue statistics also folds it (hdu_bn_stats_finalize_fold_next) -- one launch less per dense layer."""
         if self.fused is None and bn.mode == "batch" and self.ctx.fold_next and bn.C == self.var.c0 + self.var.C:
             self.fold_next = bn
+            bn.stats_src = self
         return self
+
+    def stats_block(self, bn):
+        """argument of ops.materialize_stats for the consumer of `bn` (= self.fused or self.fold_next)"""
+        ctx = self.ctx
+        n = self.SLOTS * 2 * self.var.C
+        fold = (bn.gamma.data, bn.beta.data, bn.eps, bn.sg.data if bn.sg else None, bn.sb.data if bn.sb else None,
+                bn.a, bn.b, bn.rstd, bn.mm.data, bn.mv.data, bn.momentum)
+        part = ctx.stats_acc[self.acc_off:self.acc_off + n]
+        if bn is self.fused:
+            mean, var = self.var.stats()
+            return (part, self.SLOTS, self.var.act.M, self.var.C, 0, self.var.stats_shift(), mean, var, fold)
+        r = self.var.root
+        return (part, self.SLOTS, self.var.act.M, self.var.C, self.var.c0, r.shift[:bn.C], r.mean[:bn.C], r.var[:bn.C], fold)
 
     def forward(self):
         ctx = self.ctx
@@ -1013,18 +1080,26 @@ class StatsOp:
             # the conv epilogue left sum(y - shift), sum((y - shift)^2) in the slot rows; shift = last step's mean
             n = self.SLOTS * 2 * self.var.C
             nb = self.fold_next
+            tgt = nb if nb is not None else bn
+            if tgt is not None and self.absorber is not None and ctx.absorb_stats:
+                # no finalize launch: the pass that applies `tgt` (its consumer's hdu_materialize_stats) folds it from the sums
+                tgt.batch_now = True
+                tgt.mean_used = self.var.root.mean[:tgt.C] if nb is not None else mean
+                tgt.folded_pass = ctx.pass_id
+                tgt.pending_stats = (ctx.pass_id, self)
+                return
             if nb is not None:
                 r = self.var.root
                 f2 = (nb.gamma.data, nb.beta.data, nb.eps, nb.sg.data if nb.sg else None, nb.sb.data if nb.sb else None,
                       nb.a, nb.b, nb.rstd, nb.mm.data, nb.mv.data, nb.momentum)
                 ops.bn_stats_finalize_fold_next(ctx.stats_acc[self.acc_off:self.acc_off + n], self.SLOTS, self.var.act.M,
-                                                self.var.C, self.var.c0, nb.C, r.mean[:nb.C], r.var[:nb.C], f2)
+                                                self.var.C, self.var.c0, nb.C, r.shift[:nb.C], r.mean[:nb.C], r.var[:nb.C], f2)
                 nb.batch_now = True
                 nb.mean_used = r.mean[:nb.C]
                 nb.folded_pass = ctx.pass_id
                 return
             ops.bn_stats_finalize(ctx.stats_acc[self.acc_off:self.acc_off + n], self.SLOTS, self.var.act.M, self.var.C,
-                                  mean, mean, var, fold)
+                                  self.var.stats_shift(), mean, var, fold)
         elif bn is None:
             ops.bn_stats(self.var.act, mean, var, ctx.ws)
             return

@@ -65,7 +65,16 @@ class AugSample(ctypes.Structure):
 
 
 class ZeroEntry(ctypes.Structure):
-    _fields_ = [("ptr", c_p), ("bytes", ctypes.c_uint64), ("block_begin", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
+    _fields_ = [("ptr", c_p), ("bytes", ctypes.c_uint64), ("block_begin", ctypes.c_uint32), ("pad_", ctypes.c_uint32),
+                ("src", c_p)]
+
+
+class BnStatsFold(ctypes.Structure):
+    """include/hdu.h: hdu_stats_fold_desc"""
+    _fields_ = [("partial", c_p), ("slots", ctypes.c_int32), ("Cseg", ctypes.c_int32), ("seg_c0", ctypes.c_int32),
+                ("pad_", ctypes.c_int32), ("M", c_i64), ("shift", c_p), ("mean", c_p), ("var", c_p), ("gamma", c_p),
+                ("beta", c_p), ("sgamma", c_p), ("sbeta", c_p), ("eps", c_f), ("momentum", c_f), ("a", c_p), ("b", c_p),
+                ("rstd", c_p), ("mov_mean", c_p), ("mov_var", c_p)]
 
 
 ZERO_BLOCK_BYTES = 65536      # include/hdu.h HDU_ZERO_BLOCK_BYTES
@@ -111,14 +120,18 @@ _SIGS = {
                                 c_p, c_p]),
     "hdu_bn_bwd_apply": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_p, c_p,
                                  c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
+    "hdu_bn_bwd_fused": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p,
+                                 c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
     "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
     "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
                                 c_p, c_i64, c_p, c_i64, c_p]),
+    "hdu_materialize_stats": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_int, c_int,
+                                      c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_wgrad_plan_entry_bytes": (c_sz, []),
     "hdu_wgrad_plan_fill": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_int, c_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_uint32)]),
     "hdu_wgrad_plan_run": (c_int, [c_int, c_p, c_p, c_int, ctypes.c_uint32, c_p]),
-    "hdu_bn_stats_finalize_fold_next": (c_int, [c_p, c_int, c_i64, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p,
-                                                c_p, c_p, c_p, c_p, c_f, c_p]),
+    "hdu_bn_stats_finalize_fold_next": (c_int, [c_p, c_int, c_i64, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
+                                                c_p, c_p, c_p, c_p, c_p, c_f, c_p]),
     "hdu_bn_stats_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                       c_f, c_p]),
     "hdu_stats_sync_floats": (c_sz, [c_int, c_int]),

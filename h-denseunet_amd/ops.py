@@ -215,14 +215,18 @@ class ZeroPlan:
     """hdu_zero_regions: ONE launch clears a fixed list of device buffers (and bumps the step counter).  Built once per
     list; the table lives in device memory."""
 
-    def __init__(self, tensors):
+    def __init__(self, tensors, copies=()):
+        """tensors: buffers to clear; copies: (dst, src) pairs of equal size filled by the same launch"""
         import numpy as np
         self.keep = [t for t in tensors if t is not None and t.numel() > 0]
+        self.keep_copies = [(d, s_) for d, s_ in copies if d is not None and d.numel() > 0]
         ents, blk = [], 0
-        for t in self.keep:
+        for t, src in [(t, None) for t in self.keep] + self.keep_copies:
             nb = t.numel() * t.element_size()
             assert t.is_contiguous() and t.data_ptr() % 16 == 0 and nb % 4 == 0, "zero plan: 16-byte aligned, whole dwords"
-            ents.append(_l.ZeroEntry(t.data_ptr(), nb, blk, 0))
+            if src is not None:
+                assert src.is_contiguous() and src.data_ptr() % 16 == 0 and src.numel() * src.element_size() == nb
+            ents.append(_l.ZeroEntry(t.data_ptr(), nb, blk, 0, src.data_ptr() if src is not None else None))
             blk += (nb + _l.ZERO_BLOCK_BYTES - 1) // _l.ZERO_BLOCK_BYTES
         self.n, self.blocks = len(ents), blk
         self.table = None
@@ -404,6 +408,18 @@ def bn_bwd_apply(dz, x, a, b, relu, mean, k1, k2, k3, dx, accumulate=False, drop
                                     stream()), "hdu_bn_bwd_apply")
 
 
+def bn_bwd_fused(dz, x, a, b, relu, mean, rstd, batch_stats, gamma, beta, sgamma, sums, slots, dgamma, dbeta, dsgamma,
+                 dsbeta, dx, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None):
+    """reduction (float atomics into the zeroed [slots][2][C] table `sums`) + coefficients / parameter gradients / dx: two
+    launches (include/hdu.h: hdu_bn_bwd_fused)"""
+    check(_l.get().hdu_bn_bwd_fused(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
+                                    fptr(mean), fptr(rstd), 1 if batch_stats else 0, fptr(gamma), fptr(beta), fptr(sgamma),
+                                    fptr(sums), slots, fptr(dgamma), fptr(dbeta), fptr(dsgamma), fptr(dsbeta), dx.ptr, dx.ld,
+                                    1 if accumulate else 0, drop_keep, drop_seed,
+                                    ctypes.c_void_p(drop_seed_dev.data_ptr()) if drop_seed_dev is not None else None,
+                                    stream()), "hdu_bn_bwd_fused")
+
+
 def bn_bwd_finalize(partial, slots, M, C, batch_stats, gamma, beta, sgamma, mean, rstd, dgamma, dbeta, dsgamma, dsbeta,
                     corr3, corr4):
     check(_l.get().hdu_bn_bwd_finalize(fptr(partial), slots, M, C, 1 if batch_stats else 0, fptr(gamma), fptr(beta),
@@ -436,12 +452,29 @@ def bn_stats_finalize(partial, slots, M, C, shift, mean, var, fold=None):
                                          stream()), "hdu_bn_stats_finalize")
 
 
-def bn_stats_finalize_fold_next(partial, slots, M, Cseg, seg_c0, C_all, mean_all, var_all, fold):
+def bn_stats_finalize_fold_next(partial, slots, M, Cseg, seg_c0, C_all, shift_all, mean_all, var_all, fold):
     """finalize the segment's epilogue statistics and fold the next BN over [0, C_all) in one launch (fold as above)"""
     g, be, eps, sg, sb, a, b, r, mm, mv, mom = fold
-    check(_l.get().hdu_bn_stats_finalize_fold_next(fptr(partial), slots, M, Cseg, seg_c0, C_all, fptr(mean_all), fptr(var_all),
-                                                   fptr(g), fptr(be), eps, fptr(sg), fptr(sb), fptr(a), fptr(b), fptr(r),
-                                                   fptr(mm), fptr(mv), mom, stream()), "hdu_bn_stats_finalize_fold_next")
+    check(_l.get().hdu_bn_stats_finalize_fold_next(fptr(partial), slots, M, Cseg, seg_c0, C_all, fptr(shift_all),
+                                                   fptr(mean_all), fptr(var_all), fptr(g), fptr(be), eps, fptr(sg), fptr(sb),
+                                                   fptr(a), fptr(b), fptr(r), fptr(mm), fptr(mv), mom, stream()),
+          "hdu_bn_stats_finalize_fold_next")
+
+
+def materialize_stats(x, stats, relu, up, skip, out):
+    """hdu_materialize with the BN folded inside the launch from a conv epilogue's sums.
+    stats = (partial, slots, M, Cseg, seg_c0, shift, mean, var, fold) with fold = (gamma, beta, eps, sgamma, sbeta, a, b, rstd,
+    mov_mean, mov_var, momentum); shift / mean / var are indexed by the BN's channel (= channel of x)."""
+    partial, slots, M, Cseg, seg_c0, shift, mean, var, fold = stats
+    g, be, eps, sg, sb, a, b, r, mm, mv, mom = fold
+    f = _l.BnStatsFold()
+    f.partial, f.slots, f.Cseg, f.seg_c0, f.M = fptr(partial), slots, Cseg, seg_c0, M
+    f.shift, f.mean, f.var = fptr(shift), fptr(mean), fptr(var)
+    f.gamma, f.beta, f.sgamma, f.sbeta, f.eps, f.momentum = fptr(g), fptr(be), fptr(sg), fptr(sb), eps, mom
+    f.a, f.b, f.rstd, f.mov_mean, f.mov_var = fptr(a), fptr(b), fptr(r), fptr(mm), fptr(mv)
+    check(_l.get().hdu_materialize_stats(x.dtype, x.ptr, x.ld, x.N, x.D, x.H, x.W, x.C, ctypes.byref(f), 1 if relu else 0,
+                                         up[0], up[1], up[2], skip.ptr if skip is not None else None,
+                                         skip.ld if skip is not None else 0, out.ptr, out.ld, stream()), "hdu_materialize_stats")
 
 
 def colsum(x, out, ws):

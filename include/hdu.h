@@ -306,6 +306,18 @@ int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int
                      const float* k2, const float* k3, void* dx, int64_t lddx, int accumulate, float drop_keep,
                      uint32_t drop_seed, const uint32_t* drop_seed_dev, void* stream);
 
+/* The whole BatchNormalization(+Scale)+ReLU backward in TWO launches (hdu_bn_bwd_reduce_coef + hdu_bn_bwd_apply take three).
+ * Launch 1 adds every workgroup's column sums (S1 = sum g, S2 = sum g*xhat) to row (workgroup % slots) of `sums`
+ * ([slots][2][C] float32, 1 <= slots <= 64, ZERO on entry: hdu_zero_regions) with float atomics; launch 2 sums the slot rows
+ * for its own channels, derives k1 / k2 / k3 in registers (formulas of hdu_bn_bwd_coef) and writes dx like hdu_bn_bwd_apply;
+ * its first row block writes the parameter gradients (any of them may be NULL).  Per-channel vectors 16-byte aligned.
+ * A finalize launch costs ~4.8 us of pure latency per BatchNormalization (161 of them in one DenseUNet-161 step). */
+int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C, const float* a,
+                     const float* b, int relu, const float* mean, const float* rstd, int batch_stats, const float* gamma,
+                     const float* beta, const float* sgamma, float* sums, int slots, float* dgamma, float* dbeta,
+                     float* dsgamma, float* dsbeta, void* dx, int64_t lddx, int accumulate, float drop_keep,
+                     uint32_t drop_seed, const uint32_t* drop_seed_dev, void* stream);
+
 /* materialise z = relu?(a*x+b) (needed where the activation is consumed by pooling / as a skip / HFF operand) */
 int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, const float* a, const float* b,
                    int relu, void* z, int64_t ldz, void* stream);
@@ -331,9 +343,33 @@ int hdu_bn_stats_finalize(const float* partial, int slots, int64_t M, int C, con
  * layer l+1's first BatchNormalization of a dense block (denseunet.py:229-262) reads the concatenation that layer l's
  * 3x3 conv has just extended.  One launch; results identical to the two separate calls. */
 int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, int Cseg, int seg_c0, int C_all,
-                                    float* mean_all, float* var_all, const float* gamma, const float* beta, float eps,
-                                    const float* sgamma, const float* sbeta, float* a, float* b, float* rstd,
-                                    float* mov_mean, float* mov_var, float momentum, void* stream);
+                                    const float* shift_all, float* mean_all, float* var_all, const float* gamma,
+                                    const float* beta, float eps, const float* sgamma, const float* sbeta, float* a, float* b,
+                                    float* rstd, float* mov_mean, float* mov_var, float momentum, void* stream);
+
+/* hdu_materialize with the BatchNormalization folded INSIDE the launch from a conv epilogue's statistics -- no finalize launch
+ * between the producing conv and the pass that applies the BN (a finalize costs ~4.7 us of pure latency; DenseUNet-161 has
+ * 162 of them per training step).  The BN's C input channels are the channels of x; the segment [seg_c0, seg_c0 + Cseg) of
+ * them was just written by a conv whose epilogue left sum(y - shift), sum((y - shift)^2) in `partial` ([slots][2][Cseg],
+ * slots <= 64), the other channels take the stored moments mean[c] / var[c] (dense blocks: the slab written by earlier
+ * layers).  Every workgroup derives a / b for its own channels in registers; the first row block writes a, b, rstd, the
+ * segment's mean / var and the moving averages, exactly as hdu_bn_stats_finalize(_fold_next) would have.
+ * `shift` must not alias `mean` (the launch reads one while it writes the other): the caller refreshes shift <- mean between
+ * steps (hdu_zero_regions copy entries).  Segment bounds: multiples of the 16-byte chunk; vectors 16-byte aligned. */
+typedef struct hdu_stats_fold_desc {
+  const float* partial;
+  int32_t slots, Cseg, seg_c0, pad_;
+  int64_t M;                 /* pixels the sums run over */
+  const float* shift;        /* [C] */
+  float* mean;               /* [C] in (non-segment channels) / out (segment) */
+  float* var;
+  const float* gamma; const float* beta; const float* sgamma; const float* sbeta;     /* [C]; any may be NULL */
+  float eps, momentum;
+  float* a; float* b; float* rstd; float* mov_mean; float* mov_var;                     /* [C]; rstd / mov_* may be NULL */
+} hdu_stats_fold_desc;
+int hdu_materialize_stats(int dtype, const void* x, int64_t ldx, int N, int D, int H, int W, int C, const hdu_stats_fold_desc* f,
+                          int relu, int ud, int uh, int uw, const void* skip, int64_t ldskip, void* out, int64_t ldout,
+                          void* stream);
 
 /* sync-BN over the depth shards of one volume.  buf: hdu_stats_sync_floats(C, world) floats = [world][1 + 2C].
  * hdu_stats_pack writes (n_local, mean, var) into slot `rank` and zeros into the other slots; the caller SUM-all-reduces buf
@@ -409,6 +445,8 @@ typedef struct hdu_zero_entry {
   uint64_t bytes;
   uint32_t block_begin;
   uint32_t pad_;
+  const void* src;            /* NULL: the region is cleared; else `bytes` are copied from src (16-byte aligned, no overlap) --
+                               * the shifts of the epilogue statistics take last step's means in the same launch */
 } hdu_zero_entry;
 int hdu_zero_regions(const hdu_zero_entry* dev_table, int n, uint32_t total_blocks, uint32_t* counter, uint32_t counter_inc,
                      void* stream);

@@ -278,7 +278,7 @@ def test_bn_stats_finalize_fold_next(hdu):
         mm, mv = torch.full((C_all,), 0.5, device=dev_), torch.full((C_all,), 2.0, device=dev_)
         fold = (gamma, beta, 1.1e-5, sg, sb, a, b, r, mm, mv, 0.99)
         if fused:
-            ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, c0, C_all, mean[:C_all], var[:C_all], fold)
+            ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, c0, C_all, mean.clone()[:C_all], mean[:C_all], var[:C_all], fold)
         else:
             ops.bn_stats_finalize(partial, slots, M, Cseg, mean[c0:c0 + Cseg], mean[c0:c0 + Cseg], var[c0:c0 + Cseg])
             ops.bn_fold(C_all, mean[:C_all], var[:C_all], gamma, beta, 1.1e-5, sg, sb, a, b, r, mm, mv, 0.99)
@@ -287,7 +287,62 @@ def test_bn_stats_finalize_fold_next(hdu):
         assert torch.equal(u, v)
     assert not torch.equal(outs[0][0][c0:c0 + Cseg], mean0[c0:c0 + Cseg]) and torch.equal(outs[0][0][C_all:], mean0[C_all:])
     with pytest.raises(hdu.lib.HduError):
-        ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, C_all - 3, C_all, mean, var, fold)
+        ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, C_all - 3, C_all, mean.clone(), mean, var, fold)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("seg", ["whole", "tail"])
+def test_materialize_stats(hdu, dtype, seg):
+    """hdu_materialize_stats == hdu_bn_stats_finalize(_fold_next) followed by hdu_materialize: the output tensor and
+    everything the finalize launch would have published (a, b, rstd, the segment's moments, the moving averages), with an
+    up-sampled input and a skip add, several column groups and row blocks"""
+    ops = ops_mod()
+    dev_ = ops.device()
+    N, D, H, W = 2, 1, 12, 20
+    C = 304 if seg == "tail" else 192                  # tail: a dense-block slab, the last 48 channels just written
+    Cseg, c0 = (48, C - 48) if seg == "tail" else (C, 0)
+    slots, M = 32, N * D * H * W
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float32)
+    x = q(rnd((N, D, H, W, C), 21, 2.0, dtype) + 0.3, dtype)
+    skip = q(rnd((N, D, 2 * H, 2 * W, C), 22, 1.0, dtype), dtype)
+    xa, ska = mkact(ops, x, dtype), mkact(ops, skip, dtype)
+    shift0 = rn(C) * 0.5
+    # slot sums of (y - shift), (y - shift)^2 over the segment channels, spread over the slot rows like a conv epilogue
+    xs = x.reshape(-1, C)[:, c0:c0 + Cseg] - shift0[c0:c0 + Cseg].double()
+    rows = torch.arange(M) % slots
+    part = torch.zeros(slots, 2, Cseg, dtype=torch.float64)
+    part[:, 0].index_add_(0, rows, xs)
+    part[:, 1].index_add_(0, rows, xs * xs)
+    partial = part.float().to(dev_).reshape(-1)
+    mean0, var0 = rn(C) * 0.3, rn(C).abs() + 0.2
+    gamma, beta, sg, sb = (rn(C) * 0.2 + 1.0).to(dev_), rn(C).to(dev_), (rn(C) * 0.2 + 1.0).to(dev_), rn(C).to(dev_)
+    outs = []
+    for fused in (True, False):
+        shift, mean, var = shift0.clone().to(dev_), mean0.clone().to(dev_), var0.clone().to(dev_)
+        a, b, r = (torch.zeros(C, device=dev_) for _ in range(3))
+        mm, mv = torch.full((C,), 0.5, device=dev_), torch.full((C,), 2.0, device=dev_)
+        fold = (gamma, beta, 1.1e-5, sg, sb, a, b, r, mm, mv, 0.99)
+        out = ops.Act.alloc(N, D, 2 * H, 2 * W, C, dtype)
+        if fused:
+            ops.materialize_stats(xa, (partial, slots, M, Cseg, c0, shift, mean, var, fold), True, (0, 1, 1), ska, out)
+        else:
+            if seg == "tail":
+                ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, c0, C, shift, mean, var, fold)
+            else:
+                ops.bn_stats_finalize(partial, slots, M, C, shift, mean, var, fold)
+            ops.materialize(xa, a, b, True, (0, 1, 1), ska, out)
+        outs.append([t.cpu() for t in (mean, var, a, b, r, mm, mv)] + [out.to_torch().cpu().float()])
+    names = ["mean", "var", "a", "b", "rstd", "mov_mean", "mov_var", "out"]
+    for nm, u, v in zip(names, *outs):
+        tolv = 2e-2 if (nm == "out" and dtype == BF16) else 2e-5
+        assert float((u.double() - v.double()).abs().max()) <= tolv * max(1.0, float(v.abs().max())), nm
+    # the statistics really are those of the tensor
+    xm = x.reshape(-1, C)[:, c0:c0 + Cseg]
+    assert float((outs[0][0][c0:c0 + Cseg].double() - xm.mean(0)).abs().max()) < 1e-4
+    assert float((outs[0][1][c0:c0 + Cseg].double() - xm.var(0, unbiased=False)).abs().max()) < 1e-3
+    with pytest.raises(hdu.lib.HduError):
+        ops.materialize_stats(xa, (partial, slots, M, Cseg, c0 + 4, shift, mean, var, fold), True, (0, 1, 1), ska, out)
 
 
 def test_conv_wgrad_batched_plan(hdu):
@@ -633,6 +688,49 @@ def test_bn_backward(hdu, dtype, batch_stats):
     # accumulate
     ops.bn_bwd_apply(dza, xa, a, b, True, mean, k1, k2, k3, dx, True)
     assert_close(dx.to_torch().cpu(), 2 * xr.grad, dtype, what="bn dx accumulate")
+    # the two-launch form (hdu_bn_bwd_fused): slot-table reduction + coefficients / parameter gradients / dx in the apply
+    for slots in (16, 3):
+        sums = torch.zeros(slots * 2 * C, device=ops.device())
+        dg2, db2, dsg2, dsb2 = [E() for _ in range(4)]
+        dx2 = ops.Act.alloc(N, D, H, W, C, dtype)
+        ops.bn_bwd_fused(dza, xa, a, b, True, mean, r, batch_stats, dv(g), dv(be), dv(sg), sums, slots, dg2, db2, dsg2, dsb2, dx2)
+        assert_close(dx2.to_torch().cpu(), xr.grad, dtype, what="fused bn dx")
+        for got, ref, nm in ((dg2, gr.grad, "dgamma"), (db2, ber.grad, "dbeta"), (dsg2, sgr.grad, "dsgamma"), (dsb2, sbr.grad, "dsbeta")):
+            assert_close(got.cpu(), ref, dtype, what="fused " + nm)
+        sums.zero_()
+        ops.bn_bwd_fused(dza, xa, a, b, True, mean, r, batch_stats, dv(g), dv(be), dv(sg), sums, slots, None, None, None, None,
+                         dx2, True)
+        assert_close(dx2.to_torch().cpu(), 2 * xr.grad, dtype, what="fused bn dx accumulate")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bn_backward_fused_wide(hdu, dtype):
+    """hdu_bn_bwd_fused over several column groups and many row blocks (C = 328 channels: 2 groups of 32 chunks in bf16, a
+    partial last group; M = 4096 rows) against the three-launch form of the same library"""
+    ops = ops_mod()
+    N, D, H, W, C = 1, 1, 64, 64, 328
+    x = q(rnd((N, D, H, W, C), 13, 2.0, dtype) + 0.25, dtype)
+    dz = rnd((N, D, H, W, C), 14, 1.0, dtype)
+    M = N * D * H * W
+    xa, dza = mkact(ops, x, dtype), mkact(ops, dz, dtype)
+    ws = ops.Workspace(ops.reduce_ws_bytes(M, C))
+    dv = lambda t: dev(ops, t)
+    E = lambda: torch.empty(C, device=ops.device())
+    g = dv((rnd((C,), 5, 0.5) + 1.0).float().double()); be = dv(rnd((C,), 6, 0.2).float().double())
+    mean, var, a, b, r, s1, s2, k1, k2, k3, dg, db, dg2, db2 = [E() for _ in range(14)]
+    ops.bn_stats(xa, mean, var, ws)
+    ops.bn_fold(C, mean, var, g, be, 1.1e-5, None, None, a, b, r)
+    ops.bn_bwd_reduce(dza, xa, a, b, True, mean, r, s1, s2, ws)
+    ops.bn_bwd_coef(C, M, True, s1, s2, g, be, None, r, k1, k2, k3, dg, db, None, None)
+    dx = ops.Act.alloc(N, D, H, W, C, dtype)
+    ops.bn_bwd_apply(dza, xa, a, b, True, mean, k1, k2, k3, dx)
+    sums = torch.zeros(16 * 2 * C, device=ops.device())
+    dx2 = ops.Act.alloc(N, D, H, W, C, dtype)
+    ops.bn_bwd_fused(dza, xa, a, b, True, mean, r, True, g, be, None, sums, 16, dg2, db2, None, None, dx2)
+    ref = dx.to_torch().cpu().double()
+    assert_close(dx2.to_torch().cpu(), ref, dtype, what="fused wide dx")
+    assert_close(dg2.cpu(), dg.cpu().double(), F32, scale=float(dg.abs().max()), what="fused wide dgamma")
+    assert_close(db2.cpu(), db.cpu().double(), F32, scale=float(db.abs().max()), what="fused wide dbeta")
 
 
 @pytest.mark.parametrize("dtype", DT)
