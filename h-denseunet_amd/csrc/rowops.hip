@@ -649,29 +649,47 @@ struct RowK {
 
 // Column totals of a [slots][2][C] slot table for the thread's own CH channels.  The ROWS row lanes of a column chunk split
 // the slot rows (one memory round trip for the whole table part of the workgroup), meet in LDS, and every lane then adds the
-// per-lane partials in a fixed order.  ALL 256 threads call it (barrier inside); lanes without a column pass active = false.
+// per-lane partials in a fixed order.  ALL 256 threads call it; lanes without a column pass active = false.
+// Two halves so that a caller can issue its first data rows between them: slot_loads() only requests, slot_reduce() meets at a
+// RAW barrier (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() carries a workgroup release fence, which on gfx9 is
+// s_waitcnt vmcnt(0) and would drain the caller's data loads too -- loads and stores share vmcnt).
 template <int CH, int COLS>
-__device__ __forceinline__ void slot_sums(const float* __restrict__ tbl, int slots, int C, int c0, bool active, int cc, int rl,
-                                          float (&s1)[CH], float (&s2)[CH]) {
+__device__ __forceinline__ void slot_loads(const float* __restrict__ tbl, int slots, int C, int c0, bool active, int rl,
+                                           float (&t1)[CH], float (&t2)[CH]) {
   constexpr int ROWS = 256 / COLS;
-  __shared__ float red[ROWS][2][COLS * CH];
-  float t1[CH], t2[CH];
+  constexpr int IT = 4;          // slots <= 32 <= IT * ROWS (ROWS >= 8): every slot row of this lane is requested at once --
+  // a runtime-count loop issues one row, waits, adds, and only then requests the next: 2-4 serial round trips per launch
+  f32x4 v1[IT][CH / 4], v2[IT][CH / 4];
 #pragma unroll
-  for (int j = 0; j < CH; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
-  if (active) {
-    for (int sl = rl; sl < slots; sl += ROWS) {
+  for (int it = 0; it < IT; ++it) {
+    const int sl = rl + it * ROWS;
+    const long long row = (active && sl < slots) ? sl : 0;      // unconditional, clamped (see igemm_epilogue)
 #pragma unroll
-      for (int j = 0; j < CH; j += 4) {
-        const f32x4 v1 = *(const f32x4*)(tbl + ((long long)sl * 2 + 0) * C + c0 + j);
-        const f32x4 v2 = *(const f32x4*)(tbl + ((long long)sl * 2 + 1) * C + c0 + j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { t1[j + r] += v1[r]; t2[j + r] += v2[r]; }
-      }
+    for (int j = 0; j < CH; j += 4) {
+      v1[it][j / 4] = *(const f32x4*)(tbl + (row * 2 + 0) * C + c0 + j);
+      v2[it][j / 4] = *(const f32x4*)(tbl + (row * 2 + 1) * C + c0 + j);
     }
   }
 #pragma unroll
+  for (int j = 0; j < CH; ++j) { t1[j] = 0.f; t2[j] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const bool ok = active && rl + it * ROWS < slots;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      t1[j] += ok ? v1[it][j / 4][j % 4] : 0.f;
+      t2[j] += ok ? v2[it][j / 4][j % 4] : 0.f;
+    }
+  }
+}
+template <int CH, int COLS>
+__device__ __forceinline__ void slot_reduce(int slots, int cc, int rl, const float (&t1)[CH], const float (&t2)[CH],
+                                            float (&s1)[CH], float (&s2)[CH]) {
+  constexpr int ROWS = 256 / COLS;
+  __shared__ float red[ROWS][2][COLS * CH];
+#pragma unroll
   for (int j = 0; j < CH; ++j) { red[rl][0][cc * CH + j] = t1[j]; red[rl][1][cc * CH + j] = t2[j]; }
-  __syncthreads();
+  HDU_RAW_BARRIER();
   const int nr = slots < ROWS ? slots : ROWS;
 #pragma unroll
   for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -758,8 +776,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
         g[j + r] = vg[r]; be[j + r] = ve[r]; sg[j + r] = vs[r];
       }
     }
-    float S1[CH], S2[CH];
-    slot_sums<CH, COLS>(p.sums, p.slots, p.C, cq, active, cc, rl, S1, S2);
+    float T1[CH], T2[CH], S1[CH], S2[CH];
+    slot_loads<CH, COLS>(p.sums, p.slots, p.C, cq, active, rl, T1, T2);
+    slot_reduce<CH, COLS>(p.slots, cc, rl, T1, T2, S1, S2);
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -960,8 +979,9 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
   const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
   float a[CH], b[CH];
   if constexpr (STATS) {
-    // (Requesting the thread's first rows BEFORE this prologue, so that its round trip overlaps the main loop's first one, was
-    // measured slower on the 2D step in both forms tried -- branch-guarded and unconditional: 20.41 -> 20.58 ms, round 3.)
+    // (Requesting the thread's first data rows BEFORE the workgroup meets, so that the two round trips overlap, was measured
+    // slower in three forms -- branch-guarded, unconditional, and unconditional behind the slot rows with a raw barrier and a
+    // scheduling barrier: the 16-32 extra live registers cost the large layers an occupancy step; 2D 20.46 -> 20.74 ms.)
     // No finalize launch between the producing conv and this pass: every workgroup turns the slot sums of its own segment
     // channels into (mean, var) -- or reads the stored moments of the other channels --, folds the BN(+Scale) in registers,
     // and the first row block publishes a / b / rstd / the moments / the moving averages for the backward pass and the
@@ -985,8 +1005,9 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
         mm[j + r] = v1[r]; mv[j + r] = v2[r];
       }
     }
-    float S1[CH], S2[CH];
-    slot_sums<CH, COLS>(p.st_partial, p.st_slots, p.Cseg, in_seg ? c0 - p.seg_c0 : 0, in_seg, cc, rl, S1, S2);
+    float T1[CH], T2[CH], S1[CH], S2[CH];
+    slot_loads<CH, COLS>(p.st_partial, p.st_slots, p.Cseg, in_seg ? c0 - p.seg_c0 : 0, in_seg, rl, T1, T2);
+    slot_reduce<CH, COLS>(p.st_slots, cc, rl, T1, T2, S1, S2);
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
@@ -1105,7 +1126,7 @@ extern "C" int hdu_materialize_stats(int dtype, const void* x, int64_t ldx, int 
   if (!x || !out || !f || ((ud | uh | uw) & ~1)) return hdu_set_error(HDU_ERR_ARG, "materialize_stats: bad pointers / upsample shifts");
   if (C <= 0 || C % ch || ldx % ch || ldout % ch || (skip && ldskip % ch) || N <= 0 || D <= 0 || H <= 0 || W <= 0)
     return hdu_set_error(HDU_ERR_ARG, "materialize_stats: C / strides must be multiples of the 16-byte chunk");
-  if (!f->partial || f->slots <= 0 || f->slots > 64 || f->M <= 0 || f->Cseg <= 0 || f->Cseg % ch || f->seg_c0 < 0 ||
+  if (!f->partial || f->slots <= 0 || f->slots > 32 || f->M <= 0 || f->Cseg <= 0 || f->Cseg % ch || f->seg_c0 < 0 ||
       f->seg_c0 % ch || f->seg_c0 + f->Cseg > C || !f->shift || !f->mean || !f->var || !f->a || !f->b)
     return hdu_set_error(HDU_ERR_ARG, "materialize_stats: bad statistics block (segment bounds are multiples of the 16-byte chunk)");
   if (((uintptr_t)f->partial | (uintptr_t)f->shift | (uintptr_t)f->mean | (uintptr_t)f->var | (uintptr_t)f->gamma |
@@ -1163,7 +1184,7 @@ extern "C" int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const v
                                 int64_t lddx, int accumulate, float drop_keep, uint32_t drop_seed,
                                 const uint32_t* drop_seed_dev, void* stream) {
   if (!dz || !x || !a || !b || !mean || !rstd || !sums || !dx) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: null pointer");
-  if (slots <= 0 || slots > 64) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: 1 <= slots <= 64");
+  if (slots <= 0 || slots > 32) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: 1 <= slots <= 32");
   if (((uintptr_t)sums | (uintptr_t)a | (uintptr_t)b | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta |
        (uintptr_t)sgamma) & 15)
     return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: per-channel vectors must be 16-byte aligned");

@@ -308,7 +308,7 @@ int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const void* x, int
 
 /* The whole BatchNormalization(+Scale)+ReLU backward in TWO launches (hdu_bn_bwd_reduce_coef + hdu_bn_bwd_apply take three).
  * Launch 1 adds every workgroup's column sums (S1 = sum g, S2 = sum g*xhat) to row (workgroup % slots) of `sums`
- * ([slots][2][C] float32, 1 <= slots <= 64, ZERO on entry: hdu_zero_regions) with float atomics; launch 2 sums the slot rows
+ * ([slots][2][C] float32, 1 <= slots <= 32, ZERO on entry: hdu_zero_regions) with float atomics; launch 2 sums the slot rows
  * for its own channels, derives k1 / k2 / k3 in registers (formulas of hdu_bn_bwd_coef) and writes dx like hdu_bn_bwd_apply;
  * its first row block writes the parameter gradients (any of them may be NULL).  Per-channel vectors 16-byte aligned.
  * A finalize launch costs ~4.8 us of pure latency per BatchNormalization (161 of them in one DenseUNet-161 step). */
@@ -351,7 +351,7 @@ int hdu_bn_stats_finalize_fold_next(const float* partial, int slots, int64_t M, 
  * between the producing conv and the pass that applies the BN (a finalize costs ~4.7 us of pure latency; DenseUNet-161 has
  * 162 of them per training step).  The BN's C input channels are the channels of x; the segment [seg_c0, seg_c0 + Cseg) of
  * them was just written by a conv whose epilogue left sum(y - shift), sum((y - shift)^2) in `partial` ([slots][2][Cseg],
- * slots <= 64), the other channels take the stored moments mean[c] / var[c] (dense blocks: the slab written by earlier
+ * slots <= 32), the other channels take the stored moments mean[c] / var[c] (dense blocks: the slab written by earlier
  * layers).  Every workgroup derives a / b for its own channels in registers; the first row block writes a, b, rstd, the
  * segment's mean / var and the moving averages, exactly as hdu_bn_stats_finalize(_fold_next) would have.
  * `shift` must not alias `mean` (the launch reads one while it writes the other): the caller refreshes shift <- mean between
