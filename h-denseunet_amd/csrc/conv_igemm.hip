@@ -1565,7 +1565,11 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
 // bf16 filter gradient, DMA + transpose-read form (operands need no arithmetic: materialised inputs).
 // PW = point-wise (1x1x1, stride 1, no padding, no up-sampling): input pixel == output pixel, so the per-row
 // (n, d, h, w) decode, the tap bounds tests and the per-step carry loops disappear from the K loop.
-template <int BCO, bool PW>
+// NCT = filter-row tiles of BCO channels one workgroup accumulates over the SAME staged x tile (round 3): the activations are
+// the large operand of a pointwise layer (M x Cin, Cin up to 2112, against M x 192 of dy), and with one BCO = 64 tile per
+// workgroup every x tile was fetched by 3 workgroups; NCT = 3 reads it once (LDS per stage 16 + 3 x 8 KB, two workgroups
+// per CU instead of three).
+template <int BCO, bool PW, int NCT = 1>
 __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict__ dw, long long rows_per_split,
                                                unsigned bid, char* smem) {
   typedef bf16_t T;
@@ -1576,7 +1580,7 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
   constexpr int DROWB = 128;
   constexpr int TM = BCO / 16;
   constexpr int TN = 2;
-  constexpr int STAGE = PX * (XROWB + DROWB);
+  constexpr int STAGE = PX * (XROWB + NCT * DROWB);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1593,7 +1597,7 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
   unsigned wbx, wby, wbz;
   if (!wgrad_block(p, bid, &wbx, &wby, &wbz)) return;
   const int kcol0 = (int)wbx * BKC;
-  const int co0 = (int)wby * BCO;
+  const int co0 = (int)wby * BCO * NCT;
   const long long m_begin = (long long)wbz * rows_per_split;
   long long m_end = m_begin + rows_per_split;
   if (m_end > p.M) m_end = p.M;
@@ -1634,7 +1638,9 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
   const int gd = ((dpx0 >> 1) & 1) | (((dpx0 >> 3) & 1) << 1);
   const int dp16 = tid & 7;
   const int dcl = ((((dp16 >> 1) ^ gd) << 1) | (dp16 & 1));
-  const bool dvalid = dcl * CH < BCO && co0 + dcl * CH < p.Cout;
+  bool dvalid[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) dvalid[t] = dcl * CH < BCO && co0 + t * BCO + dcl * CH < p.Cout;
 
   auto issue_tile = [&](int buf, long long mt) {
     char* Xt = smem + buf * STAGE;
@@ -1656,11 +1662,13 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
       hdu_glds16(g, Xt + (i * 16 + wave * 4) * XROWB);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long long m = mt + dpx0 + j * 32;
-      const char* g = (dvalid && m < m_end) ? (const char*)(dyp + m * p.ldy + co0 + dcl * CH) : zero;
-      hdu_glds16(g, Dt + (j * 32 + wave * 8) * DROWB);
-    }
+    for (int t = 0; t < NCT; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const long long m = mt + dpx0 + j * 32;
+        const char* g = (dvalid[t] && m < m_end) ? (const char*)(dyp + m * p.ldy + co0 + t * BCO + dcl * CH) : zero;
+        hdu_glds16(g, Dt + t * (PX * DROWB) + (j * 32 + wave * 8) * DROWB);
+      }
   };
 
   auto advance_pixels = [&]() {
@@ -1681,11 +1689,13 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
     }
   };
 
-  f32x4 acc[TM][TN];
+  f32x4 acc[NCT][TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int t = 0; t < NCT; ++t)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = (int)((m_end - m_begin + PX - 1) / PX);
   if (nsteps > 0) issue_tile(0, m_begin);
@@ -1705,13 +1715,6 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
         u32x4 af[TM], bf[TN];
         const int prow = kg * 32 + lg * 8 + (li >> 2);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int bc = (i * 16 + (li & 3) * 4) * 2;
-          const u32x2 lo = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow, bc));
-          const u32x2 hi = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow + 4, bc));
-          af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
-        }
-#pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int bc = (wave * 32 + j * 16 + (li & 3) * 4) * 2;
           const u32x2 lo = hdu_lds_tr16_b64(Xt + tr_off<XROWB>(prow, bc));
@@ -1719,26 +1722,38 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
           bf[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int t = 0; t < NCT; ++t) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int i = 0; i < TM; ++i) {
+            const int bc = (i * 16 + (li & 3) * 4) * 2;
+            const u32x2 lo = hdu_lds_tr16_b64(Dt + t * (PX * DROWB) + tr_off<DROWB>(prow, bc));
+            const u32x2 hi = hdu_lds_tr16_b64(Dt + t * (PX * DROWB) + tr_off<DROWB>(prow + 4, bc));
+            af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[t][i][j] = Mma<T>::kgroup(af[i], bf[j], acc[t][i][j]);
+        }
       }
     }
     __syncthreads();
   }
 
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int t = 0; t < NCT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
-      if (co >= p.Cout) continue;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int kcol = kcol0 + wave * 32 + j * 16 + (lane & 15);
-        if (kcol < p.Ktot && !(p.debug_flags & 4)) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + t * BCO + i * 16 + (lane >> 4) * 4 + r;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int kcol = kcol0 + wave * 32 + j * 16 + (lane & 15);
+          if (kcol < p.Ktot && !(p.debug_flags & 4)) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[t][i][j][r]);
+        }
       }
-    }
 }
 
 // =====================================================================================
@@ -1889,10 +1904,10 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
 // one launch covers MANY layers (hdu_wgrad_plan_run): filter gradients feed nothing but the optimiser, so the engine
 // defers them to the end of the backward pass; the late dense layers (2048..8192 pixels) that cannot fill the chip on
 // their own then share it, and ~135 launches per step (ramp-up, tail, drain each) become a handful.
-template <int BCO, bool PW>
+template <int BCO, bool PW, int NCT = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * (256 + 128)];
-  wgrad_dma_body<BCO, PW>(p, dw, rows_per_split, blockIdx.x, smem);
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * (256 + NCT * 128)];
+  wgrad_dma_body<BCO, PW, NCT>(p, dw, rows_per_split, blockIdx.x, smem);
 }
 
 template <int BCO>
@@ -1911,13 +1926,13 @@ __device__ __forceinline__ int batched_find(const unsigned* __restrict__ begins,
   return lo;
 }
 
-template <int BCO, bool PW>
+template <int BCO, bool PW, int NCT = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_batched_kernel(const WgradEntry* __restrict__ tab,
                                                                      const unsigned* __restrict__ begins, int n) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * (256 + 128)];
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * (256 + NCT * 128)];
   const int e = batched_find(begins, n, blockIdx.x);
   const ConvK p = tab[e].k;
-  wgrad_dma_body<BCO, PW>(p, tab[e].dw, tab[e].per, blockIdx.x - begins[e], smem);
+  wgrad_dma_body<BCO, PW, NCT>(p, tab[e].dw, tab[e].per, blockIdx.x - begins[e], smem);
 }
 
 template <int BCO>
@@ -2712,9 +2727,16 @@ static bool wgrad_pointwise(const ConvK& k) {
 // work grid of the DMA filter gradient: k-column tiles x filter-row tiles x pixel splits.  Pixel splits: fill the chip
 // (`target` workgroups) but keep >= min_steps steps of 64 pixels per workgroup so that the pipeline fill and the float
 // atomics of the partial tile are amortised.  Returns the pixel rows per split.
-static long long wgrad_dma_geometry(const ConvK& k, int BCO, int target, ConvK* kk, int default_min_steps = 4) {
+// filter-row tiles one workgroup accumulates (wgrad_dma_body NCT): pointwise layers whose Cout spans 2 or 3 tiles of 64
+static int wgrad_nct(const ConvK& k, int BCO) {
+  if (g_tuning[HDU_TUNE_WGRAD_NCT] == 1 || !wgrad_pointwise(k) || BCO != 64) return 1;
+  const int tiles = (k.Cout + BCO - 1) / BCO;
+  return tiles >= 3 ? 3 : (tiles == 2 ? 2 : 1);
+}
+
+static long long wgrad_dma_geometry(const ConvK& k, int BCO, int target, ConvK* kk, int default_min_steps = 4, int nct = 1) {
   constexpr int PX = 64;
-  const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
+  const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO * nct - 1) / (BCO * nct));
   long long want = target / ((long long)gx * gy);
   if (want < 1) want = 1;
   long long steps = (k.M + PX - 1) / PX;
@@ -2733,8 +2755,13 @@ template <int BCO>
 static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
   const int target = g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768;
   ConvK kk;
-  const long long rows_per = wgrad_dma_geometry(k, BCO, target, &kk);
+  const int nct = (k.pro_a == nullptr && k.skip == nullptr) ? wgrad_nct(k, BCO) : 1;
+  const long long rows_per = wgrad_dma_geometry(k, BCO, target, &kk, 4, nct);
   if (k.pro_a == nullptr && k.skip == nullptr) {
+    if constexpr (BCO == 64) {
+      if (nct == 3) { HDU_LAUNCH((conv_wgrad_dma_kernel<64, true, 3>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per); return; }
+      if (nct == 2) { HDU_LAUNCH((conv_wgrad_dma_kernel<64, true, 2>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per); return; }
+    }
     if (wgrad_pointwise(k)) HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, true>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
     else HDU_LAUNCH((conv_wgrad_dma_kernel<BCO, false>), dim3(wgrad_grid(kk)), dim3(256), 0, s, kk, dw, rows_per);
   } else
@@ -2804,7 +2831,8 @@ extern "C" int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream) {
 }
 
 // ---- batched filter gradients (see conv_wgrad_*_batched_kernel).  Variant id = kernel family of an entry:
-// 0..5 DMA form <BCO, PW> = (64|48|32) x (false|true); 8..10 halo-tile form <64|48|32>.
+// 0..5 DMA form <BCO, PW> = (64|48|32) x (false|true); 6 / 7 pointwise <64, true> with 3 / 2 filter-row tiles per workgroup;
+// 8..10 halo-tile form <64|48|32>.
 extern "C" size_t hdu_wgrad_plan_entry_bytes(void) { return sizeof(WgradEntry); }
 
 extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, void* entry, int* variant,
@@ -2823,8 +2851,9 @@ extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target
     *variant = 8 + bi;
   } else {
     const int target = target_wgs > 0 ? target_wgs : (g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768);
-    e->per = wgrad_dma_geometry(k, best, target, &e->k, 8);   // batched: other layers fill the chip, fewer atomics win (swept)
-    *variant = bi * 2 + (wgrad_pointwise(k) ? 1 : 0);
+    const int nct = wgrad_nct(k, best);
+    e->per = wgrad_dma_geometry(k, best, target, &e->k, 8, nct);   // batched: other layers fill the chip, fewer atomics win (swept)
+    *variant = nct == 3 ? 6 : (nct == 2 ? 7 : bi * 2 + (wgrad_pointwise(k) ? 1 : 0));
   }
   e->dw = dw;
   *nblocks = wgrad_grid(e->k);
@@ -2844,6 +2873,8 @@ extern "C" int hdu_wgrad_plan_run(int variant, const void* dev_entries, const ui
     case 3: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<48, true>), g, b, 0, s, tab, dev_begins, n); break;
     case 4: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<32, false>), g, b, 0, s, tab, dev_begins, n); break;
     case 5: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<32, true>), g, b, 0, s, tab, dev_begins, n); break;
+    case 6: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<64, true, 3>), g, b, 0, s, tab, dev_begins, n); break;
+    case 7: HDU_LAUNCH((conv_wgrad_dma_batched_kernel<64, true, 2>), g, b, 0, s, tab, dev_begins, n); break;
     case 8: HDU_LAUNCH((conv_wgrad_halo_batched_kernel<64>), g, b, 0, s, tab, dev_begins, n); break;
     case 9: HDU_LAUNCH((conv_wgrad_halo_batched_kernel<48>), g, b, 0, s, tab, dev_begins, n); break;
     case 10: HDU_LAUNCH((conv_wgrad_halo_batched_kernel<32>), g, b, 0, s, tab, dev_begins, n); break;

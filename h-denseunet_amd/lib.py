@@ -240,6 +240,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(19, int(os.environ["HDU_NO_PW_BSTAT"]))
     if "HDU_PW_BSTAT_WGS" in os.environ:
         lib.hdu_set_tuning(20, int(os.environ["HDU_PW_BSTAT_WGS"]))
+    if "HDU_WGRAD_NCT" in os.environ:
+        lib.hdu_set_tuning(21, int(os.environ["HDU_WGRAD_NCT"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
         lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
 

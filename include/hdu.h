@@ -69,6 +69,7 @@ size_t hdu_sizeof_conv_desc(void);
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
 #define HDU_TUNE_NO_PW_BSTAT 19      /* 1 = disable the filter-stationary pointwise kernel (A/B) */
 #define HDU_TUNE_PW_BSTAT_WGS 20     /* workgroups that kernel aims for (default 256) */
+#define HDU_TUNE_WGRAD_NCT 21        /* 1 = one filter-row tile per pointwise filter-gradient workgroup (round 2's form; A/B) */
 int hdu_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------ convolution
