@@ -549,6 +549,46 @@ extern "C" int hdu_bn_fold_batched(const hdu_fold_entry* table, const uint32_t* 
   return hdu_check_launch("bn_fold_batched");
 }
 
+// parameter gradients of MANY inference-mode BN(+Scale) layers from the slot sums their data-gradient epilogues left: one
+// launch at the end of the backward pass instead of one ~4.6 us finalize per layer inside it (nothing in the backward chain
+// reads them: frozen statistics have no k2 / k3 terms).  Geometry of reduce_finalize_kernel: 8 channels x 32 slot lanes.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_batched_kernel(const hdu_bnbwd_entry* __restrict__ table,
+                                                                      const unsigned* __restrict__ begins, int n) {
+  __shared__ double red[2][4][8];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (begins[mid] <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hdu_bnbwd_entry e = table[lo];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = (int)(blockIdx.x - begins[lo]) * 8 + cl;
+  const bool mine = pl == 0 && c < e.C;
+  const float g = (mine && e.gamma) ? e.gamma[c] : 1.f, be = (mine && e.beta) ? e.beta[c] : 0.f;
+  const float sg = (mine && e.sgamma) ? e.sgamma[c] : 1.f;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < e.C) {
+    for (int b = pl; b < e.slots; b += 32) {
+      a1 += (double)e.partial[((long long)b * 2 + 0) * e.C + c];
+      a2 += (double)e.partial[((long long)b * 2 + 1) * e.C + c];
+    }
+  }
+  fin_reduce32(a1, a2, red);
+  if (!mine) return;
+  const float S1 = (float)a1, S2 = (float)a2;
+  if (e.dgamma) e.dgamma[c] = sg * S2;
+  if (e.dbeta) e.dbeta[c] = sg * S1;
+  if (e.dsgamma) e.dsgamma[c] = g * S2 + be * S1;
+  if (e.dsbeta) e.dsbeta[c] = S1;
+}
+
+extern "C" int hdu_bn_bwd_finalize_batched(const hdu_bnbwd_entry* table, const uint32_t* begins, int n, uint32_t total_blocks,
+                                           void* stream) {
+  if (!table || !begins || n <= 0 || total_blocks == 0) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_finalize_batched: bad args");
+  HDU_LAUNCH(bn_bwd_finalize_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, begins, n);
+  return hdu_check_launch("bn_bwd_finalize_batched");
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(int C, float invM, int batch_stats, const float* s1,
                                                           const float* s2, const float* gamma, const float* beta,
                                                           const float* sgamma, const float* rstd, float* k1,

@@ -168,6 +168,8 @@ class Ctx:
         # of data-gradient epilogues (the u / gradient-slab loads are exposed: 2-3 workgroups per CU cannot hide them
         # the way the 2048-workgroup streaming kernels do) and +1.0 ms of correction launches: neutral (23.1 vs 23.2 ms).
         # Default 1 = inference-mode BNs only; 2 = every BN (tests cover both); 0 = off.
+        self.defer_bnb_finalize = os.environ.get("HDU_DEFER_BNB_FINALIZE", "1") == "1"
+        self._bnb_deferred, self._bnb_plan = [], None
         self.absorb_stats = os.environ.get("HDU_ABSORB_STATS", "1") == "1"     # BN fold inside the consumer's materialize pass
         self.bn_bwd_fused = os.environ.get("HDU_BN_BWD_FUSED", "1") == "1"      # two-launch BN backward (hdu_bn_bwd_fused)
         self.fuse_bn_bwd_mode = int(os.environ.get("HDU_FUSE_BN_BWD", "1"))
@@ -501,8 +503,15 @@ class Ctx:
                 self._zp_bwd.run()         # (a training step's head launch has already cleared the whole arena)
                 self._zeroed_bwd_pass = self.pass_id
         order = list(reversed(self.bwd))
+        if lo == 0:
+            self._bnb_deferred = []
         for f in order[lo:hi]:
             f()
+        if hi == len(self.bwd) and self._bnb_deferred:
+            keys = tuple(k for k, _ in self._bnb_deferred)
+            if self._bnb_plan is None or self._bnb_plan[0] != keys:       # (the set is fixed by the model: built once)
+                self._bnb_plan = (keys, ops.BnBwdPlan([e for _, e in self._bnb_deferred]))
+            self._bnb_plan[1].run()
         if hi == len(self.bwd) and self.wgrad_plan is not None:
             self.wgrad_plan.run()
 
@@ -955,6 +964,14 @@ def _conv_backward_fused_bn(self, dy):
             ld = r.act.ld
             base = r.corr_off + xv.c0
             c3, c4 = ctx.corr_acc[base:base + bn.C], ctx.corr_acc[base + ld:base + ld + bn.C]
+        if not bn.batch_now and ctx.batch_wgrad and ctx.defer_bnb_finalize:
+            # inference-mode BN: the sums feed parameter gradients only -- finalized with every other such layer by ONE launch
+            # at the end of the backward pass (run_backward), like the deferred filter gradients
+            ctx._bnb_deferred.append((id(self), (part, self.BNB_SLOTS, bn.C, bn.gamma.data, bn.beta.data,
+                                                 bn.sg.data if bn.sg else None, bn.gamma.grad if tr_bn else None,
+                                                 bn.beta.grad if tr_bn else None, bn.sg.grad if tr_sc else None,
+                                                 bn.sb.grad if tr_sc else None)))
+            return
         ops.bn_bwd_finalize(part, self.BNB_SLOTS, x.M, bn.C, bn.batch_now, bn.gamma.data, bn.beta.data,
                             bn.sg.data if bn.sg else None, bn.mean_used, bn.rstd,
                             bn.gamma.grad if tr_bn else None, bn.beta.grad if tr_bn else None,

@@ -69,6 +69,12 @@ class ZeroEntry(ctypes.Structure):
                 ("src", c_p)]
 
 
+class BnBwdEntry(ctypes.Structure):
+    """include/hdu.h: hdu_bnbwd_entry"""
+    _fields_ = [("partial", c_p), ("slots", ctypes.c_int32), ("C", ctypes.c_int32), ("gamma", c_p), ("beta", c_p),
+                ("sgamma", c_p), ("dgamma", c_p), ("dbeta", c_p), ("dsgamma", c_p), ("dsbeta", c_p)]
+
+
 class BnStatsFold(ctypes.Structure):
     """include/hdu.h: hdu_stats_fold_desc"""
     _fields_ = [("partial", c_p), ("slots", ctypes.c_int32), ("Cseg", ctypes.c_int32), ("seg_c0", ctypes.c_int32),
@@ -125,6 +131,7 @@ _SIGS = {
     "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
     "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
                                 c_p, c_i64, c_p, c_i64, c_p]),
+    "hdu_bn_bwd_finalize_batched": (c_int, [c_p, c_p, c_int, c_u32, c_p]),
     "hdu_materialize_stats": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_int, c_int,
                                       c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_wgrad_plan_entry_bytes": (c_sz, []),

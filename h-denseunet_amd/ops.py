@@ -371,6 +371,32 @@ class FoldPlan:
                                            self.n, self.total, stream()), "hdu_bn_fold_batched")
 
 
+class BnBwdPlan:
+    """parameter gradients of many inference-mode BN(+Scale) layers from their fused-epilogue slot sums as ONE launch
+    (hdu_bn_bwd_finalize_batched); built once, tables on device"""
+
+    def __init__(self, entries):
+        """entries: [(partial, slots, C, gamma, beta, sgamma|None, dgamma|None, dbeta|None, dsgamma|None, dsbeta|None)]"""
+        import numpy as np
+        self.keep = entries
+        n = len(entries)
+        tab = (_l.BnBwdEntry * n)()
+        begins = np.zeros(n, dtype=np.uint32)
+        tot = 0
+        p = lambda t: t.data_ptr() if t is not None else None
+        for i, (part, slots, C, g, be, sg, dg, db, dsg, dsb) in enumerate(entries):
+            tab[i] = _l.BnBwdEntry(p(part), slots, C, p(g), p(be), p(sg), p(dg), p(db), p(dsg), p(dsb))
+            begins[i] = tot
+            tot += (C + 7) // 8
+        self.n, self.total = n, tot
+        self.table = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy()).to(device())
+        self.begins = torch.from_numpy(begins.view(np.int32)).to(device())
+
+    def run(self):
+        check(_l.get().hdu_bn_bwd_finalize_batched(ctypes.c_void_p(self.table.data_ptr()), ctypes.c_void_p(self.begins.data_ptr()),
+                                                   self.n, self.total, stream()), "hdu_bn_bwd_finalize_batched")
+
+
 def bn_stats_fold(x, mean, var, gamma, beta, eps, sgamma, sbeta, a, b, rstd, mov_mean, mov_var, momentum, ws):
     check(_l.get().hdu_bn_stats_fold(x.dtype, x.ptr, x.ld, x.M, x.C, fptr(mean), fptr(var), fptr(gamma), fptr(beta), eps,
                                      fptr(sgamma), fptr(sbeta), fptr(a), fptr(b), fptr(rstd), fptr(mov_mean),

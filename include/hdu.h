@@ -157,6 +157,18 @@ int hdu_bn_bwd_finalize(const float* partial, int slots, int64_t M, int C, int b
                         const float* beta, const float* sgamma, const float* mean, const float* rstd, float* dgamma,
                         float* dbeta, float* dsgamma, float* dsbeta, float* corr3, float* corr4, void* stream);
 
+/* hdu_bn_bwd_finalize of MANY inference-mode BNs (batch_stats = 0: parameter gradients only, nothing the backward chain reads)
+ * as ONE launch at the end of the backward pass -- dense_rnn_net trains 216 Scale layers on frozen statistics
+ * (hybridnet.py:182-354), i.e. 216 finalize launches of ~4.6 us inside one step.  `begins[i]` = first 8-channel block of entry
+ * i (exclusive prefix sum of ceil(C / 8)); total_blocks = the grand total. */
+typedef struct hdu_bnbwd_entry {
+  const float* partial;      /* [slots][2][C] */
+  int32_t slots, C;
+  const float* gamma; const float* beta; const float* sgamma;
+  float* dgamma; float* dbeta; float* dsgamma; float* dsbeta;      /* any may be NULL */
+} hdu_bnbwd_entry;
+int hdu_bn_bwd_finalize_batched(const hdu_bnbwd_entry* table, const uint32_t* begins, int n, uint32_t total_blocks, void* stream);
+
 /* du[m][c] += -corr3[c]*u[m][c] + corr4[c]: the deferred, reduction-dependent part of the BN backward of every consumer
  * of these channels, applied ONCE, right before their producer reads the gradient. */
 int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t M, int C, const float* corr3, const float* corr4,

@@ -1012,3 +1012,34 @@ def test_stats_sync_combine(hdu):
     np.testing.assert_allclose(mean.cpu().numpy(), allx.mean(0), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(var.cpu().numpy(), allx.var(0), rtol=2e-5)
     assert lib.hdu_stats_pack(C, ops.fptr(mean), ops.fptr(var), 5, 3, 3, ops.fptr(total), ops.stream()) != 0      # rank out of range
+
+
+def test_bn_bwd_finalize_batched(hdu):
+    """hdu_bn_bwd_finalize_batched (one launch for many inference-mode BNs) == hdu_bn_bwd_finalize per layer"""
+    ops = ops_mod()
+    dev_ = ops.device()
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float32).to(dev_)
+    entries, refs = [], []
+    for C, slots, has_scale, tr_bn in ((48, 32, True, False), (200, 32, True, True), (8, 5, False, True), (1208, 32, True, False)):
+        part = (rn(slots * 2 * C) * 3).contiguous()
+        gamma, beta, sg = rn(C) * 0.2 + 1.0, rn(C), (rn(C) * 0.2 + 1.0) if has_scale else None
+        mean, rstd = rn(C), rn(C).abs() + 0.5
+        outs = [torch.full((C,), 7.0, device=dev_) for _ in range(4)]
+        want = [tr_bn, tr_bn, has_scale, has_scale]
+        o = [t if w else None for t, w in zip(outs, want)]
+        entries.append((part, slots, C, gamma, beta, sg, o[0], o[1], o[2], o[3]))
+        r = [torch.full((C,), 7.0, device=dev_) for _ in range(4)]
+        ro = [t if w else None for t, w in zip(r, want)]
+        ops.bn_bwd_finalize(part, slots, 1000, C, False, gamma, beta, sg, mean, rstd, ro[0], ro[1], ro[2], ro[3], None, None)
+        refs.append(r)
+        entries[-1] = entries[-1] + ()
+    plan = ops.BnBwdPlan(entries)
+    plan.run()
+    for e, r in zip(entries, refs):
+        got = [t for t in e[6:10]]
+        for i, (a, b) in enumerate(zip(got, r)):
+            if a is None:
+                assert float((b - 7.0).abs().max()) == 0.0       # the per-layer call left an unwanted output alone too
+            else:
+                assert torch.equal(a.cpu(), b.cpu()), i
