@@ -44,6 +44,12 @@ def inputs_for(variant, seed=1234):
     return x, y
 
 
+def _new_signature(opt):
+    """Keras 2.0.8: get_updates(self, loss, params), wrapped by legacy_get_updates_support (K.legacy/interfaces.py)"""
+    import inspect
+    return list(inspect.signature(opt.get_updates).parameters)[:1] != ["params"]
+
+
 def run(variant):
     K = H.setup("float64")
     x, y = inputs_for(variant)
@@ -77,11 +83,36 @@ def run(variant):
     out = model(feed())
     loss = H.loss_fn(variant)(K._k(torch.tensor(y)), out)
     tw = list(model.trainable_weights)
-    grads = torch.autograd.grad(loss, tw, allow_unused=True)
+    grads = torch.autograd.grad(loss, tw, allow_unused=True, retain_graph=True)
     owner = {}
     for layer in model.layers:
         for i, w in enumerate(layer.weights):
             owner[id(w)] = (layer.name, i)
+    # ---- the reference's optimiser on the same loss: keras.optimizers.SGD(lr=1e-3, momentum=0.9, nesterov=True).get_updates
+    # (K.optimizers.py:155-185, train_2ddense.py:181 / train_hybrid.py:149), executed unmodified.  Its moment variables are
+    # created by K.zeros inside get_updates; they are handed a deterministic NON-ZERO previous velocity here
+    # (weights.det_weights(<layer>/<index>, "Moment")) so that one step exercises the momentum and the Nesterov term.
+    from keras.optimizers import SGD
+    sgd = SGD(lr=1e-3, momentum=0.9, nesterov=True)
+    order = [owner[id(w)] for w in tw]
+    calls = []
+    zeros_orig = K.zeros
+
+    def zeros_moment(shape, dtype=None, name=None):
+        name_i = order[len(calls)]
+        calls.append(name_i)
+        return K.variable(det_weights("%s/%d" % name_i, "Moment", [tuple(shape)])[0], dtype, name)
+    K.zeros = zeros_moment
+    try:
+        updates = sgd.get_updates(loss, tw) if _new_signature(sgd) else sgd.get_updates(tw, {}, loss)
+    finally:
+        K.zeros = zeros_orig
+    assert calls == order
+    sgd_dig = {}
+    by_var = {id(var): new for var, new in updates}
+    for w, m in zip(tw, sgd.weights[1:]):
+        name, i = owner[id(w)]
+        sgd_dig["%s/%d" % (name, i)] = {"v": digest(by_var[id(m)].detach().numpy()), "p": digest(by_var[id(w)].detach().numpy())}
     gdig = {}
     for w, g in zip(tw, grads):
         name, i = owner[id(w)]
@@ -94,7 +125,8 @@ def run(variant):
     meta = {
         "variant": variant, "model_name": model.name, "input_shape": list(x.shape), "n_layers": len(model.layers),
         "floatx": "float64", "dropout": "identity", "loss": float(loss.detach()),
-        "inventory": inv, "call_args": call_args, "grad_digests": gdig, "bn_update_digests": upd,
+        "inventory": inv, "call_args": call_args, "grad_digests": gdig, "bn_update_digests": upd, "sgd_step_digests": sgd_dig,
+        "sgd": {"lr": 1e-3, "momentum": 0.9, "nesterov": True, "iterations_after": int(by_var[id(sgd.iterations)])},
         "n_params": int(sum(int(np.prod(tuple(w.shape))) for layer in model.layers for w in layer.weights)),
         "generated_by": "oracle/ref_keras/make_ref_fixtures.py over /root/reference (xmengli/H-DenseUNet, Keras 2.0.8 vendored)",
         "seconds": round(time.time() - t0, 1),

@@ -30,6 +30,8 @@ def det_weights(layer_name, class_name, shapes):
                  rng.uniform(0.5, 1.5, shape))[idx]
         elif class_name == "Scale":
             a = (rng.uniform(0.5, 1.5, shape), rng.normal(0.0, 0.1, shape))[idx]
+        elif class_name == "Moment":       # a previous SGD velocity (the optimiser-step fixture starts from a non-zero one)
+            a = rng.normal(0.0, 1e-3, shape)
         else:
             raise ValueError("no weight recipe for layer class %s (%s)" % (class_name, layer_name))
         out.append(np.asarray(a, dtype=np.float64))

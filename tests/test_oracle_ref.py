@@ -187,3 +187,26 @@ def test_fixture_regenerates_from_reference_tree():
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], capture_output=True, text=True, env=env, timeout=900)
     assert "REGEN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_oracle_sgd_step_equals_reference_optimizer(variant):
+    """One optimiser step from a NON-ZERO previous velocity: the reference's own keras.optimizers.SGD(lr=1e-3, momentum=0.9,
+    nesterov=True).get_updates (K.optimizers.py:155-185, run unmodified over the eager backend on the reference model's loss)
+    produced the fixture's new velocities and new weights; oracle/torch_ref.py's train_step -- the restatement the product's
+    hdu_sgd_nesterov is tested against -- must reproduce both for every trainable tensor."""
+    meta, z = load_fixture(variant)
+    assert meta["sgd"] == {"lr": 1e-3, "momentum": 0.9, "nesterov": True, "iterations_after": 1}
+    x, y = z["x"], z["y"]
+    P, fwd, kind = oracle_with_reference_weights(variant, meta, x)
+    sd = meta["sgd_step_digests"]
+    vel = {}
+    for key in sd:
+        name, i = key.rsplit("/", 1)
+        vel[(name, int(i))] = torch.tensor(det_weights(key, "Moment", [tuple(P.w[name][int(i)].shape)])[0])
+    R.train_step(P, fwd, U.loss_fn_for(kind), torch.tensor(x), torch.tensor(y), vel, lr=1e-3, momentum=0.9)
+    assert set("%s/%d" % k for k in vel) == set(sd)
+    for key, d in sd.items():
+        name, i = key.rsplit("/", 1)
+        digest_matches(d["v"], vel[(name, int(i))].numpy(), what="velocity " + key)
+        digest_matches(d["p"], P.w[name][int(i)].numpy(), what="updated weight " + key)
