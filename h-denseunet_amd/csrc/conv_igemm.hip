@@ -700,6 +700,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
     }
 }
 
+#ifdef HDU_TIMELINE
+#define HDU_TL_WGS 8192
+__device__ unsigned long long hdu_timeline[HDU_TL_WGS * 10];
+#define HDU_TP(i)                                                                                               \
+  do {                                                                                                           \
+    if (threadIdx.x == 0) {                                                                                      \
+      const unsigned b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
+      if (b_ < HDU_TL_WGS) {                                                                                     \
+        hdu_timeline[b_ * 10 + (i)] = __builtin_readcyclecounter();                                              \
+        if ((i) == 0) hdu_timeline[b_ * 10 + 8] = wall_clock64();                                                \
+        if ((i) >= 5) hdu_timeline[b_ * 10 + 9] = wall_clock64();                                                \
+      }                                                                                                          \
+    }                                                                                                            \
+  } while (0)
+extern "C" int hdu_timeline_read(unsigned long long* host, int clear) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(hdu_timeline), sizeof(unsigned long long) * HDU_TL_WGS * 10) != hipSuccess) return 1;
+  if (clear) {
+    void* dp = nullptr;
+    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(hdu_timeline)) != hipSuccess) return 1;
+    if (hipMemset(dp, 0, sizeof(unsigned long long) * HDU_TL_WGS * 10) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#else
+#define HDU_TP(i) do { } while (0)
+#endif
+
 // ---- per-channel moments of the output tile while it is still staged in LDS (ConvK::stats_partial).  Called by all
 // 256 threads after the tile stores; reads the tile only.  Thread = (16-byte column chunk, row lane): the 16 row lanes of
 // a chunk are 16 ADJACENT lanes of a wave, each sums rows rl, rl+16, ... in registers, a 4-step xor butterfly adds the 16
@@ -727,24 +754,38 @@ __device__ __forceinline__ void epilogue_stats(const ConvK& p, char* smem, int n
         sh[j] = v4[0]; sh[j + 1] = v4[1]; sh[j + 2] = v4[2]; sh[j + 3] = v4[3];
       }
     }
-    if (cc < NCC && nbase < p.Cout) {
-      for (int row = rl; row < BM; row += 16) {
-        if (!valid(row)) continue;
-        float f[CH];
-        Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), f);
+    {
+      // every row of the lane requested up front, unconditionally (a chunk beyond the tile re-reads chunk 0; rows past M and
+      // lanes without a column are masked in the arithmetic): the per-row `continue` of round 2 made this a chain of BM / 16
+      // dependent LDS round trips -- measured round 3 (profiles/r03_timeline_epilogue_split.txt): the statistics cost 2.1 us
+      // of a 128x96 tile's 4.7 us epilogue
+      const bool col = cc < NCC && nbase < p.Cout;
+      const int ccq = col ? cc : 0;
+      u32x4 rv[BM / 16];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { const float d = f[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
+      for (int q = 0; q < BM / 16; ++q) rv[q] = *(const u32x4*)(smem + (rl + q * 16) * ROWB + ccq * 16);
+#pragma unroll
+      for (int q = 0; q < BM / 16; ++q) {
+        const float keep = (col && valid(rl + q * 16)) ? 1.f : 0.f;
+        float f[CH];
+        Chunk<T>::unpack(rv[q], f);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { const float d = (f[j] - sh[j]) * keep; s1[j] += d; s2[j] += d * d; }
       }
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) { s1[j] = hdu_row16_sum(s1[j]); s2[j] = hdu_row16_sum(s2[j]); }
-    if (rl == 0 && cc < NCC && nbase < p.Cout) {
+    // every lane of the 16-lane group holds all 2 * CH totals: lane q adds total q (q < CH: sum of channel q, else the sum of
+    // squares of channel q - CH) -- ONE atomic instruction per wave with 64 different addresses instead of 2 * CH
+    // instructions with 4 active lanes each
+    float mine = 0.f;
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        atomicAdd(dst + nbase + j, s1[j]);
-        atomicAdd(dst + p.Cout + nbase + j, s2[j]);
-      }
+    for (int j = 0; j < CH; ++j) {
+      mine = rl == j ? s1[j] : mine;
+      mine = rl == CH + j ? s2[j] : mine;
     }
+    if (rl < 2 * CH && cc < NCC && nbase < p.Cout)
+      atomicAdd(dst + (rl < CH ? 0 : p.Cout) + nbase + (rl < CH ? rl : rl - CH), mine);
   }
 }
 
@@ -940,6 +981,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x4 (&acc)[TM][
     }
   }
   __syncthreads();
+  HDU_TP(7);                                         // (timeline builds: the tile is staged)
   if constexpr (BNB) {                               // data gradient with the consumer BN's backward fused in
     epilogue_bn_backward<T, BM, BN, ROWB>(p, smem, m0, n0, tid, bnb_uv, bnb_ov);
     return;
@@ -1000,32 +1042,6 @@ __device__ __attribute__((aligned(16))) unsigned hdu_zero_page[16];
 // Developer instrumentation (tools/timeline_probe.py builds its own library with -DHDU_TIMELINE; never in libhdu.so):
 // lane 0 of every workgroup stamps the shader clock at a few points of the implicit-GEMM kernels, plus the constant
 // 100 MHz clock at entry / exit so that workgroups of different XCDs share one time axis.
-#ifdef HDU_TIMELINE
-#define HDU_TL_WGS 8192
-__device__ unsigned long long hdu_timeline[HDU_TL_WGS * 10];
-#define HDU_TP(i)                                                                                               \
-  do {                                                                                                           \
-    if (threadIdx.x == 0) {                                                                                      \
-      const unsigned b_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
-      if (b_ < HDU_TL_WGS) {                                                                                     \
-        hdu_timeline[b_ * 10 + (i)] = __builtin_readcyclecounter();                                              \
-        if ((i) == 0) hdu_timeline[b_ * 10 + 8] = wall_clock64();                                                \
-        if ((i) >= 5) hdu_timeline[b_ * 10 + 9] = wall_clock64();                                                \
-      }                                                                                                          \
-    }                                                                                                            \
-  } while (0)
-extern "C" int hdu_timeline_read(unsigned long long* host, int clear) {
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(hdu_timeline), sizeof(unsigned long long) * HDU_TL_WGS * 10) != hipSuccess) return 1;
-  if (clear) {
-    void* dp = nullptr;
-    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(hdu_timeline)) != hipSuccess) return 1;
-    if (hipMemset(dp, 0, sizeof(unsigned long long) * HDU_TL_WGS * 10) != hipSuccess) return 1;
-  }
-  return 0;
-}
-#else
-#define HDU_TP(i) do { } while (0)
-#endif
 
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool BNB = false>

@@ -550,7 +550,7 @@ class Ctx:
 class BNLayer:
     """BatchNormalization (+ optional Scale) + optional ReLU folded to a per-channel affine that the consumer
     applies on load.  K.layers/normalization.py:126-190, lib/custom_layers.py:63-69."""
-    BSUM_SLOTS = 16      # slot rows the backward reduction spreads its float atomics over (workgroup % slots)
+    BSUM_SLOTS = int(os.environ.get("HDU_BSUM_SLOTS", "16"))      # slot rows the backward reduction spreads its float atomics over (workgroup % slots; <= 32)
 
     def __init__(self, ctx, name, C, eps=1e-3, momentum=0.99, mode="batch", trainable=True, scale_name=None,
                  scale_trainable=True, relu=True):
@@ -1020,7 +1020,7 @@ class StatsOp:
     """tf.nn.moments of a freshly written tensor / slab, once, shared by every consumer BN.  When the tensor has a
     single batch-stat consumer BN over exactly these channels, `fuse(bn)` folds it in the same two launches."""
 
-    SLOTS = 32     # slot rows a conv epilogue spreads its float atomics over (workgroup % SLOTS)
+    SLOTS = int(os.environ.get("HDU_STATS_SLOTS", "32"))     # slot rows a conv epilogue spreads its float atomics over (workgroup % SLOTS; <= 32)
 
     def __init__(self, ctx, var):
         self.ctx, self.var = ctx, var

@@ -70,6 +70,9 @@ def main():
         live = t[:, 0] != 0
         t = t[live]
         n = len(t)
+        if n == 0:
+            print("\n%s  -> %s: no stamps (this kernel family is not instrumented)" % (name, kname))
+            continue
         w0 = (t[:, 8] - t[:, 8].min()) * 10.0 / 1e3        # us
         w1 = (t[:, 9] - t[:, 8].min()) * 10.0 / 1e3
         last = t[:, 6] != 0                                    # ran the epilogue (the tile's last split, or unsplit)
@@ -89,6 +92,10 @@ def main():
             dt = (t[sel, i + 1] - t[sel, i]) / ghz / 1e3
             line += "  %s %.2f" % (s, np.median(dt))
         print(line)
+        st = last & (t[:, 7] != 0)
+        if st.sum():
+            print("    epilogue split: accumulators -> LDS staging (incl. both barriers) %.2f us, stores (+ statistics) %.2f us" %
+                  (np.median((t[st, 7] - t[st, 5]) / ghz / 1e3), np.median((t[st, 6] - t[st, 7]) / ghz / 1e3)))
         # first-round workgroups (cold instruction / scalar caches on their CU) against later rounds
         early, late = w0 < 2.0, w0 > 4.0
         if late.sum() >= 16:
