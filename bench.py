@@ -33,6 +33,7 @@ TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 PROFILE_ROUND = "r03"
+EVENT_OVERHEAD_MS = [0.0]      # duration an event pair reports around no launch at all (measured in the instrumented step)
 
 # HDU_BENCH_DRYRUN=1 (tests/test_bench_flow_gloo.py only): the same control flow on CPU -- x86 emulator build of the
 # kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
@@ -189,18 +190,30 @@ def instrumented_step(m):
         _sync()
     finally:
         ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w
+    # what an event pair measures around NOTHING (the second event's own processing: ~1.5-2.5 us on this runtime) is taken
+    # off every launch -- without it a family of 120 launches of 14 us reads 17 us per launch (rocprofv3: 14.4) and can
+    # overtake, as "dominant kernel", a family of 43 launches of 46 us whose kernel time is larger
+    Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
+    null = [(Ev(enable_timing=True), Ev(enable_timing=True)) for _ in range(33)]
+    for e0, e1 in null:
+        e0.record()
+        e1.record()
+    _sync()
+    ov = sorted(e0.elapsed_time(e1) for e0, e1 in null)[len(null) // 2]
+    EVENT_OVERHEAD_MS[0] = ov
     agg = {}
     bym = {}
     detail = os.environ.get("HDU_BENCH_VERBOSE") == "2"      # one row per GEMM shape (N, K, taps) instead of per M
     for name, fl, e0, e1, mm, shape, nbytes in recs:
+        t = max(e0.elapsed_time(e1) - ov, 1e-4)
         a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
         a[0] += 1
-        a[1] += e0.elapsed_time(e1)
+        a[1] += t
         a[2] += fl
         a[3] += nbytes
         b = bym.setdefault((mm, name + (" N=%d K=%d taps=%d" % shape if detail else "")), [0, 0.0, 0.0])
         b[0] += 1
-        b[1] += e0.elapsed_time(e1)
+        b[1] += t
         b[2] += fl
     if os.environ.get("HDU_BENCH_VERBOSE"):
         for mm in sorted(bym):
@@ -295,6 +308,7 @@ def roofline_record(agg, name, config, dtype):
          "unit": "GB/s" if hbm_bound else "TFLOP/s",
          "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak_tf), 4),
          "traffic": traffic, "kernel": name, "launches_per_step": n, "avg_launch_us": round(tms / n * 1e3, 2),
+         "event_pair_overhead_us": round(EVENT_OVERHEAD_MS[0] * 1e3, 2),
          "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak_tf, 4),
          "hbm_gbs_algorithmic": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
          "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void bn_bwd_correct_kernel(RowK p) {
   for (; m < r_end; m += ROWS) body(m, *(const u32x4*)(xp + m * p.ldx + c0), *(const u32x4*)(op + m * p.ldo + c0));
 }
 
-// geometry shared by the row kernels: column groups of COLS chunks, row blocks sized to ~2048 workgroups
+// geometry shared by the row kernels: column groups of COLS chunks, row blocks sized to ~512 workgroups
 static void row_geometry(int dtype, long long M, int C, int* cols, unsigned* gx, unsigned* gy, long long* rpb) {
   const int ch = dtype == HDU_BF16 ? 8 : 4;
   const int nchunks = C / ch;
@@ -933,7 +933,9 @@ static void row_geometry(int dtype, long long M, int C, int* cols, unsigned* gx,
   *cols = c;
   *gy = (unsigned)((nchunks + c - 1) / c);
   const int rows = 256 / c;
-  long long want = (g_tuning[HDU_TUNE_ROW_WGS] > 0 ? g_tuning[HDU_TUNE_ROW_WGS] : 2048) / *gy;
+  // ~2 workgroups per CU (swept in round 3 after the statistics / coefficient prologues moved into these kernels:
+  // 256 / 384 / 512 / 768 / 1024 / 2048 / 4096 -> 2D step 19.92 / 19.60 / 19.18 / 19.30 / 19.62 / 19.69 / 20.01 ms; rounds 1-2: 2048)
+  long long want = (g_tuning[HDU_TUNE_ROW_WGS] > 0 ? g_tuning[HDU_TUNE_ROW_WGS] : 512) / *gy;
   if (want < 1) want = 1;
   long long maxb = (M + (long long)rows * 4 - 1) / ((long long)rows * 4);
   if (maxb < 1) maxb = 1;

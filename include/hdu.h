@@ -56,7 +56,7 @@ size_t hdu_sizeof_conv_desc(void);
                                         bit4 (16): treat every input tensor as >= 4 GiB (64-bit pointer path; tests) */
 #define HDU_TUNE_XCD_SWIZZLE 3       /* bit0 = XCD-aware tile order in the implicit GEMM (default on) */
 #define HDU_TUNE_RED_WGS 11          /* workgroups a per-channel reduction aims for (default 512) */
-#define HDU_TUNE_ROW_WGS 12          /* workgroups an element-wise row kernel aims for (default 2048) */
+#define HDU_TUNE_ROW_WGS 12          /* workgroups an element-wise row kernel aims for (default 512 = 2 per CU; rounds 1-2: 2048) */
 #define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
 #define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */

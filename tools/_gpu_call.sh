@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-rm -f gpurun_out/bf16_parity_figures.txt
-( timeout 900 python -m pytest tests/test_gpu_parity_bf16.py -m gpu -q --tb=short 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl\|^RCCL\|^HIP version" | tail -15 ) > gpurun_out/c26_parity.log 2>&1
-tail -8 gpurun_out/c26_parity.log; grep "per-tensor gates" gpurun_out/bf16_parity_figures.txt | cut -c1-200
+( timeout 300 python -m pytest tests/test_kernels.py -m gpu -x -q 2>&1 | tail -2 ) > gpurun_out/c30_tests.log 2>&1
+( time python bench.py ) > gpurun_out/c30_bench.json 2> gpurun_out/c30_bench.err
+cp gpurun_out/bench_details.json gpurun_out/c30_bench_details.json
+cat gpurun_out/c30_tests.log; wc -c gpurun_out/c30_bench.json; tail -4 gpurun_out/c30_bench.err; head -c 300 gpurun_out/c30_bench.json
