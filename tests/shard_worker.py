@@ -14,6 +14,34 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+class GlooComm:
+    """test double of h-denseunet_amd.comm.Comm (hdu_comm_* = RCCL, which the CPU tier does not have): the same two methods
+    over torch.distributed / gloo, so that the `sh.comm is not None` branches of shard.py and parallel.py -- which buffers go
+    to which neighbour, in which order -- are exercised by the sharded-equals-unsharded check below"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def allreduce_(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def sendrecv(self, lo_rank, send_lo, recv_lo, hi_rank, send_hi, recv_hi):
+        ops_ = []
+        for peer, snd, rcv in ((lo_rank, send_lo, recv_lo), (hi_rank, send_hi, recv_hi)):
+            assert (peer is None) == (snd is None) == (rcv is None)
+            if peer is not None:
+                assert snd.is_contiguous() and rcv.is_contiguous() and snd.numel() == rcv.numel() and snd.dtype == rcv.dtype
+                ops_.append(dist.P2POp(dist.isend, snd, peer))
+                ops_.append(dist.P2POp(dist.irecv, rcv, peer))
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
+
+    def close(self):
+        pass
+
+
 def main():
     pkg = importlib.import_module("h-denseunet_amd")
     pkg.lib.use_emulator_for_tests()
@@ -21,6 +49,8 @@ def main():
     par, ka = U.pkg("parallel"), U.pkg("keras_api")
     sh = par.depth_shard_info("gloo")
     rank, world = sh.rank, sh.world
+    if os.environ.get("SHARD_TEST_COMM") == "double":
+        sh.comm = GlooComm(rank, world)
     H, D = int(os.environ.get("SHARD_TEST_H", "32")), int(os.environ.get("SHARD_TEST_DL", "8")) * world
     Dl = D // world
     nb = (1, 1, 1, 1)

@@ -21,8 +21,9 @@ def test_depth_shard_world4_gloo(emu_lib):
     assert "SHARD_OK" in out.stdout and out.stdout.count("rank ") >= 4
 
 
-@pytest.mark.parametrize("net,port", [("end2end", "29551"), ("3dpart", "29553")])
-def test_depth_sharded_hybrid_world2_gloo(emu_lib, net, port):
+@pytest.mark.parametrize("net,port,comm", [("end2end", "29551", ""), ("3dpart", "29553", ""), ("end2end", "29555", "double")],
+                         ids=["end2end", "3dpart", "end2end-comm-object"])
+def test_depth_sharded_hybrid_world2_gloo(emu_lib, net, port, comm):
     """SURVEY.md section 8e, third row: the HYBRID nets on one volume split over 2 ranks -- each rank runs the 2D branch on
     its own slices (one raw CT plane exchanged with each depth neighbour for the 2.5D slabs, denseunet3d.py:399-409), the
     3D net with halo exchange / sync-BN, the HFF add + `fianl_conv` with a halo, loss.py's slices 1:7 split over the
@@ -32,7 +33,11 @@ def test_depth_sharded_hybrid_world2_gloo(emu_lib, net, port):
     # (hdu_conv_desc.layer_rows = the unsharded layer's pixel count), so every output is summed over the same K partition as in the unsharded run.
     # (Round 2 had to force HDU_SPLITK=1 here: the split count followed the shard's own tile count and the different float32
     # summation order alone moved the hybrid's logits -- 250 x logits2d feed the 3D stem -- by 3e-4 of max|logit|.)
-    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net)
+    # "end2end-comm-object": the same run with ShardInfo.comm set (a gloo-backed double of h-denseunet_amd.comm.Comm): every
+    # halo exchange, halo-gradient return, CT-plane exchange, sync-BN table and the flat gradient go through the
+    # `sh.comm.sendrecv / allreduce_` call sites that HDU_COMM=rccl_abi uses on hardware
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", SHARD_TEST_DL="4", SHARD_TEST_H="32", SHARD_TEST_NET=net,
+               SHARD_TEST_COMM=comm)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)
