@@ -420,7 +420,7 @@ def all(x, axis=None, keepdims=False):
 
 
 def softmax(x):                                                    # TFB:2697-2708 -> tf.nn.softmax (last axis)
-    return torch.softmax(x, dim=-1)
+    return torch.softmax(_as_tensor(x), dim=-1)          # (tf.nn.softmax takes numpy arrays too: lib/funcs.py:31 passes one)
 
 
 def relu(x, alpha=0.0, max_value=None):                            # TFB:2656-2679

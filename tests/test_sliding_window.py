@@ -76,3 +76,26 @@ def test_sliding_window_full_size_vs_torch_oracle(hip_lib):
         for a, b in ((s1, r1), (s2, r2)):
             assert float(((a >= thr) != (b >= thr)).mean()) <= 1e-4
     assert float(np.abs(r1).max()) > 0
+
+
+def test_reference_loop_restatement_equals_the_references_own_function():
+    """`reference_loop` above -- what the product's HBM-resident sweep is held to -- against arrays produced by the REFERENCE'S OWN
+    lib/funcs.py:predict_tumor_inwindow, run unmodified over the eager backend with a deterministic stand-in model
+    (oracle/ref_keras/make_funcs_fixture.py): window starts incl. the clamped last window, the [1:-1] trim, overlap counts"""
+    import os
+    import sys
+    import types
+    sys.path.insert(0, U.ROOT)
+    from oracle.ref_keras.make_funcs_fixture import StandInModel
+    z = np.load(os.path.join(U.ROOT, "tests", "golden", "ref_funcs_sliding_window.npz"))
+    n = len([k for k in z.files if k.startswith("meta")])
+    assert n == 3
+    for i in range(n):
+        meta = [int(v) for v in z["meta%d" % i]]
+        shape, win, mini, maxi, seed = tuple(meta[0:3]), meta[3], tuple(meta[4:7]), tuple(meta[7:10]), meta[10]
+        vol = np.random.default_rng(seed).normal(0.0, 40.0, shape).astype(np.float32)
+        args = types.SimpleNamespace(b=1, input_size=shape[0], input_cols=win)
+        r1, r2 = reference_loop(StandInModel(), vol, 3, mini, maxi, args)
+        np.testing.assert_allclose(r1, z["s1_%d" % i], atol=2e-6)
+        np.testing.assert_allclose(r2, z["s2_%d" % i], atol=2e-6)
+        assert float(np.abs(z["s1_%d" % i]).max()) > 0.1
