@@ -59,3 +59,23 @@ nn = _NN()
 float32 = torch.float32
 float64 = torch.float64
 int32 = torch.int32
+
+
+# ---- K.utils2/multi_gpu.py:7-69 (make_parallel): tower placement is a no-op on one eager device
+import contextlib      # noqa: E402
+
+
+@contextlib.contextmanager
+def device(name):
+    """tf.device('/gpu:%d'): placement only -- the towers of make_parallel share their variables and differ in the batch slice"""
+    yield
+
+
+@contextlib.contextmanager
+def name_scope(name, default_name=None, values=None):
+    yield name
+
+
+def shape(input, name=None, out_type=None):
+    """tf.shape: the dynamic shape as a 1-D integer tensor (multi_gpu.py:9 computes it and does not use it)"""
+    return torch.tensor(list(input.shape), dtype=torch.int64)

@@ -155,6 +155,15 @@ class KTensor(torch.Tensor):
     def __itruediv__(self, other):
         return self / other
 
+    def get_shape(self):
+        """tf.Tensor.get_shape(): the static shape (K.utils2/multi_gpu.py:46 calls .as_list() on it)"""
+        shp = tuple(int(s) for s in self.shape)
+
+        class _Shape(tuple):
+            def as_list(self_inner):
+                return list(self_inner)
+        return _Shape(shp)
+
 
 def _k(t):
     return t.as_subclass(KTensor)

@@ -210,3 +210,48 @@ def test_oracle_sgd_step_equals_reference_optimizer(variant):
         name, i = key.rsplit("/", 1)
         digest_matches(d["v"], vel[(name, int(i))].numpy(), what="velocity " + key)
         digest_matches(d["p"], P.w[name][int(i)].numpy(), what="updated weight " + key)
+
+
+def test_oracle_data_parallel_semantics_equal_reference_make_parallel():
+    """What data parallelism COMPUTES in the reference, from its own K.utils2/multi_gpu.py:make_parallel run unmodified around
+    denseunet.DenseUNet (oracle/ref_keras/make_parallel_fixture.py: 2 towers x 1 slice): BatchNormalization statistics per
+    tower, loss.py's mean over the concatenated batch, gradients of that mean w.r.t. the shared weights, and one
+    moving-average candidate per tower.  The oracle run tower by tower reproduces all of it -- the semantics the product's
+    one-process-per-GPU path (local BN statistics, loss / world, summed gradients; tests/test_dp_gloo.py) is built to."""
+    with open(os.path.join(GOLD, "ref_keras_make_parallel.json")) as f:
+        pm = json.load(f)
+    zp = np.load(os.path.join(GOLD, "ref_keras_make_parallel.npz"))
+    meta, _ = load_fixture("denseunet")                       # the same network: its inventory names the weights
+    x, y = zp["x"], zp["y"]
+    P, fwd, kind = oracle_with_reference_weights("denseunet", meta, x[:1])
+    P.learning_phase = 1
+    trainable = P.trainable_tensors()
+    for _, _, t in trainable:
+        t.requires_grad_(True)
+    outs, cands = [], []
+    for i in range(pm["gpu_count"]):
+        P.bn_batch_means = {}
+        outs.append(fwd(P, torch.tensor(x[i:i + 1])))
+        cands.append({n: (m.clone(), v.clone()) for n, (m, v) in P.bn_batch_means.items()})
+    out = torch.cat(outs, 0)
+    scale = max(1.0, float(np.abs(zp["logits_train"]).max()))
+    assert np.abs(out.detach().numpy() - zp["logits_train"]).max() <= 1e-9 * scale
+    loss = U.loss_fn_for(kind)(torch.tensor(y), out)
+    assert close(float(loss.detach()), pm["loss"], rtol=1e-10)
+    grads = torch.autograd.grad(loss, [t for _, _, t in trainable], allow_unused=True)
+    gd = pm["grad_digests"]
+    assert set("%s/%d" % (n, i) for n, i, _ in trainable) == set(gd)
+    for (name, i, t), g in zip(trainable, grads):
+        digest_matches(gd["%s/%d" % (name, i)], g.numpy(), what="make_parallel gradient %s/%d" % (name, i))
+    # one moving-average candidate per tower, each from the OLD value (TFB:915-927)
+    uc = pm["bn_update_candidates"]
+    assert set(k.rsplit("/", 1)[0] for k in uc) == set(cands[0])
+    for name in cands[0]:
+        mom = P.bn_cfg[name]["momentum"]
+        for tower in range(2):
+            mean, var = cands[tower][name]
+            digest_matches(uc[name + "/2"][tower], (P.w[name][2] - (P.w[name][2] - mean) * (1 - mom)).detach().numpy(),
+                           what="moving mean of %s, tower %d" % (name, tower))
+            digest_matches(uc[name + "/3"][tower], (P.w[name][3] - (P.w[name][3] - var) * (1 - mom)).detach().numpy(),
+                           what="moving variance of %s, tower %d" % (name, tower))
+    P.bn_batch_means = {}
