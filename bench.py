@@ -32,8 +32,7 @@ sys.path.insert(0, ROOT)
 TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3d": 121.3}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
-PROFILE_ROUND = "r03"
-EVENT_OVERHEAD_MS = [0.0]      # duration an event pair reports around no launch at all (measured in the instrumented step)
+PROFILE_ROUND = "r04"
 
 # HDU_BENCH_DRYRUN=1 (tests/test_bench_flow_gloo.py only): the same control flow on CPU -- x86 emulator build of the
 # kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
@@ -112,115 +111,139 @@ def build(config, dtype, b, size, cols):
     return m
 
 
+def _esz(dtype):
+    return 2 if dtype == 0 else 4
+
+
+def _conv_work(d, op, scale):
+    """algorithmic work of one conv launch (DESIGN.md section 3): FLOPs = 2 * M * Cout * taps * Cin (logical channels);
+    bytes = every stored input element and every filter element read once, every output element written once (and read
+    once more in accumulate mode); the filter gradient reads x and dy once and writes the float32 gradient once"""
+    esz = _esz(d.dtype)
+    m_in = d.N * d.Di * d.Hi * d.Wi
+    m_out = d.N * d.Do * d.Ho * d.Wo
+    taps = d.KD * d.KH * d.KW
+    fl = 2.0 * m_out * d.Cout * taps * d.Cin * scale.get(d.w, 1.0)
+    if op == 1:
+        return fl, (m_in * d.Cin + m_out * d.Cout) * esz + d.Cout * taps * d.Cin * 4.0
+    nb = (m_in * d.Cin + d.Cout * taps * d.Cin) * esz + m_out * d.Cout * esz * (2 if d.accumulate else 1)
+    if d.bnb_u:          # fused BN backward: the BN input is read as well
+        nb += m_out * d.Cout * esz
+    return fl, nb
+
+
+def _row_work(name, a, ctx):
+    """algorithmic HBM bytes of the launches of one row-kernel entry point (include/hdu.h argument order), one entry per
+    kernel the call launches: every element the operation has to read / write, once.
+    None = no model (small per-channel kernels)."""
+    v = lambda x: getattr(x, "value", x)
+    if name in ("hdu_materialize", "hdu_materialize_stats"):
+        dt, N, D, H, W, C = v(a[0]), v(a[3]), v(a[4]), v(a[5]), v(a[6]), v(a[7])
+        k = 9 if name == "hdu_materialize_stats" else 10
+        ud, uh, uw, skip = v(a[k + 1]), v(a[k + 2]), v(a[k + 3]), a[k + 4]
+        m_in, m_out = N * D * H * W, N * (D << ud) * (H << uh) * (W << uw)
+        return [(m_in * C + m_out * C * (2 if v(skip) else 1)) * _esz(dt)]
+    if name == "hdu_affine_act":
+        return [2.0 * v(a[3]) * v(a[4]) * _esz(v(a[0]))]
+    if name == "hdu_bn_bwd_fused":       # reduction (dz, x) + apply (dz, x, old gradient in accumulate mode -> dx)
+        dt, M, C, acc = v(a[0]), v(a[5]), v(a[6]), v(a[24])
+        e = _esz(dt)
+        return [2.0 * M * C * e, (3.0 + (1 if acc else 0)) * M * C * e]
+    if name == "hdu_bn_bwd_apply":
+        dt, M, C, acc = v(a[0]), v(a[5]), v(a[6]), v(a[16])
+        return [(3.0 + (1 if acc else 0)) * M * C * _esz(dt)]
+    if name in ("hdu_bn_bwd_reduce_coef", "hdu_bn_bwd_reduce"):
+        return [2.0 * v(a[5]) * v(a[6]) * _esz(v(a[0])), None]
+    if name in ("hdu_bn_stats", "hdu_bn_stats_fold", "hdu_colsum"):
+        return [1.0 * v(a[3]) * v(a[4]) * _esz(v(a[0])), None]
+    if name == "hdu_bn_bwd_correct":
+        return [3.0 * v(a[3]) * v(a[4]) * _esz(v(a[0]))]
+    if name in ("hdu_maxpool3s2_fwd", "hdu_avgpool2_fwd"):
+        dt, N, D, H, W, C = (v(a[i]) for i in (0, 3, 4, 5, 6, 7))
+        m = N * D * H * W
+        return [m * C * _esz(dt) * 1.25]
+    if name in ("hdu_maxpool3s2_bwd", "hdu_avgpool2_bwd"):
+        off = 1 if name == "hdu_maxpool3s2_bwd" else 0
+        dt, N, D, H, W, C = v(a[0]), v(a[3 + off]), v(a[4 + off]), v(a[5 + off]), v(a[6 + off]), v(a[7 + off])
+        return [N * D * H * W * C * _esz(dt) * 1.25]
+    if name == "hdu_upsample_bwd":
+        dt, N, D, H, W, C, ud, uh, uw = (v(a[i]) for i in (0, 3, 4, 5, 6, 7, 8, 9, 10))
+        m = N * D * H * W
+        return [(m * (1 << (ud + uh + uw)) + m) * C * _esz(dt)]
+    if name == "hdu_sgd_nesterov":
+        return [5.0 * v(a[3]) * 4]
+    if name == "hdu_weight_prep_batched":
+        return [sum(cv.kernel.numel for cv in ctx.convs) * 4.0 + ctx.Wc.numel() * ctx.Wc.element_size()]
+    if name == "hdu_wce_loss":
+        return [v(a[4]) * (2 * 8 * _esz(v(a[0])) + 1.0)]
+    return None
+
+
 def instrumented_step(m):
-    """one eager step with a HIP-event pair around every conv launch (events on the launch stream = torch's current
-    stream); returns {kernel_name: [n_launches, total_ms, total_algorithmic_flops]}"""
-    ops = importlib.import_module("h-denseunet_amd.ops")
+    """ONE eager step with the library's launch profiler armed (include/hdu.h: hdu_profile_*): EVERY kernel the step
+    launches is recorded with its own begin-to-end time (start / stop events attached to the dispatch itself -- the figure
+    rocprofv3 --kernel-trace reports, no marker-packet overhead to subtract) and its instantiated name; the C-ABI call log
+    attaches the algorithmic FLOPs / HBM bytes to each record.
+    Returns {kernel_name: [n_launches, total_ms, algorithmic_flops, algorithmic_bytes (or None)]}."""
+    lib = importlib.import_module("h-denseunet_amd.lib")
     ctx = m.ctx
     scale = {}
     for cv in ctx.convs:
         ks = cv.kernel.keras_shape
-        s = (ks[-2] / cv.cin_p) * (ks[-1] / cv.cout_p)
-        scale[cv.wf_ptr.value] = s
+        sc = (ks[-2] / cv.cin_p) * (ks[-1] / cv.cout_p)
+        scale[cv.wf_ptr.value] = sc
         if cv.wd_ptr is not None:
-            scale[cv.wd_ptr.value] = s
-    recs = []
-    orig_f, orig_w = ops.conv_fprop, ops.conv_wgrad
-
-    def flops(d, op):
-        m_out = d.N * d.Do * d.Ho * d.Wo
-        return 2.0 * m_out * d.Cout * d.KD * d.KH * d.KW * d.Cin * scale.get(d.w, 1.0)
-
-    def alg_bytes(d, op):
-        """algorithmic HBM bytes of one conv launch: every stored input element and every filter
-        element read once, every output element written once (and read once more in accumulate mode); the filter
-        gradient reads x and dy once and writes the float32 gradient once"""
-        esz = 2 if d.dtype == 0 else 4
-        m_in = d.N * d.Di * d.Hi * d.Wi
-        m_out = d.N * d.Do * d.Ho * d.Wo
-        taps = d.KD * d.KH * d.KW
-        if op == 1:
-            return (m_in * d.Cin + m_out * d.Cout) * esz + d.Cout * taps * d.Cin * 4.0
-        return (m_in * d.Cin + d.Cout * taps * d.Cin) * esz + m_out * d.Cout * esz * (2 if d.accumulate else 1)
-
-    def wrap(fn, op):
-        def f(d, *a):
-            Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
-            e0, e1 = Ev(enable_timing=True), Ev(enable_timing=True)
-            e0.record()
-            fn(d, *a)
-            e1.record()
-            recs.append((ops.conv_kernel_name(d, op), flops(d, op), e0, e1, d.N * d.Do * d.Ho * d.Wo,
-                         (d.Cout, d.KD * d.KH * d.KW * d.Cin, d.KD * d.KH * d.KW), alg_bytes(d, op)))
-        return f
-
-    ops.conv_fprop, ops.conv_wgrad = wrap(orig_f, 0), wrap(orig_w, 1)
-    plan = ctx.wgrad_plan
-    if plan is not None:
-        # the deferred filter gradients stay batched (what the timed step runs): one event pair per kernel family, its
-        # algorithmic FLOPs = the sum over the layers of that launch
-        orig_run = plan.run
-
-        def timed_plan_run():
-            def around(variant, launch):
-                ds = plan.descs[variant]
-                Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
-                e0, e1 = Ev(enable_timing=True), Ev(enable_timing=True)
-                e0.record()
-                launch()
-                e1.record()
-                name = ops.conv_kernel_name(ds[0], 1).replace("_kernel<", "_batched_kernel<")
-                recs.append((name, sum(flops(d, 1) for d in ds), e0, e1, -len(ds), (0, 0, 0), sum(alg_bytes(d, 1) for d in ds)))
-            orig_run(around)
-        plan.run = timed_plan_run
-    try:
-        g = m._graph
-        m._graph = None
-        # this extra step runs on rank 0 ONLY: it must not enter the gradient all-reduce (the other ranks are already
-        # waiting in the final barrier)
-        dp = (m._allreduce, m._allreduce_async, m._buckets)
-        m._allreduce = m._allreduce_async = m._buckets = None
-        try:
-            m.train_step_resident()
-        finally:
-            m._graph = g
-            m._allreduce, m._allreduce_async, m._buckets = dp
-            if plan is not None:
-                del plan.run                 # back to the class method
-        _sync()
-    finally:
-        ops.conv_fprop, ops.conv_wgrad = orig_f, orig_w
-    # what an event pair measures around NOTHING (the second event's own processing: ~1.5-2.5 us on this runtime) is taken
-    # off every launch -- without it a family of 120 launches of 14 us reads 17 us per launch (rocprofv3: 14.4) and can
-    # overtake, as "dominant kernel", a family of 43 launches of 46 us whose kernel time is larger
-    Ev = torch.cuda.Event if torch.cuda.is_available() else _HostEvent
-    null = [(Ev(enable_timing=True), Ev(enable_timing=True)) for _ in range(33)]
-    for e0, e1 in null:
-        e0.record()
-        e1.record()
+            scale[cv.wd_ptr.value] = sc
+    g = m._graph
+    m._graph = None
+    # this extra step runs on rank 0 ONLY: it must not enter the gradient all-reduce (the other ranks are already
+    # waiting in the final barrier)
+    dp = (m._allreduce, m._allreduce_async, m._buckets)
+    m._allreduce = m._allreduce_async = m._buckets = None
     _sync()
-    ov = sorted(e0.elapsed_time(e1) for e0, e1 in null)[len(null) // 2]
-    EVENT_OVERHEAD_MS[0] = ov
+    lib.profile_begin()
+    try:
+        m.train_step_resident()
+    finally:
+        recs, calls = lib.profile_end()
+        m._graph = g
+        m._allreduce, m._allreduce_async, m._buckets = dp
+    _sync()
+    work = [None] * len(recs)           # (flops, bytes) per record
+    plan = ctx.wgrad_plan
+    for name, args, n0, n1 in calls:
+        if name in ("hdu_conv_fprop", "hdu_conv_wgrad", "hdu_conv_dgrad_strided"):
+            d = args[0]._obj
+            work[n0] = _conv_work(d, 1 if name == "hdu_conv_wgrad" else 0, scale)
+        elif name == "hdu_wgrad_plan_run" and plan is not None:
+            ds = plan.descs[getattr(args[0], "value", args[0])]
+            ws = [_conv_work(d, 1, scale) for d in ds]
+            work[n0] = (sum(w[0] for w in ws), sum(w[1] for w in ws))
+        else:
+            rw = _row_work(name, args, ctx)
+            if rw is not None:
+                for i, nb in enumerate(rw[:n1 - n0]):
+                    if nb is not None:
+                        work[n0 + i] = (0.0, nb)
     agg = {}
-    bym = {}
-    detail = os.environ.get("HDU_BENCH_VERBOSE") == "2"      # one row per GEMM shape (N, K, taps) instead of per M
-    for name, fl, e0, e1, mm, shape, nbytes in recs:
-        t = max(e0.elapsed_time(e1) - ov, 1e-4)
-        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+    for (kname, ms), w in zip(recs, work):
+        a = agg.setdefault(kname, [0, 0.0, 0.0, 0.0, True])
         a[0] += 1
-        a[1] += t
-        a[2] += fl
-        a[3] += nbytes
-        b = bym.setdefault((mm, name + (" N=%d K=%d taps=%d" % shape if detail else "")), [0, 0.0, 0.0])
-        b[0] += 1
-        b[1] += t
-        b[2] += fl
+        a[1] += max(ms, 1e-5)
+        if w is None:
+            a[4] = False
+        else:
+            a[2] += w[0]
+            a[3] += w[1]
+    out = {}
+    for k, a in agg.items():
+        out[k] = [a[0], a[1], a[2], a[3] if a[4] else None]
     if os.environ.get("HDU_BENCH_VERBOSE"):
-        for mm in sorted(bym):
-            b = bym[mm]
-            print("M=%8d %-44s launches=%4d ms=%7.3f us/launch=%7.1f TF=%6.1f" %
-                  (mm[0], mm[1], b[0], b[1], b[1] / b[0] * 1e3, b[2] / (b[1] * 1e-3) / 1e12), file=sys.stderr)
-    return agg
+        tot = sum(v[1] for v in out.values())
+        for k, v in sorted(out.items(), key=lambda kv: -kv[1][1]):
+            print("%-100s launches=%4d ms=%7.3f (%5.2f%%) us/launch=%7.1f" % (k[:100], v[0], v[1], 100 * v[1] / tot, v[1] / v[0] * 1e3),
+                  file=sys.stderr)
+    return out
 
 
 def cpu_baseline(config, size, cols, samples=2):
@@ -265,7 +288,7 @@ def pmc_traffic(kernel, config, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC summaries (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     passes over this same bench command, profiles/): FETCH_SIZE [KB] x2 (gfx950 counts a 128-B request as 64 B,
     MI355X_MICROARCH.md "HBM") + WRITE_SIZE [KB].  None when no summary of this config / kernel is committed."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r03"):
         vals = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             path = os.path.join(ROOT, "profiles", "%s_pmc_%s_%s_%s.txt" % (rnd, ctr, config, dtype))
@@ -292,31 +315,58 @@ DETAILS = {}          # per-workload conv-kernel tables: written to gpurun_out/ 
 
 
 def roofline_record(agg, name, config, dtype):
-    """SURVEY.md section 8(d) / DESIGN.md section 3: the dominant conv kernel's algorithmic FLOPs and algorithmic HBM bytes per
-    launch over its HIP-event launch time.  `bound` is the roof its arithmetic intensity puts it under (ridge = MFMA
-    peak / HBM peak); `achieved` / `peak` / `frac` are in that roof's unit; both fractions are reported."""
+    """SURVEY.md section 8(d) / DESIGN.md section 3: the kernel with the largest total time in the step (over ALL kernels, row
+    kernels included): its algorithmic FLOPs and algorithmic HBM bytes per launch over its own begin-to-end launch time
+    (library launch profiler, live).  `bound` is the roof its arithmetic intensity puts it under (ridge = MFMA peak / HBM
+    peak; a kernel without FLOPs is HBM-bound); `achieved` / `peak` / `frac` are in that roof's unit; both fractions are
+    reported."""
     n, tms, fl, nbytes = agg[name]
     sec = tms * 1e-3
-    tf, gbs = fl / sec / 1e12, nbytes / sec / 1e9
+    step_ms = sum(v[1] for v in agg.values())
     peak_tf = PEAK_TFLOPS[dtype]
-    ai = fl / max(nbytes, 1.0)
+    tf = fl / sec / 1e12
+    gbs = (nbytes / sec / 1e9) if nbytes else None
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
-    hbm_bound = ai < ridge
+    ai = (fl / nbytes) if nbytes else None
+    hbm_bound = fl == 0.0 or (ai is not None and ai < ridge)
     traffic, rnd = pmc_traffic(name, config, dtype)
-    r = {"bound": "hbm" if hbm_bound else "mfma",
-         "achieved": round(gbs if hbm_bound else tf, 2), "peak": PEAK_HBM_GBS if hbm_bound else peak_tf,
-         "unit": "GB/s" if hbm_bound else "TFLOP/s",
-         "frac": round((gbs / PEAK_HBM_GBS) if hbm_bound else (tf / peak_tf), 4),
+    if hbm_bound:
+        ach, peak, unit = (round(gbs, 2) if gbs is not None else None), PEAK_HBM_GBS, "GB/s"
+        frac = round(gbs / PEAK_HBM_GBS, 4) if gbs is not None else None
+    else:
+        ach, peak, unit, frac = round(tf, 2), peak_tf, "TFLOP/s", round(tf / peak_tf, 4)
+    r = {"bound": "hbm" if hbm_bound else "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": frac,
          "traffic": traffic, "kernel": name, "launches_per_step": n, "avg_launch_us": round(tms / n * 1e3, 2),
-         "event_pair_overhead_us": round(EVENT_OVERHEAD_MS[0] * 1e3, 2),
+         "share_of_step_kernel_time": round(tms / step_ms, 4),
+         "timing": "begin-to-end time of each dispatch (hipExtLaunchKernel start/stop events), no overhead subtracted",
          "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak_tf, 4),
-         "hbm_gbs_algorithmic": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
-         "flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
-         "algorithmic_bytes_per_launch": int(nbytes / n), "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+         "hbm_gbs_algorithmic": round(gbs, 1) if gbs is not None else None,
+         "hbm_frac": round(gbs / PEAK_HBM_GBS, 4) if gbs is not None else None,
+         "flop_per_byte": round(ai, 1) if ai is not None else None, "ridge_flop_per_byte": round(ridge, 1),
+         "algorithmic_bytes_per_launch": int(nbytes / n) if nbytes else None,
+         "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
     if traffic is not None:
         r["traffic_source"] = "profiles/%s_pmc_{FETCH,WRITE}_SIZE_%s_%s.txt (FETCH x2 + WRITE, per launch)" % (rnd, config, dtype)
         r["hbm_gbs_counters"] = round(traffic / (sec / n) / 1e9, 1)
     return r
+
+
+def top_kernels(agg, dtype, k=4):
+    """the k kernels with the largest total time, compact: (name, launches, us per step, share, fraction of its roof)"""
+    tot = sum(v[1] for v in agg.values())
+    ridge = PEAK_TFLOPS[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    out = []
+    for name, (n, tms, fl, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:k]:
+        sec = tms * 1e-3
+        hbm = fl == 0.0 or (nb and fl / nb < ridge)
+        frac = None
+        if hbm and nb:
+            frac = nb / sec / 1e9 / PEAK_HBM_GBS
+        elif not hbm:
+            frac = fl / sec / 1e12 / PEAK_TFLOPS[dtype]
+        out.append({"kernel": name[:72], "n": n, "us": round(tms * 1e3, 1), "share": round(tms / tot, 3),
+                    "bound": "hbm" if hbm else "mfma", "frac": round(frac, 3) if frac is not None else None})
+    return out
 
 
 def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline):
@@ -392,11 +442,16 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
     # (halo exchange, sync-BN), so it is skipped there when world > 1
     if rank == 0 and roofline and not (config == "shard3d" and world > 1):
         agg = instrumented_step(m)
-        name = max(agg.items(), key=lambda kv: kv[1][1])[0]
+        name = max(agg.items(), key=lambda kv: kv[1][1])[0]       # largest total time over ALL kernels of the step
         rec["roofline"] = roofline_record(agg, name, config, dtype)
+        rec["top_kernels"] = top_kernels(agg, dtype)
+        kms = sum(v[1] for v in agg.values())
+        rec["step_kernel_ms_eager_profiled"] = round(kms, 3)
+        rec["launches_per_step"] = sum(v[0] for v in agg.values())
         DETAILS["%s:%s" % (config, dtype)] = {
-            k: {"launches": v[0], "ms": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
-                "alg_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1)}
+            k: {"launches": v[0], "ms": round(v[1], 4), "us_per_launch": round(v[1] / v[0] * 1e3, 2),
+                "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                "alg_gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     del m
     gc.collect()
@@ -412,8 +467,8 @@ def compact(rec):
     out["workload"] = rec["workload"][:120]
     if "roofline" in rec:
         r = rec["roofline"]
-        out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "mfma_frac",
-                                             "hbm_frac")}
+        out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step",
+                                             "avg_launch_us", "share_of_step_kernel_time", "mfma_frac", "hbm_frac")}
     if "cpu_baseline" in rec:
         c = rec["cpu_baseline"]
         out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind")}
@@ -478,7 +533,7 @@ def main():
                 e_b, e_size, e_cols = 1, 64 if DRYRUN else 512, (8 if DRYRUN else 64) * world
             else:
                 e_b, e_size, e_cols = 1, 32 if DRYRUN else 224, 8 if DRYRUN else 12
-            cap = {"shard3d": 5}.get(cfg, 30 if dt == "bf16" else 3)
+            cap = {"shard3d": 10}.get(cfg, 30 if dt == "bf16" else 10)       # every workload is timed over >= 10 steps
             e_steps = max(2, min(a.steps, cap))
             e_warm = max(1, min(a.warmup, 3 if (dt == "bf16" and cfg != "shard3d") else 1))
             extra_recs.append(run_workload(cfg, dt, e_b, e_size, e_cols, e_steps, e_warm, rank, world, not a.no_graph,
@@ -503,6 +558,8 @@ def main():
     if rank == 0:
         if "roofline" in main_rec:
             out["roofline"] = main_rec["roofline"]
+            out["config"]["top_kernels"] = main_rec.get("top_kernels")
+            out["config"]["launches_per_step"] = main_rec.get("launches_per_step")
         if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
             out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
             for r in extra_recs:

@@ -35,3 +35,115 @@ extern "C" const char* hdu_backend(void) {
 }
 extern "C" int hdu_abi_version(void) { return HDU_ABI_VERSION; }
 extern "C" size_t hdu_sizeof_conv_desc(void) { return sizeof(hdu_conv_desc); }
+
+// ---------------------------------------------------------------- launch profiler (include/hdu.h: hdu_profile_*)
+#include <cxxabi.h>
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+int g_hdu_prof_on = 0;
+
+namespace {
+struct ProfRec {
+  const void* addr;
+#ifndef HDU_EMU
+  hipEvent_t e0, e1;
+#endif
+};
+std::vector<ProfRec> g_prof;
+size_t g_prof_cap = 0;
+#ifndef HDU_EMU
+std::vector<hipEvent_t> g_prof_pool;      // events are created once and reused by later profiling windows
+#endif
+
+// kernel address -> "conv_igemm_dma_kernel<unsigned short, 128, 96, 4, 1, true, false, 0>": the symbol the address belongs
+// to (the kernels are template instantiations with default visibility: they are in the dynamic symbol table), demangled,
+// without the return type and the parameter list -- spelled as rocprofv3 prints the kernel
+std::string kernel_of(const void* addr) {
+  Dl_info info;
+  if (!addr || !dladdr(addr, &info) || !info.dli_sname) return "unknown_kernel";
+  int status = 0;
+  char* dm = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &status);
+  std::string s = (status == 0 && dm) ? dm : info.dli_sname;
+  free(dm);
+  if (s.compare(0, 5, "void ") == 0) s = s.substr(5);
+  const std::string stub = "__device_stub__";
+  size_t q = s.find(stub);
+  if (q != std::string::npos) s.erase(q, stub.size());
+  int depth = 0;
+  for (size_t i = 0; i < s.size(); ++i) {            // cut at the '(' of the parameter list (outside template brackets)
+    if (s[i] == '<') ++depth;
+    else if (s[i] == '>') --depth;
+    else if (s[i] == '(' && depth == 0) { s.resize(i); break; }
+  }
+  return s;
+}
+}  // namespace
+
+#ifndef HDU_EMU
+int hdu_prof_next(const void* kernel_addr, hipEvent_t* e0, hipEvent_t* e1) {
+  if (g_prof.size() >= g_prof_cap) return 0;
+  const size_t i = g_prof.size();
+  while (g_prof_pool.size() < 2 * (i + 1)) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return 0;
+    g_prof_pool.push_back(e);
+  }
+  ProfRec r;
+  r.addr = kernel_addr;
+  r.e0 = g_prof_pool[2 * i];
+  r.e1 = g_prof_pool[2 * i + 1];
+  g_prof.push_back(r);
+  *e0 = r.e0;
+  *e1 = r.e1;
+  return 1;
+}
+#else
+int hdu_prof_note(const void* kernel_addr) {
+  if (g_prof.size() >= g_prof_cap) return 0;
+  ProfRec r;
+  r.addr = kernel_addr;
+  g_prof.push_back(r);
+  return 1;
+}
+#endif
+
+extern "C" int hdu_profile_begin(int max_records) {
+  if (max_records <= 0) return hdu_set_error(HDU_ERR_ARG, "profile_begin: max_records must be positive");
+  g_prof.clear();
+  g_prof.reserve((size_t)max_records);
+  g_prof_cap = (size_t)max_records;
+  g_hdu_prof_on = 1;
+  return 0;
+}
+
+extern "C" int hdu_profile_count(void) { return (int)g_prof.size(); }
+
+extern "C" int hdu_profile_end(void) {
+  g_hdu_prof_on = 0;
+#ifndef HDU_EMU
+  if (!g_prof.empty() && hipEventSynchronize(g_prof.back().e1) != hipSuccess) {
+    (void)hipGetLastError();
+    return hdu_set_error(HDU_ERR_LAUNCH, "profile_end: waiting for the last recorded kernel failed");
+  }
+#endif
+  return (int)g_prof.size();
+}
+
+extern "C" int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms) {
+  if (i < 0 || (size_t)i >= g_prof.size() || !name_buf || buflen < 2 || !ms)
+    return hdu_set_error(HDU_ERR_ARG, "profile_get: bad index / buffer");
+  const std::string k = kernel_of(g_prof[(size_t)i].addr);
+  snprintf(name_buf, buflen, "%s", k.c_str());
+  *ms = 0.f;
+#ifndef HDU_EMU
+  if (hipEventElapsedTime(ms, g_prof[(size_t)i].e0, g_prof[(size_t)i].e1) != hipSuccess) {
+    (void)hipGetLastError();
+    return hdu_set_error(HDU_ERR_LAUNCH, "profile_get: hipEventElapsedTime failed");
+  }
+#endif
+  return 0;
+}

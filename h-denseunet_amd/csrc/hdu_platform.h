@@ -8,17 +8,37 @@
 
 #ifdef HDU_EMU
 #include "hipemu.h"
-#define HDU_LAUNCH(kern, grid, block, smem, stream, ...) \
-  hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+extern int g_hdu_prof_on;
+int hdu_prof_note(const void* kernel_addr);
+#define HDU_LAUNCH(kern, grid, block, smem, stream, ...)                      \
+  do {                                                                        \
+    if (g_hdu_prof_on) (void)hdu_prof_note((const void*)(kern));              \
+    hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); });    \
+  } while (0)
 #define HDU_DYN_SMEM(name) char* name = hipemu::g_cur->dyn_smem
 #define HDU_LANE() (hipemu::g_cur->lane)
 #define HDU_LAUNCH_OK() 0
 #else
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+// Launch profiler (include/hdu.h: hdu_profile_*).  While armed, every HDU_LAUNCH goes through hipExtLaunchKernelGGL with
+// a start / stop event pair attached to THAT dispatch (the events take the dispatch's own begin / end timestamps -- what
+// rocprofv3 --kernel-trace reports -- not the time between two marker packets, which adds a box-dependent 2-9 us to
+// every launch); the record keeps the kernel's address (hdu_profile_get resolves it to the instantiated name: dladdr +
+// demangling).  Not armed (always, outside bench.py's one instrumented step): one predictable branch.
+extern int g_hdu_prof_on;
+int hdu_prof_next(const void* kernel_addr, hipEvent_t* e0, hipEvent_t* e1);
 // hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind so that
 // hdu_check_launch() reports THIS launch only
-#define HDU_LAUNCH(kern, grid, block, smem, stream, ...) \
-  do { (void)hipGetLastError(); hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
+#define HDU_LAUNCH(kern, grid, block, smem, stream, ...)                                                         \
+  do {                                                                                                           \
+    (void)hipGetLastError();                                                                                     \
+    hipEvent_t pe0_, pe1_;                                                                                       \
+    if (g_hdu_prof_on && hdu_prof_next((const void*)(kern), &pe0_, &pe1_))                                       \
+      hipExtLaunchKernelGGL(kern, (grid), (block), (smem), (stream), pe0_, pe1_, 0, __VA_ARGS__);                \
+    else                                                                                                         \
+      hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                                  \
+  } while (0)
 #define HDU_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define HDU_LANE() ((int)(threadIdx.x & 63))
 #define HDU_LAUNCH_OK() ((int)hipGetLastError())

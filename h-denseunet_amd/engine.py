@@ -191,6 +191,11 @@ class Ctx:
         self.fold_next = os.environ.get("HDU_FOLD_NEXT", "1") == "1"
         self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
+        # Round 4: a POINTWISE conv behind a BN(+Scale)+ReLU (every dense-block bottleneck, every transition) reads the raw
+        # tensor and applies the affine to its operand fragments in registers (conv_igemm.hip: PRO kernels; the filter
+        # gradient recomputes it the same way), so the normalised copy of the O(L^2)-wide concatenated slab is never written.
+        # HDU_FUSE_PW=0 restores the materialised operand of rounds 1-3 (A/B runs).
+        self.fuse_pw = os.environ.get("HDU_FUSE_PW", "1") == "1"
         # filter gradients deferred to the end of the backward pass and run as ONE launch per kernel family
         # (ops.WgradPlan); bf16 + materialised inputs only; off under depth sharding / bucketed data parallelism
         self.batch_wgrad = os.environ.get("HDU_BATCH_WGRAD", "1") == "1"
@@ -328,6 +333,9 @@ class Ctx:
                 d = ops.conv_desc(cv.xin.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.conv_up)
             elif cv.bn is None and cv.skip is None:      # the conv reads its producer directly (stems, 1x1 heads)
                 d = ops.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up)
+            elif cv.pw_fused:                            # pointwise over relu(a * x + b): recomputed on the x fragments
+                d = ops.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up, None,
+                                  (cv.bn.a, cv.bn.b), cv.bn.relu)
             else:
                 continue                    # fused prologue: per-layer launch
             plan.add(d, cv.kernel.grad)
@@ -713,7 +721,11 @@ class ConvLayer:
         # prologue costs more VALU cycles than the MFMAs it feeds (profiles/).
         self.xin = None
         self.conv_up = up
-        if halo:
+        self.pw_fused = bool(ctx.fuse_pw and bn is not None and skip is None and not halo and K == (1, 1, 1)
+                             and stride == (1, 1, 1) and pad == (0, 0, 0) and up == (0, 0, 0) and cin_p <= ops.PRO_CMAX)
+        if self.pw_fused:
+            pass                      # no operand buffer: hdu_conv_desc.pro_* on the DMA kernels
+        elif halo:
             self.xin = ctx.new_var(xa.N, xa.D + 2 * halo, xa.H, xa.W, cin_p)
             plane = xa.H * xa.W * cin_p
             self.xin_interior = ops.Act(self.xin.act.buf, halo * plane, xa.N, xa.D, xa.H, xa.W, cin_p, cin_p, dt)
@@ -1226,7 +1238,8 @@ class LossLayer:
 
     def run(self, with_grad=True):
         if self.ctx._zeroed_fwd_pass != self.ctx.pass_id:      # not inside a step whose head launch cleared the arena
-            ops.zero_tensor(self.ctx.arena[:4 * len(self.ctx.loss_layers)])
+            i = self.ctx.loss_layers.index(self)                # this layer's own [loss sum | 3 class counts] slot only
+            ops.zero_tensor(self.ctx.arena[4 * i:4 * i + 4])
         dl = None
         if with_grad:
             self.logits.root.written = True

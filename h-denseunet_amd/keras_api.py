@@ -121,6 +121,7 @@ class Model:
         self.world_size = 1
         self._graph = None
         self._graph_hparams = None
+        self._eager_steps = 0            # eager training steps run so far (capture_graph needs two before it captures)
         self._allreduce = None
         self._allreduce_async = None
         self._buckets = None
@@ -259,6 +260,7 @@ class Model:
             if self._allreduce is not None:
                 self._allreduce(self.ctx.G[:self.ctx.n_trainable])
         self._step_update()
+        self._eager_steps += 1
 
     def capture_graph(self, warmup=2):
         """capture the step into hipGraphs.  Single GPU: ONE graph (fwd + bwd + SGD).  Data parallel: the gradient
@@ -267,6 +269,11 @@ class Model:
             raise RuntimeError("compile() the model first")
         if self.optimizer.decay > 0:
             raise RuntimeError("graph capture freezes the learning rate; decay>0 is not supported with it")
+        # The step's device tables (ops.ZeroPlan of the step head, ops.BnBwdPlan of the deferred finalizes) are built lazily
+        # by the first TWO eager steps (the first backward registers the partially written gradient slabs, the second step
+        # head builds the table with them) with synchronous host-to-device copies: that must not happen inside the capture.
+        warmup = max(warmup, 2 - self._eager_steps)
+        self._graph = None                 # (a re-capture: the warm-up below must run eagerly)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

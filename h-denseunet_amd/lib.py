@@ -161,6 +161,10 @@ _SIGS = {
     "hdu_cast_out": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
     "hdu_zero_regions": (c_int, [c_p, c_int, c_u32, c_p, c_u32, c_p]),
     "hdu_zero": (c_int, [c_p, ctypes.c_uint64, c_p]),
+    "hdu_profile_begin": (c_int, [c_int]),
+    "hdu_profile_count": (c_int, []),
+    "hdu_profile_end": (c_int, []),
+    "hdu_profile_get": (c_int, [c_int, ctypes.c_char_p, c_sz, ctypes.POINTER(c_f)]),
     "hdu_comm_unique_id": (c_int, [c_p]),
     "hdu_comm_init": (c_int, [ctypes.POINTER(c_p), c_int, c_int, c_p]),
     "hdu_comm_destroy": (c_int, [c_p]),
@@ -178,7 +182,7 @@ class HduError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4        # include/hdu.h HDU_ABI_VERSION
+ABI_VERSION = 5        # include/hdu.h HDU_ABI_VERSION
 
 
 def product_library_path():
@@ -249,6 +253,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(20, int(os.environ["HDU_PW_BSTAT_WGS"]))
     if "HDU_WGRAD_NCT" in os.environ:
         lib.hdu_set_tuning(21, int(os.environ["HDU_WGRAD_NCT"]))
+    if "HDU_NO_PRO_DMA" in os.environ:
+        lib.hdu_set_tuning(22, int(os.environ["HDU_NO_PRO_DMA"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
         lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
 
@@ -280,7 +286,61 @@ def use_emulator_for_tests():
     return _lib
 
 
+class _CallLog:
+    """proxy of the bound library used while the launch profiler is armed (profile_begin): every C-ABI call is forwarded
+    unchanged, and (entry point, its arguments, index of the first / one-past-last kernel record it produced) is appended to
+    `calls`, so that a caller (bench.py) can attach an algorithmic-work model to each recorded launch"""
+
+    def __init__(self, lib):
+        self._lib, self.calls = lib, []
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("hdu_") or name.startswith("hdu_profile") or name in ("hdu_last_error", "hdu_conv_kernel_name"):
+            return fn
+        lib, calls = self._lib, self.calls
+
+        def wrapped(*args):
+            n0 = lib.hdu_profile_count()
+            r = fn(*args)
+            n1 = lib.hdu_profile_count()
+            if n1 > n0:
+                calls.append((name, args, n0, n1))
+            return r
+        return wrapped
+
+
+_call_log = None
+
+
+def profile_begin(max_records=1 << 16):
+    """arm the library's launch profiler (include/hdu.h: hdu_profile_*) and start logging the C-ABI calls"""
+    global _call_log
+    lib = get() if _call_log is None else _call_log._lib
+    check(lib.hdu_profile_begin(max_records), "hdu_profile_begin")
+    _call_log = _CallLog(lib)
+
+
+def profile_end():
+    """-> ([(kernel name, milliseconds)] in launch order, [(entry point, args, first record, one past last record)])"""
+    global _call_log
+    log, _call_log = _call_log, None
+    lib = log._lib
+    n = lib.hdu_profile_end()
+    if n < 0:
+        raise HduError("hdu_profile_end failed: %s" % lib.hdu_last_error().decode())
+    buf = ctypes.create_string_buffer(256)
+    ms = c_f(0.0)
+    recs = []
+    for i in range(n):
+        check(lib.hdu_profile_get(i, buf, 256, ctypes.byref(ms)), "hdu_profile_get")
+        recs.append((buf.value.decode(), float(ms.value)))
+    return recs, log.calls
+
+
 def get():
+    if _call_log is not None:
+        return _call_log
     if _lib is None:
         load()
     return _lib

@@ -97,6 +97,7 @@ SPLITK_BYTES = 320 * 16 * 64 * 128 * 4
 # Number of depth shards the layers of the descriptors built next are split over: the engine sets it while it builds / runs a
 # depth-sharded model (engine.Ctx._desc_scope), 1 otherwise.  conv_desc turns it into hdu_conv_desc.layer_rows.
 SHARD_WORLD = 1
+PRO_CMAX = 2304      # conv_igemm.hip HDU_PRO_CMAX: widest contraction whose BN prologue the async-DMA pointwise kernels take
 
 
 def splitk_scratch():

@@ -43,10 +43,23 @@ const char* hdu_backend(void);
 /* Layout version of the structs in this header (hdu_conv_desc, hdu_fold_entry, hdu_aug_sample, hdu_prep_entry) and of the
  * entry-point set.  A binding compares hdu_abi_version() and hdu_sizeof_conv_desc() with what it was written against and
  * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*,
- * 4 = round 3 (hdu_zero_regions, hdu_comm_*). */
-#define HDU_ABI_VERSION 4
+ * 4 = round 3 (hdu_zero_regions, hdu_comm_*), 5 = round 4 (hdu_profile_*, pointwise convs with a fused BN prologue on the
+ * DMA path). */
+#define HDU_ABI_VERSION 5
 int hdu_abi_version(void);
 size_t hdu_sizeof_conv_desc(void);
+/* Launch profiler (measurement only; replaces nothing in the reference -- Keras has `verbose`, the reference was profiled with
+ * nvprof from outside).  hdu_profile_begin(max_records) arms it: from then on EVERY kernel launch of this library is made
+ * with a start / stop event pair attached to that dispatch (hipExtLaunchKernelGGL), so a record is the kernel's own
+ * begin-to-end time -- the figure rocprofv3 --kernel-trace reports -- not a marker-to-marker interval.  hdu_profile_end()
+ * disarms it, waits for the last recorded kernel and returns the number of records; hdu_profile_get(i, ...) then returns
+ * record i in launch order: the instantiated kernel name (NUL-terminated, truncated to `buflen`) and its duration in
+ * milliseconds.  Launches beyond max_records run unprofiled.  Do not arm it during hipGraph capture.  The x86 test
+ * build records names with a duration of 0. */
+int hdu_profile_begin(int max_records);
+int hdu_profile_count(void);
+int hdu_profile_end(void);
+int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
 /* developer tuning knobs (process-wide): key HDU_TUNE_DMA_STAGES: 2 = two LDS stages, deep ring for small grids (default); 6 = deep ring everywhere */
 #define HDU_TUNE_DMA_STAGES 0
 #define HDU_TUNE_HALO_TARGET_WGS 7    /* workgroups a halo-tile filter-gradient launch aims for */
@@ -69,6 +82,7 @@ size_t hdu_sizeof_conv_desc(void);
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
 #define HDU_TUNE_NO_PW_BSTAT 19      /* 1 = disable the filter-stationary pointwise kernel (A/B) */
 #define HDU_TUNE_PW_BSTAT_WGS 20     /* workgroups that kernel aims for (default 256) */
+#define HDU_TUNE_NO_PRO_DMA 22       /* 1 = a pointwise conv with a BN prologue takes the VGPR-gather kernels of rounds 1-3 (A/B) */
 #define HDU_TUNE_WGRAD_NCT 21        /* 1 = one filter-row tile per pointwise filter-gradient workgroup (round 2's form; A/B) */
 int hdu_set_tuning(int key, int value);
 

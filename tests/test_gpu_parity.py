@@ -21,6 +21,8 @@ def _pair(kind, variant, b, size, cols, dtype):
 @pytest.mark.parametrize("kind,variant,b,size,cols,primed", [
     ("2d", "denseunet", 1, 512, None, False),          # BASELINE configs[0]: single 512x512 slice
     ("2d", "denseunet", 1, 512, None, True),           # same, batch statistics taken in the conv epilogues
+    ("2d", "denseunet", 8, 512, None, True),           # BASELINE configs[1]: the batch bench.py times --
+                                                       # M = 8 x 512^2 picks other tiles / split-K counts than 1-2 slices do
     ("2d", "densenet", 2, 224, None, False),
     ("hybrid", "3dpart", 1, 224, 12, False),           # configs[2]
     ("hybrid", "end2end", 1, 224, 12, False),          # configs[3]
@@ -94,6 +96,93 @@ def test_full_forward_parity_f32(hip_lib, kind, variant, b, size, cols, primed):
     d_got = w_after[last][0] - w_before[last][0]
     d_ref = P.numpy()[last][0] - w_before[last][0]
     assert np.linalg.norm(d_got - d_ref) <= 2e-2 * np.linalg.norm(d_ref) + 1e-9
+
+
+def test_shard_shape_forward_loss_f32(hip_lib):
+    """the per-GPU shard shape of BASELINE configs[4] -- 512 x 512 planes of the stand-alone 3D DenseNet,
+    16 depth planes here (bench.py's `shard3d` runs 64: the same large-grid kernel forms, M = 65 K ... 4.2 M pixels per layer)
+    -- training-phase forward (batch statistics) + loss.py's loss in float32 against the float32 oracle."""
+    kind, variant, b, size, cols = "3d", "3dpart", 1, 512, 16
+    m, P, fwd = _pair(kind, variant, b, size, cols, "f32")
+    x, y = U.synthetic_batch(kind, b, size, cols)
+    xt = torch.tensor(x)
+    P.learning_phase = 1
+    with torch.no_grad():
+        ref = fwd(P, xt)
+        ref_loss = float(U.loss_fn_for(kind)(torch.tensor(y), ref))
+    P.bn_batch_means = {}
+    ref = ref.numpy()
+    m.loss_layer.set_labels(m._labels_internal(y))
+    got = m.forward_train_mode(x)
+    m.loss_layer.run(False)
+    loss = m.loss_layer.value()
+    scale = max(1.0, float(np.abs(ref).max()))
+    e = float(np.abs(got - ref).max())
+    print("shard shape 512x512x16 f32: train-mode logits max abs err %.3e (scale %.3g), loss %.6f (oracle %.6f)" % (e, scale, loss, ref_loss))
+    assert e <= 2e-4 * scale, "train-mode logits: max abs err %.3e (scale %.3g)" % (e, scale)
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
+    assert min(U.dice_vs_oracle(got, ref)) >= 1 - 1e-3
+
+
+@pytest.mark.parametrize("dtype,kind,variant,b,size,cols", [
+    ("f32", "2d", "denseunet", 2, 256, None),
+    ("bf16", "2d", "denseunet", 8, 512, None),          # the benchmarked configuration itself
+    ("bf16", "hybrid", "end2end", 1, 224, 12),
+], ids=["f32-2d", "bf16-2d-8x512", "bf16-end2end"])
+def test_graph_replay_equals_eager_steps(hip_lib, dtype, kind, variant, b, size, cols):
+    """what bench.py times is a REPLAYED hipGraph of the step; every parity test drives eager steps.
+    Same model, same start state (weights, velocities, moving statistics, dropout counter): three eager steps, then the state
+    is restored, the step is captured and replayed three times.  The two runs launch the same kernels on the same buffers, so
+    they differ only by the order of the float atomics (epilogue statistics, pixel-split filter gradients): the parameters
+    after three steps agree to that noise -- measured, and gated at 1e-5 (f32) / 2e-3 (bf16) of the accumulated update's norm
+    ... a captured launch with a stale pointer / argument (learning rate, seed, a buffer rebuilt after capture) is off by O(1)."""
+    ka = U.pkg("keras_api")
+    if kind == "2d":
+        m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(b, size), dtype=dtype)
+        lossfn = U.pkg("loss").weighted_crossentropy_2ddense
+    else:
+        m = U.pkg("hybridnet").dense_rnn_net(U.make_args(b, size, cols), dtype=dtype)
+        lossfn = U.pkg("loss").weighted_crossentropy
+    m.compile(optimizer=ka.SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[lossfn])
+    x, y = U.synthetic_batch(kind, b, size, cols)
+    m.train_on_batch(x, y)                   # primes the epilogue statistics, builds the step tables (dropout stays ON)
+    m.train_step_resident()
+    torch.cuda.synchronize()
+    ctx = m.ctx
+    state = (ctx.P.clone(), ctx.V.clone(), ctx.seed_dev.clone(), m.optimizer.iterations,
+             [(r.mean.clone(), r.var.clone()) for r in ctx.stat_roots])
+
+    def restore():
+        ctx.P.copy_(state[0]); ctx.V.copy_(state[1]); ctx.seed_dev.copy_(state[2])
+        m.optimizer.iterations = state[3]
+        for r, (mu, va) in zip(ctx.stat_roots, state[4]):
+            r.mean.copy_(mu); r.var.copy_(va)
+
+    def three_steps():
+        losses = []
+        for _ in range(3):
+            m.train_step_resident()
+            losses.append(m.loss_value())
+        torch.cuda.synchronize()
+        return losses, ctx.P.clone()
+
+    assert m._graph is None
+    l_eager, p_eager = three_steps()
+    restore()
+    m.capture_graph(warmup=0)
+    assert m._graph is not None
+    restore()                                 # (capture executes nothing, but be explicit)
+    l_graph, p_graph = three_steps()
+    upd = float((p_eager - state[0]).double().norm())
+    diff = float((p_graph - p_eager).double().norm())
+    print("graph replay vs eager (%s %s/%s): losses %s vs %s; |P_graph - P_eager| = %.3e of |update| %.3e (%.2e relative)"
+          % (dtype, kind, variant, ["%.6f" % v for v in l_graph], ["%.6f" % v for v in l_eager], diff, upd, diff / upd))
+    assert upd > 0 and np.isfinite(diff)
+    assert diff <= (1e-5 if dtype == "f32" else 2e-3) * upd, (diff, upd)
+    for a, g in zip(l_eager, l_graph):
+        assert abs(a - g) <= (1e-5 if dtype == "f32" else 2e-3) * abs(a), (l_eager, l_graph)
+    # and the replayed step is not a no-op: the three losses differ from each other
+    assert len({round(v, 7) for v in l_graph}) == 3
 
 
 @pytest.mark.parametrize("kind,variant,b,size,cols", [

@@ -157,7 +157,11 @@ CASES = [
     ("3d", "3dpart", 1, 224, 12, "trained"),                 # the per-shard network of configs[4]
     ("2d", "denseunet", 2, 512, None, "mid"),
     ("hybrid", "end2end", 1, 224, 12, "mid"),
+    ("2d", "denseunet", 8, 512, None, "mid"),                # BASELINE configs[1] itself: the batch bench.py times
 ]
+# The gate constants of this file (BF16_SLACK, REL_FLOOR, COS_MIN, the 1 % / 10 x per-tensor rule, the Dice floors, the 1.5 x
+# logit bound, the regression-coefficient bounds) are FROZEN as of commit 44f1729 (round 3).  Changing
+# one needs a figure in profiles/ that shows the product equal to the bf16-storage oracle at the new bound.
 FIGURES = os.path.join(U.ROOT, "gpurun_out", "bf16_parity_figures.txt")
 
 
@@ -172,7 +176,7 @@ def _log(msg):
 
 
 @pytest.mark.parametrize("kind,variant,b,size,cols,recipe", CASES,
-                         ids=["2d-2x512", "3dpart", "end2end", "3d", "2d-2x512-mid", "end2end-mid"])
+                         ids=["2d-2x512", "3dpart", "end2end", "3d", "2d-2x512-mid", "end2end-mid", "2d-8x512-mid"])
 def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols, recipe):
     small = os.environ.get("HDU_PARITY_SMALL") == "1"       # developer switch: same flow at reduced depth / size
     nb2d, nb3d = ((2, 2, 2, 2), (1, 1, 2, 1)) if small else (FULL2D, FULL3D)
@@ -219,6 +223,9 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols,
           "%.5f, Dice vs oracle %s (bf16-storage oracle vs oracle %s); Dice vs ground truth %s (oracle %s, bf16-storage oracle %s)" %
           (kind_tag, scale, e_pred, e_pred / scale, float(np.median(margin)), agree, ["%.5f" % d for d in dice],
            ["%.5f" % d for d in dice_cal], ["%.4f" % d for d in dice_gt_got], ["%.4f" % d for d in dice_gt_ref], ["%.4f" % d for d in dice_gt_cal]))
+    _log("[%s] north_star tolerances, bf16 product vs FLOAT32 oracle: Dice deficit per class %s (bound 1e-3: %s); per-voxel logits "
+         "max abs err %.3e (bound 1e-4: NOT MET -- bf16 storage; the float32 / split-bf16 modes meet it, tests/test_gpu_parity.py)"
+         % (kind_tag, ["%.2e" % (1.0 - d) for d in dice], "MET" if min(dice) >= 1 - 1e-3 else "NOT MET", e_pred))
     m.compile(optimizer=_sgd(), loss=[U.pkg("loss").weighted_crossentropy])
     assert m.ctx.wgrad_plan is not None and len(m.ctx.wgrad_plan) > 10, "deferred batched filter gradients must be on"
     assert len(m.ctx.stats_sinks) > 5, "conv-epilogue statistics must be on"

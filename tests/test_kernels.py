@@ -101,6 +101,12 @@ CONV_CASES = [
     # count, a channel count that is not a multiple of its 128-channel groups, slab input and output
     dict(N=2, D=1, H=13, W=11, Cin=192, Cout=328, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=208, ldout=344, id="pw_bstat_k192_ragged"),
     dict(N=1, D=3, H=9, W=10, Cin=128, Cout=256, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="pw_bstat_k128_3d"),
+    # round 4: pointwise convs over relu(a * x + b) on the async-DMA kernels (the affine applied to the operand fragments in
+    # registers): a grid that takes the two-stage form (> 256 tiles of 128 rows, ragged M, slab input), a contraction wider than
+    # the small (1024-channel) LDS table with split-K, a 3D bottleneck (Cout 128 -> 128-wide tile) and a ragged channel count
+    dict(N=1, D=1, H=131, W=128, Cin=72, Cout=192, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=True, bias=False, ldin=96, ldout=None, id="pw_pro_two_stage"),
+    dict(N=1, D=1, H=7, W=9, Cin=1096, Cout=48, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=True, bias=False, ldin=1112, ldout=64, id="pw_pro_wide_table_splitk"),
+    dict(N=1, D=3, H=9, W=10, Cin=104, Cout=128, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=True, bias=True, ldin=None, ldout=None, id="pw_pro_3d_bn128"),
 ]
 
 
@@ -356,14 +362,19 @@ def test_conv_wgrad_batched_plan(hdu):
         dict(N=2, D=1, H=8, W=32, Cin=64, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=96, id="halo48"),
         dict(N=1, D=2, H=6, W=6, Cin=16, Cout=32, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="c333"),
     ]
-    cases = [c for c in CONV_CASES if not c["pro"] and not c["skip"]] + extra
+    # (round 4: pointwise layers WITH a BN prologue are batched too -- the affine is recomputed on the x fragments)
+    pointwise = lambda c: c["K"] == (1, 1, 1) and c["up"] == (0, 0, 0)
+    cases = [c for c in CONV_CASES if (not c["pro"] or pointwise(c)) and not c["skip"]] + extra
+    assert sum(1 for c in cases if c["pro"]) >= 4
     plan = ops.WgradPlan()
     items = []
     for i, cs in enumerate(cases):
         b = build_conv_case(ops, cs, BF16, seed=300 + 7 * i)
         N, Do, Ho, Wo, Cout = b["out_dims"]
         dya = mkact(ops, rnd((N, Do, Ho, Wo, Cout), 900 + i, 1.0, BF16), BF16, cs["ldout"], 8 if cs["ldout"] else 0)
-        d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"])
+        pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+        b["pro_dev"] = pro
+        d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"], None, pro, True)
         ref = torch.full(b["w"].shape, 0.25, dtype=torch.float32, device=ops.device())     # dw += ...
         got = ref.clone()
         ops.conv_wgrad(d, ref)
