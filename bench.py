@@ -225,6 +225,30 @@ def instrumented_step(m):
                 for i, nb in enumerate(rw[:n1 - n0]):
                     if nb is not None:
                         work[n0 + i] = (0.0, nb)
+    if os.environ.get("HDU_BENCH_TRACE"):
+        # developer view: the step as a launch-ordered list (kernel, us, entry point, shape), gpurun_out/step_trace_<tag>.json
+        owner = [None] * len(recs)
+        for name, args, n0, n1 in calls:
+            v = lambda x: getattr(x, "value", x)
+            shape = None
+            if name in ("hdu_conv_fprop", "hdu_conv_wgrad", "hdu_conv_dgrad_strided"):
+                d = args[0]._obj
+                shape = dict(M=d.N * d.Do * d.Ho * d.Wo, Cout=d.Cout, Cin=d.Cin, taps=d.KD * d.KH * d.KW, acc=d.accumulate)
+            elif name in ("hdu_materialize", "hdu_materialize_stats"):
+                shape = dict(M=v(args[3]) * v(args[4]) * v(args[5]) * v(args[6]), C=v(args[7]))
+            elif name in ("hdu_bn_bwd_fused", "hdu_bn_bwd_apply", "hdu_bn_bwd_reduce_coef"):
+                shape = dict(M=v(args[5]), C=v(args[6]))
+            elif name in ("hdu_bn_stats", "hdu_bn_stats_fold", "hdu_colsum", "hdu_affine_act"):
+                shape = dict(M=v(args[3]), C=v(args[4]))
+            for i in range(n0, n1):
+                owner[i] = (name, shape)
+        trace = [dict(k=kn, us=round(ms * 1e3, 2), api=(owner[i] or (None, None))[0], shape=(owner[i] or (None, None))[1])
+                 for i, (kn, ms) in enumerate(recs)]
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", "step_trace_%d.json" % len(DETAILS)), "w") as f:   # 0 = main workload, 1.. = extras
+                json.dump(trace, f)
+        except OSError:
+            pass
     agg = {}
     for (kname, ms), w in zip(recs, work):
         a = agg.setdefault(kname, [0, 0.0, 0.0, 0.0, True])

@@ -133,9 +133,9 @@ def test_graph_replay_equals_eager_steps(hip_lib, dtype, kind, variant, b, size,
     """what bench.py times is a REPLAYED hipGraph of the step; every parity test drives eager steps.
     Same model, same start state (weights, velocities, moving statistics, dropout counter): three eager steps, then the state
     is restored, the step is captured and replayed three times.  The two runs launch the same kernels on the same buffers, so
-    they differ only by the order of the float atomics (epilogue statistics, pixel-split filter gradients): the parameters
-    after three steps agree to that noise -- measured, and gated at 1e-5 (f32) / 2e-3 (bf16) of the accumulated update's norm
-    ... a captured launch with a stale pointer / argument (learning rate, seed, a buffer rebuilt after capture) is off by O(1)."""
+    they differ only by the order of the float atomics (epilogue statistics, pixel-split filter gradients).  That noise is
+    MEASURED in the test (the eager steps are run twice from the same state) and the replayed graph is held to it; a captured
+    launch with a stale pointer / argument (learning rate, seed, a buffer rebuilt after capture) is off by O(1) of the update."""
     ka = U.pkg("keras_api")
     if kind == "2d":
         m = U.pkg("denseunet").DenseUNet(reduction=0.5, args=U.make_args(b, size), dtype=dtype)
@@ -169,18 +169,25 @@ def test_graph_replay_equals_eager_steps(hip_lib, dtype, kind, variant, b, size,
     assert m._graph is None
     l_eager, p_eager = three_steps()
     restore()
+    l_again, p_again = three_steps()          # the SAME eager steps once more: the run-to-run noise of the float atomics
+    restore()
     m.capture_graph(warmup=0)
     assert m._graph is not None
     restore()                                 # (capture executes nothing, but be explicit)
     l_graph, p_graph = three_steps()
     upd = float((p_eager - state[0]).double().norm())
+    noise = float((p_again - p_eager).double().norm())
     diff = float((p_graph - p_eager).double().norm())
-    print("graph replay vs eager (%s %s/%s): losses %s vs %s; |P_graph - P_eager| = %.3e of |update| %.3e (%.2e relative)"
-          % (dtype, kind, variant, ["%.6f" % v for v in l_graph], ["%.6f" % v for v in l_eager], diff, upd, diff / upd))
+    print("graph replay vs eager (%s %s/%s): losses %s vs %s (eager again %s); |P_graph - P_eager| = %.3e, |P_eager' - P_eager| = %.3e, "
+          "|update| %.3e" % (dtype, kind, variant, ["%.6f" % v for v in l_graph], ["%.6f" % v for v in l_eager],
+                             ["%.6f" % v for v in l_again], diff, noise, upd))
     assert upd > 0 and np.isfinite(diff)
-    assert diff <= (1e-5 if dtype == "f32" else 2e-3) * upd, (diff, upd)
-    for a, g in zip(l_eager, l_graph):
-        assert abs(a - g) <= (1e-5 if dtype == "f32" else 2e-3) * abs(a), (l_eager, l_graph)
+    # a fresh random-init net amplifies roundoff by orders of magnitude per step (measured: two eager runs of the float32 net
+    # differ by 4e-4 of the update after three steps), so the bound is the eager-vs-eager distance itself: the replayed graph
+    # must not be further from an eager run than ~ another eager run is (factor 4 + a floor for the case of identical runs)
+    assert diff <= 4.0 * noise + 1e-6 * upd, (diff, noise, upd)
+    for a, g, a2 in zip(l_eager, l_graph, l_again):
+        assert abs(a - g) <= 4.0 * abs(a - a2) + (1e-5 if dtype == "f32" else 2e-3) * abs(a), (l_eager, l_graph, l_again)
     # and the replayed step is not a no-op: the three losses differ from each other
     assert len({round(v, 7) for v in l_graph}) == 3
 
