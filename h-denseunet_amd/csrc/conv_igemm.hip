@@ -2994,7 +2994,7 @@ extern "C" int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream) {
 // 8..10 halo-tile form <64|48|32>.
 extern "C" size_t hdu_wgrad_plan_entry_bytes(void) { return sizeof(WgradEntry); }
 
-extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, void* entry, int* variant,
+extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, int min_steps, void* entry, int* variant,
                                    uint32_t* nblocks) {
   if (!d || !dw || !entry || !variant || !nblocks) return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_fill: null pointer");
   ConvK k;
@@ -3011,11 +3011,32 @@ extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target
   } else {
     const int target = target_wgs > 0 ? target_wgs : (g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768);
     const int nct = wgrad_nct(k, best);
-    e->per = wgrad_dma_geometry(k, best, target, &e->k, 8, nct);   // batched: other layers fill the chip, fewer atomics win (swept)
+    e->per = wgrad_dma_geometry(k, best, target, &e->k, min_steps > 0 ? min_steps : 8, nct);   // batched: other layers fill the chip, fewer atomics win (swept)
     *variant = nct == 3 ? 6 : (nct == 2 ? 7 : bi * 2 + (wgrad_pointwise(k) ? 1 : 0));
   }
   e->dw = dw;
   *nblocks = wgrad_grid(e->k);
+  return 0;
+}
+
+extern "C" int hdu_wgrad_plan_shape(const hdu_conv_desc* d, int* variant, uint32_t* tiles, uint32_t* steps) {
+  if (!d || !variant || !tiles || !steps) return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_shape: null pointer");
+  ConvK k;
+  if (int e = fill_convk(d, &k, true)) return e;
+  if (d->dtype != HDU_BF16 || !wgrad_dma_ok(k) || k.M == 0)
+    return hdu_set_error(HDU_ERR_ARG, "wgrad_plan_shape: not a layer hdu_wgrad_plan_fill accepts");
+  const int best = choose_wgrad(k);
+  const int bi = best == 64 ? 0 : (best == 48 ? 1 : 2);
+  if (wgrad_halo_ok(k)) {
+    *variant = 8 + bi;
+    *tiles = (uint32_t)(k.Cin / 32) * (uint32_t)((k.Cout + best - 1) / best);
+    *steps = (uint32_t)(k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32));
+  } else {
+    const int nct = wgrad_nct(k, best);
+    *variant = nct == 3 ? 6 : (nct == 2 ? 7 : bi * 2 + (wgrad_pointwise(k) ? 1 : 0));
+    *tiles = (uint32_t)((k.Ktot + 127) / 128) * (uint32_t)((k.Cout + best * nct - 1) / (best * nct));
+    *steps = (uint32_t)((k.M + 63) / 64);
+  }
   return 0;
 }
 

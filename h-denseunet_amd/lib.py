@@ -135,7 +135,9 @@ _SIGS = {
     "hdu_materialize_stats": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_int, c_int, c_int, c_int,
                                       c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_wgrad_plan_entry_bytes": (c_sz, []),
-    "hdu_wgrad_plan_fill": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_int, c_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_uint32)]),
+    "hdu_wgrad_plan_fill": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_int, c_int, c_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_uint32)]),
+    "hdu_wgrad_plan_shape": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_uint32),
+                                     ctypes.POINTER(ctypes.c_uint32)]),
     "hdu_wgrad_plan_run": (c_int, [c_int, c_p, c_p, c_int, ctypes.c_uint32, c_p]),
     "hdu_bn_stats_finalize_fold_next": (c_int, [c_p, c_int, c_i64, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p,
                                                 c_p, c_p, c_p, c_p, c_p, c_f, c_p]),

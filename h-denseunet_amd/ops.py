@@ -159,40 +159,73 @@ class WgradPlan:
     """Deferred, batched filter gradients (hdu_wgrad_plan_*): add(desc, dw) for every layer at build time, run() once
     per backward pass.  One launch per kernel family; tables live in device memory (uploaded once).  (Launching the plan in
     groups on a second stream while the backward chain continues was measured slower in rounds 1 and 3:
-    profiles/r03_experiment_wgrad_side_stream_overlap.txt.)"""
+    profiles/r03_experiment_wgrad_side_stream_overlap.txt.)
 
-    def __init__(self, target_wgs=0):
+    Pixel splits are sized from the WHOLE launch (round 4): a workgroup ends with Cout x 128 float atomics on its partial
+    tile, and inside a batched launch the OTHER layers fill the GPU, so every workgroup of a DMA family takes the same number
+    of 64-pixel steps S = clamp(sum over the family layers of tiles x steps / LAUNCH_WGS, 8, 128) instead of the 8 a layer
+    launched alone would need.  Swept on MI355X (profiles/r04_experiment_wgrad_split_sizing.txt): 2D best at 64-128 steps
+    (18.1 -> 17.6 ms), end2end at 32-64, denseunet_3d (few small layers) at 8 -- all three fall out of LAUNCH_WGS = 512 (1024 and 2048 within 0.1 ms)."""
+
+    LAUNCH_WGS = 512
+
+    def __init__(self, target_wgs=0, min_steps=None):
         self.target = target_wgs
+        self.min_steps = min_steps        # None: sized per family as described above; an int forces it (tests / A-B runs)
+        self.layers = []                  # (descriptor, dw): descriptors (and the tensors they point to) must outlive the plan
         self.by_variant = {}
         self.descs = {}
+        self.steps_of = {}
         self.tables = None
-        self.keep = []            # descriptors (and the tensors they point to) must outlive the plan
 
     def add(self, d, dw):
-        lib = _l.get()
-        nb = lib.hdu_wgrad_plan_entry_bytes()
-        ent = (ctypes.c_ubyte * nb)()
-        variant, nblk = ctypes.c_int(0), ctypes.c_uint32(0)
-        check(lib.hdu_wgrad_plan_fill(ctypes.byref(d), fptr(dw), self.target, ctypes.cast(ent, ctypes.c_void_p),
-                                      ctypes.byref(variant), ctypes.byref(nblk)), "hdu_wgrad_plan_fill")
-        self.by_variant.setdefault(variant.value, []).append((bytes(ent), nblk.value))
-        self.descs.setdefault(variant.value, []).append(d)       # (bench.py: algorithmic FLOPs of a batched launch)
-        self.keep.append((d, dw))
+        self.layers.append((d, dw))
         self.tables = None
 
     def __len__(self):
-        return sum(len(v) for v in self.by_variant.values())
+        return len(self.layers)
 
     def finalize(self):
         import numpy as np
+        import os
+        lib = _l.get()
+        forced = os.environ.get("HDU_WGRAD_PLAN_STEPS")
+        shapes, work = [], {}
+        for d, dw in self.layers:
+            variant, tiles, steps = ctypes.c_int(0), ctypes.c_uint32(0), ctypes.c_uint32(0)
+            check(lib.hdu_wgrad_plan_shape(ctypes.byref(d), ctypes.byref(variant), ctypes.byref(tiles), ctypes.byref(steps)),
+                  "hdu_wgrad_plan_shape")
+            shapes.append(variant.value)
+            work[variant.value] = work.get(variant.value, 0) + tiles.value * steps.value
+        self.steps_of = {}
+        for v, w in work.items():
+            if v >= 8:
+                self.steps_of[v] = 0                      # halo families: spatial tiles, library default
+            elif forced:
+                self.steps_of[v] = int(forced)
+            elif self.min_steps is not None:
+                self.steps_of[v] = int(self.min_steps)
+            else:
+                wgs = int(os.environ.get("HDU_WGRAD_LAUNCH_WGS", self.LAUNCH_WGS))
+                self.steps_of[v] = max(8, min(128, (w + wgs - 1) // wgs))
+        nb = lib.hdu_wgrad_plan_entry_bytes()
+        self.by_variant, self.descs = {}, {}
+        for (d, dw), v in zip(self.layers, shapes):
+            ent = (ctypes.c_ubyte * nb)()
+            variant, nblk = ctypes.c_int(0), ctypes.c_uint32(0)
+            check(lib.hdu_wgrad_plan_fill(ctypes.byref(d), fptr(dw), self.target, self.steps_of[v], ctypes.cast(ent, ctypes.c_void_p),
+                                          ctypes.byref(variant), ctypes.byref(nblk)), "hdu_wgrad_plan_fill")
+            assert variant.value == v
+            self.by_variant.setdefault(v, []).append((bytes(ent), nblk.value))
+            self.descs.setdefault(v, []).append(d)       # (bench.py: algorithmic FLOPs of a batched launch)
         self.tables = []
         for variant, ents in sorted(self.by_variant.items()):
             raw = np.frombuffer(b"".join(e for e, _ in ents), dtype=np.uint8).copy()
             begins = np.zeros(len(ents), dtype=np.uint32)
             tot = 0
-            for i, (_, nb) in enumerate(ents):
+            for i, (_, nb_) in enumerate(ents):
                 begins[i] = tot
-                tot += nb
+                tot += nb_
             assert tot < 2 ** 31
             self.tables.append((variant, torch.from_numpy(raw).to(device()),
                                 torch.from_numpy(begins.view(np.int32)).to(device()), len(ents), tot))

@@ -44,7 +44,7 @@ const char* hdu_backend(void);
  * entry-point set.  A binding compares hdu_abi_version() and hdu_sizeof_conv_desc() with what it was written against and
  * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*,
  * 4 = round 3 (hdu_zero_regions, hdu_comm_*), 5 = round 4 (hdu_profile_*, pointwise convs with a fused BN prologue on the
- * DMA path). */
+ * DMA path, hdu_wgrad_plan_shape / min_steps). */
 #define HDU_ABI_VERSION 5
 int hdu_abi_version(void);
 size_t hdu_sizeof_conv_desc(void);
@@ -206,12 +206,19 @@ int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream);
  *   hdu_wgrad_plan_entry_bytes(): size of one opaque table entry.
  *   hdu_wgrad_plan_fill(): fills ONE host-side entry for (desc, dw) as hdu_conv_wgrad(desc, dw) would run it;
  *     *variant = kernel family of the entry (entries of one family go into one table), *nblocks = workgroups it needs.
- *     target_wgs <= 0: the single-launch default split.
+ *     target_wgs <= 0: the single-launch default split.  min_steps > 0 (DMA families): every workgroup keeps at least that
+ *     many 64-pixel steps -- the caller sizes it from the WHOLE launch (hdu_wgrad_plan_shape of every layer of the family):
+ *     a partial tile costs Cout x 128 float atomics, and in a batched launch the other layers fill the GPU, so a layer needs
+ *     far fewer pixel splits than it would alone (measured round 4: 8 -> ~100 steps, 2D step 18.1 -> 17.6 ms).
+ *   hdu_wgrad_plan_shape(): *variant as above, *tiles = output tiles of the layer (workgroups per pixel split), *steps = its
+ *     64-pixel steps (DMA families) / 4x32-pixel spatial tiles (halo families).
  *   hdu_wgrad_plan_run(): dev_entries = the entries of ONE family copied to device memory, dev_begins[i] = first
  *     workgroup of entry i (exclusive prefix sum of nblocks), total_blocks = their sum.  Same result as calling
  *     hdu_conv_wgrad per layer (dw += ..., float atomics). */
 size_t hdu_wgrad_plan_entry_bytes(void);
-int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, void* entry, int* variant, uint32_t* nblocks);
+int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target_wgs, int min_steps, void* entry, int* variant,
+                        uint32_t* nblocks);
+int hdu_wgrad_plan_shape(const hdu_conv_desc* d, int* variant, uint32_t* tiles, uint32_t* steps);
 int hdu_wgrad_plan_run(int variant, const void* dev_entries, const uint32_t* dev_begins, int n, uint32_t total_blocks,
                        void* stream);
 

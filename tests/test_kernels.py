@@ -380,6 +380,7 @@ def test_conv_wgrad_batched_plan(hdu):
         ops.conv_wgrad(d, ref)
         plan.add(d, got)
         items.append((cs["id"], ref, got, b, dya))
+    plan.finalize()
     assert len(plan) == len(cases) and len(plan.by_variant) >= 3      # several kernel families in one plan
     plan.run()
     for name, ref, got, _, _ in items:
