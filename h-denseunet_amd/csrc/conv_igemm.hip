@@ -1519,6 +1519,292 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 }
 
 // =====================================================================================
+// Persistent form of the implicit GEMM for LARGE grids (round 4).
+// The two-stage kernel above keeps ONE 28 KB operand stage in flight per workgroup and pays row decode, first-tile latency
+// and the epilogue per 128 x BN tile, hidden only by the second workgroup of the CU (measured round 2: the K loop is half of
+// a workgroup's life; 23 B/clk/CU of the ~50 the L2 -> LDS path delivers; MFMA busy 16 %).  Here ONE 512-thread workgroup
+// per CU owns the CU's LDS and walks a list of 256 x BN tiles:
+//   * a 3-slot ring of (256 + BN) x 128 B stages that runs ACROSS tile boundaries: while the last K steps of tile t are
+//     multiplied the first stages of tile t+1 are already in flight (row decode of t+1 included), two stages = ~90 KB in
+//     flight per CU, counted vmcnt + one raw barrier per K step;
+//   * 8 waves (2 per SIMD: one wave's MFMAs overlap the other's DMA issue / epilogue), each 32 rows x BN columns;
+//   * the epilogue leaves the LDS alone: a lane holds 4 consecutive output channels of one pixel (operands swapped in the
+//     MFMA), so bias / dropout / output affine / accumulate / the 8- or 16-byte store happen in registers, the statistics as
+//     DPP row sums + one atomic instruction per 16-column group -- no barrier, it overlaps the next tile's DMAs;
+//   * 256 rows per filter tile: 21 % fewer operand bytes per FLOP than 128 x 96.
+// MEASURED (MI355X, profiles/r04_experiment_persistent_gemm.txt): correct, and 10-20 % SLOWER per launch than the two-stage
+// kernel on every one of the 25 large-grid launches of the 2D step (2D 17.5 -> 17.9 ms with 8 lock-stepped waves, 17.7 with the
+// two waves of a SIMD in opposite phase order; a 4-wave form with 64 x BN outputs per wave: 22 ms).  Both forms move ~23 B/clk/CU
+// through the L2 -> LDS path whatever the pipeline depth: with ~0.65 KiB of LDS fragment reads per MFMA on top of the DMA
+// writes the LDS itself is ~60 % busy, and two independent 4-wave workgroups interleave their DMA / MFMA / epilogue phases
+// better than 8 waves behind one barrier per K step.  OFF by default (HDU_TUNE_PERS = 1 / HDU_PERS=1 turns it on); kept as a
+// tested, measured option.
+// m-tiles are dealt round-robin to the workgroups; a workgroup visits all n-tiles of an m-tile back to back (the A rows come
+// from its XCD's L2 the second time).  FAST addressing only (no up-sampling, <= 32 taps, tensor < 4 GiB), no fused BN
+// backward; the BN(+Scale)+ReLU operand prologue of a pointwise conv (PROC > 0) as in the kernels above.
+template <typename T, int BN, int PROC = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_pers_kernel(ConvK p, int tiles_m, int tiles_n) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int BK = 8 * CH;
+  constexpr int BM = 256, NS = 3;
+  constexpr int RP = NW * 8;                      // rows one pass of the workgroup's DMA instructions covers
+  constexpr int A_IT = BM / RP;
+  constexpr int B_IT = (BN + RP - 1) / RP;
+  constexpr int WM = BM / NW, TM = WM / 16, TN = BN / 16;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr bool PRO = PROC > 0;
+  static_assert(BN % 16 == 0 && NS * STAGE + 8 * PROC <= 160 * 1024, "tile / LDS");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 8 * PROC];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  if constexpr (PRO) {     // per-channel a / b of the whole contraction range: once per workgroup, older than every operand DMA
+    const hdu_bufsrd asrd = hdu_make_srd(p.pro_a, (unsigned)p.Cin * 4u);
+    const hdu_bufsrd bsrd = hdu_make_srd(p.pro_b, (unsigned)p.Cin * 4u);
+    const int nch = (p.Cin + 255) >> 8;
+    for (int q = wave; q < 2 * nch; q += NW) {
+      const bool isb = q >= nch;
+      const int cq = isb ? q - nch : q;
+      hdu_bufload_lds16(isb ? bsrd : asrd, (unsigned)(cq * 256 + lane * 4) * 4u, smem + NS * STAGE + (isb ? PROC * 4 : 0) + cq * 1024);
+    }
+  }
+  const float* pro_ta = (const float*)(smem + NS * STAGE);
+  const float* pro_tb = pro_ta + PROC;
+  const float pro_lo = p.pro_relu ? 0.f : -__builtin_huge_valf();
+  const int r0 = tid >> 3;                       // 0..RP-1: this lane stages rows r0 + RP * i
+  const int kcl = (tid & 7) ^ (r0 & 7);          // logical 16-byte chunk it fetches (lands at physical chunk tid & 7)
+  const T* __restrict__ xp = (const T*)p.x;
+  const T* __restrict__ wp = (const T*)p.w;
+  const hdu_bufsrd xsrd = hdu_make_srd(xp, p.x_bytes);
+  const hdu_bufsrd wsrd = hdu_make_srd(wp, p.w_bytes);
+  const bool pointwise = p.KD * p.KH * p.KW == 1 && p.sd == 1 && p.sh == 1 && p.sw == 1 && (p.pd | p.ph | p.pw) == 0;
+  const int nk = (p.Ktot + BK - 1) / BK;
+  // filter rows this wave's DMA instructions cover: instruction j holds rows j * RP + wave * 8 .. + 7 (wave-uniform count)
+  int nb_w = 0;
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) nb_w += (j * RP + wave * 8 < BN) ? 1 : 0;
+
+  // work items = (m-tile, n-tile) pairs.  Enough m-tiles for every workgroup: a workgroup takes m-tiles b, b + G, ... and
+  // visits all n-tiles of each back to back (the A rows come from its XCD's L2 the second time); fewer: the pairs are dealt
+  // round-robin.  `nitems` = pairs of this workgroup.
+  const int G = (int)gridDim.x, bx = (int)blockIdx.x;
+  const bool by_mtile = tiles_m >= G;
+  const int nitems = by_mtile ? ((tiles_m - bx + G - 1) / G) * tiles_n : (tiles_m * tiles_n - bx + G - 1) / G;
+  auto item_pos = [&](int it, int& mt, int& nt) {
+    if (it >= nitems) { mt = tiles_m; nt = 0; return; }       // past the list: nothing valid
+    if (by_mtile) {
+      const int q = it / tiles_n;
+      mt = bx + q * G;
+      nt = it - q * tiles_n;
+    } else {
+      const int w = bx + it * G;
+      mt = w / tiles_n;
+      nt = w - mt * tiles_n;
+    }
+  };
+  // ---- LOAD side: position (item, K step) of the next stage to request
+  int l_it = 0, l_mt, l_nt, l_kt = 0;
+  item_pos(0, l_mt, l_nt);
+  int rpix[A_IT];
+  unsigned rmask[A_IT];
+  int wrow[B_IT];
+  int k, c, kd, kh, kw, tap_i;
+  auto tile_state = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int rn, rid, rih, riw;
+      if (l_mt < tiles_m) {
+        hdu_row_state<true>(p, (unsigned)(l_mt * BM + r0 + i * RP), pointwise, rn, rid, rih, riw, rpix[i], rmask[i]);
+      } else {
+        rpix[i] = 0;
+        rmask[i] = 0u;
+      }
+    }
+  };
+  auto n_state = [&]() {
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int row = r0 + j * RP;
+      const int col = l_nt * BN + row;
+      wrow[j] = (row < BN && col < p.Cout && l_mt < tiles_m) ? col * p.Ktot : -1;
+    }
+  };
+  auto k_reset = [&]() {
+    k = kcl * CH;
+    hdu_k_state(p, k, c, kd, kh, kw, tap_i);
+  };
+  // every call issues exactly A_IT + nb_w DMA instructions per wave (a position past the tile list reads out of range =
+  // zeros into a slot nobody multiplies), so the counted waits below are uniform
+  auto issue = [&](int slot) {
+    char* As = smem + slot * STAGE;
+    char* Bs = As + BM * 128;
+    const bool kvalid = kd < p.KD;
+    const int toff = ((kd * p.He + kh) * p.We + kw) * (int)p.ldx + c;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool ok = kvalid && ((rmask[i] >> tap_i) & 1u);
+      hdu_bufload_lds16(xsrd, ok ? (unsigned)(rpix[i] + toff) * (unsigned)sizeof(T) : HDU_OOB, As + (i * RP + wave * 8) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      if (j * RP + wave * 8 < BN)       // wave-uniform
+        hdu_bufload_lds16(wsrd, (wrow[j] >= 0 && k < p.Ktot) ? (unsigned)(wrow[j] + k) * (unsigned)sizeof(T) : HDU_OOB,
+                          Bs + (j * RP + wave * 8) * 128);
+    }
+    // advance to the next stage's position
+    if (++l_kt == nk) {
+      l_kt = 0;
+      k_reset();
+      const int prev_mt = l_mt;
+      item_pos(++l_it, l_mt, l_nt);
+      if (l_mt != prev_mt) tile_state();
+      n_state();
+    } else {
+      k += BK;
+      c += BK;
+      while (c >= p.Cin) {
+        c -= p.Cin;
+        ++tap_i;
+        if (++kw == p.KW) {
+          kw = 0;
+          if (++kh == p.KH) {
+            kh = 0;
+            ++kd;
+          }
+        }
+      }
+    }
+  };
+  tile_state();
+  n_state();
+  k_reset();
+  issue(0);
+  issue(1);
+
+  // ---- COMPUTE side
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
+  T* __restrict__ yp = (T*)p.y;
+  int slot = 0;
+  for (int it = 0; it < nitems; ++it) {
+    int mt, nt;
+    item_pos(it, mt, nt);
+    {
+      f32x4 acc[TM][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kt = 0; kt < nk; ++kt) {
+        // stage `slot` has landed once at most ONE younger stage's DMAs of this wave are outstanding (epilogue stores share
+        // the counter and only make the wait more conservative: loads return in order among themselves)
+        if (nb_w == B_IT) hdu_wait_vmcnt_n<A_IT + B_IT>(); else hdu_wait_vmcnt_n<A_IT + B_IT - 1>();
+        HDU_RAW_BARRIER();                       // everyone's part has landed; everyone is done reading the slot refilled next
+        // the two waves of a SIMD (w, w + 4) take the step's two phases in OPPOSITE order, so that one requests the next
+        // stage while the other multiplies (in lock step both would queue on the memory pipe, then both on the MFMA pipe)
+        const bool issue_first = wave < 4 || (p.debug_flags & 64);
+        if (issue_first) issue(slot == 0 ? NS - 1 : slot - 1);    // slot (s + NS - 1) % NS
+        const char* As = smem + slot * STAGE;
+        const char* Bs = As + BM * 128;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+          u32x4 af[TM], bf[TN];
+          const int chunk = kg * 4 + (lane >> 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *(const u32x4*)(As + lds_chunk_off(wave * WM + i * 16 + (lane & 15), chunk));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = *(const u32x4*)(Bs + lds_chunk_off(j * 16 + (lane & 15), chunk));
+          if constexpr (PRO) {
+            const int cb = kt * BK + chunk * CH;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = pro_apply<T>(af[i], pro_ta + cb, pro_tb + cb, pro_lo);
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // swapped: lane = 4 channels of one pixel
+        }
+        if (!issue_first) issue(slot == 0 ? NS - 1 : slot - 1);
+        slot = slot == NS - 1 ? 0 : slot + 1;
+      }
+      // ---- epilogue in registers: C[m = lane & 15][n = 4 * (lane >> 4) + r] of each 16 x 16 fragment
+      const int n0 = nt * BN;
+      float* sdst = p.stats_partial ? p.stats_partial + (long long)((unsigned)mt % (unsigned)p.stats_slots) * 2 * p.Cout : nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + j * 16 + (lane >> 4) * 4;
+        const bool n_ok = n < p.Cout;                 // Cout is a multiple of the 16-byte chunk: 4 channels are all-or-nothing
+        const int nc = n_ok ? n : 0;
+        const f32x4 bias_v = has_bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 epa_v = has_epi ? *(const f32x4*)(p.epi_a + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 epb_v = has_epi ? *(const f32x4*)(p.epi_b + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 sh_v = sdst ? *(const f32x4*)(p.stats_shift + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const long long m = (long long)mt * BM + wave * WM + i * 16 + (lane & 15);
+          const bool ok = n_ok && m < p.M;
+          T* dst = yp + (ok ? m * p.ldy + n : 0);
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (has_bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bias_v[r];
+          }
+          if (drop) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(n + r), dseed);
+              v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+            }
+          }
+          if (has_epi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = epa_v[r] * v[r] + epb_v[r];
+              if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+          }
+          if (p.accumulate) {                       // unconditional load at a clamped address (see bnb_issue_loads)
+            float old[4];
+            Chunk<T>::load4(dst, old);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += old[r];
+          }
+          if (ok) Chunk<T>::store4(dst, v);
+          if (sdst) {                               // moments of the STORED values (what the consumers read)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float d = ok ? Chunk<T>::rounded(v[r]) - sh_v[r] : 0.f;
+              s1[r] += d;
+              s2[r] += d * d;
+            }
+          }
+        }
+        if (sdst) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[r] = hdu_row16_sum(s1[r]); s2[r] = hdu_row16_sum(s2[r]); }
+          // every lane of a 16-lane group holds the group's 8 totals: lane q of the group adds total q
+          const int q = lane & 15;
+          float mine = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            mine = q == r ? s1[r] : mine;
+            mine = q == 4 + r ? s2[r] : mine;
+          }
+          if (q < 8 && n_ok) atomicAdd(sdst + (q < 4 ? 0 : p.Cout) + n + (q & 3), mine);
+        }
+      }
+    }
+  }
+  HDU_WAIT_VMCNT(0);          // the two stages still in flight write LDS: they must land before the workgroup retires
+}
+
+// =====================================================================================
 // Pointwise GEMM with a SHORT contraction and a WIDE output -- filter-stationary streaming form.
 // The data gradient of every dense-block bottleneck (denseunet.py:245-248 / denseunet3d.py:34-37 backward):
 //   dx[M x c] = dt[M x 192] . W^T,  c = 96 .. 2160 channels, K = 192 (2D) / 128 (3D) = 3 / 2 steps of 64.
@@ -2451,10 +2737,10 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep
 // ------------------------------------------------------------------ host-side dispatch
 #include "hdu_host.h"
 
-int g_tuning[24] = {2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_tuning[32] = {2, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 extern "C" int hdu_set_tuning(int key, int value) {
-  if (key < 0 || key >= 24) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
+  if (key < 0 || key >= 32) return hdu_set_error(HDU_ERR_ARG, "set_tuning: bad key");
   g_tuning[key] = value;
   return 0;
 }
@@ -2736,10 +3022,57 @@ static void dispatch_igemm_bn(const ConvK& k, int bn, size_t skb, hipStream_t s)
   }
 }
 
+// persistent 256-row form (conv_igemm_pers_kernel): plain or pointwise-with-BN-prologue launches on FAST addressing whose
+// (m-tile, n-tile) list gives every one of the CU-resident workgroups at least `HDU_TUNE_PERS_MIN_ITEMS` / CUs tiles
+static int pers_table_cap(int bn, int cin) {                 // LDS table capacity for the prologue, -1 = does not fit
+  const int stage3 = 3 * (256 + bn) * 128;
+  if (cin <= HDU_PRO_CSMALL && stage3 + 8 * HDU_PRO_CSMALL <= 160 * 1024) return HDU_PRO_CSMALL;
+  if (stage3 + 8 * HDU_PRO_CMAX <= 160 * 1024) return HDU_PRO_CMAX;
+  return -1;
+}
+
+static bool igemm_pers_ok(const ConvK& k, int bn) {
+  if (g_tuning[HDU_TUNE_PERS] == 0) return false;
+  if (k.skip != nullptr || !k.vec_out || k.bnb_u != nullptr || !igemm_fast_ok(k)) return false;
+  if (k.pro_a != nullptr && (!igemm_pro_dma_ok(k) || pers_table_cap(bn, k.Cin) < 0)) return false;
+  const long long items = ((k.M_layer + 255) / 256) * ((k.Cout + bn - 1) / bn);
+  const int min_items = g_tuning[HDU_TUNE_PERS_MIN_ITEMS] > 0 ? g_tuning[HDU_TUNE_PERS_MIN_ITEMS] : 512;
+  return items >= min_items && k.M < (1ll << 31) - 256;
+}
+
+template <typename T, int BN>
+static void launch_pers(const ConvK& k, hipStream_t s) {
+  const int tiles_m = (int)((k.M + 255) / 256), tiles_n = (k.Cout + BN - 1) / BN;
+  const int cus = g_tuning[HDU_TUNE_PERS] > 1 ? g_tuning[HDU_TUNE_PERS] : 256;        // one workgroup per CU (MI355X: 256)
+  long long items = (long long)tiles_m * tiles_n;
+  const dim3 grid((unsigned)(items < cus ? items : cus));
+  if (k.pro_a != nullptr) {
+    const int cap = pers_table_cap(BN, k.Cin);
+    if (cap == HDU_PRO_CSMALL) {
+      if constexpr (3 * (256 + BN) * 128 + 8 * HDU_PRO_CSMALL <= 160 * 1024)
+        HDU_LAUNCH((conv_igemm_pers_kernel<T, BN, HDU_PRO_CSMALL>), grid, dim3(512), 0, s, k, tiles_m, tiles_n);
+    } else {
+      if constexpr (3 * (256 + BN) * 128 + 8 * HDU_PRO_CMAX <= 160 * 1024)
+        HDU_LAUNCH((conv_igemm_pers_kernel<T, BN, HDU_PRO_CMAX>), grid, dim3(512), 0, s, k, tiles_m, tiles_n);
+    }
+  } else {
+    HDU_LAUNCH((conv_igemm_pers_kernel<T, BN, 0>), grid, dim3(512), 0, s, k, tiles_m, tiles_n);
+  }
+}
+
 template <typename T>
 static void dispatch_igemm(const ConvK& k, size_t skb, hipStream_t s) {
   int bm, bn;
   choose_igemm(k, &bm, &bn);
+  if (bm == 128 && igemm_pers_ok(k, bn)) {
+    switch (bn) {
+      case 128: launch_pers<T, 128>(k, s); return;
+      case 96: launch_pers<T, 96>(k, s); return;
+      case 64: launch_pers<T, 64>(k, s); return;
+      case 48: launch_pers<T, 48>(k, s); return;
+      default: launch_pers<T, 32>(k, s); return;
+    }
+  }
   if (bm == 64) dispatch_igemm_bn<T, 64>(k, bn, skb, s);
   else dispatch_igemm_bn<T, 128>(k, bn, skb, s);
 }
@@ -2830,6 +3163,7 @@ extern "C" size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d) {
   if (k.M == 0 || pw_bstat_ok(k, d->dtype) || fprop_halo_ok(k, d->dtype) || (k.pro_a != nullptr && !igemm_pro_dma_ok(k)) || k.skip != nullptr) return 0;
   int bm, bn;
   choose_igemm(k, &bm, &bn);
+  if (bm == 128 && igemm_pers_ok(k, bn)) return 0;
   const long long nblk = ((k.M + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
   const long long nblk_layer = ((k.M_layer + bm - 1) / bm) * ((k.Cout + bn - 1) / bn);
   const int stage = (bm + ((bn + 31) / 32) * 32) * 128;
@@ -3178,6 +3512,10 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
   } else {
     int bm, bn;
     choose_igemm(k, &bm, &bn);
+    if (bm == 128 && igemm_pers_ok(k, bn)) {
+      snprintf(buf, buflen, "conv_igemm_pers_kernel<%s, %d, %d>", t, bn, k.pro_a ? pers_table_cap(bn, k.Cin) : 0);
+      return 0;
+    }
     const int wm = (bn >= 128) ? 2 : ((bm == 64 && (bn == 64 || bn == 32)) ? 2 : 4);
     const bool prodma = igemm_pro_dma_ok(k);
     const bool dma = prodma || (k.pro_a == nullptr && k.skip == nullptr && k.vec_out);

@@ -13,4 +13,4 @@ static inline unsigned hdu_grid_1d(long long work_items, int per_block, unsigned
   return (unsigned)b;
 }
 
-extern int g_tuning[24];   // hdu_set_tuning values (conv_igemm.hip)
+extern int g_tuning[32];   // hdu_set_tuning values (conv_igemm.hip)

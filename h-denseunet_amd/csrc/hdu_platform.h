@@ -114,6 +114,11 @@ template <> struct Chunk<float> {
   __device__ __forceinline__ static void store4(float* p, const float* v) {
     *(u32x4*)p = u32x4{hdu_f2u(v[0]), hdu_f2u(v[1]), hdu_f2u(v[2]), hdu_f2u(v[3])};
   }
+  __device__ __forceinline__ static void load4(const float* p, float* v) {
+    const u32x4 q = *(const u32x4*)p;
+    v[0] = hdu_u2f(q.x); v[1] = hdu_u2f(q.y); v[2] = hdu_u2f(q.z); v[3] = hdu_u2f(q.w);
+  }
+  __device__ __forceinline__ static float rounded(float v) { return v; }     // the value as stored
 };
 
 template <> struct Chunk<bf16_t> {
@@ -134,6 +139,11 @@ template <> struct Chunk<bf16_t> {
   __device__ __forceinline__ static void store4(bf16_t* p, const float* v) {
     *(u32x2*)p = u32x2{hdu_pack_bf16x2(v[0], v[1]), hdu_pack_bf16x2(v[2], v[3])};
   }
+  __device__ __forceinline__ static void load4(const bf16_t* p, float* v) {
+    const u32x2 q = *(const u32x2*)p;
+    v[0] = hdu_u2f(q.x << 16); v[1] = hdu_u2f(q.x & 0xffff0000u); v[2] = hdu_u2f(q.y << 16); v[3] = hdu_u2f(q.y & 0xffff0000u);
+  }
+  __device__ __forceinline__ static float rounded(float v) { return bf16_to_f32(hdu_f32_to_bf16_dev(v)); }   // the value as stored
 };
 
 // ---- MFMA wrappers: one "k-group" = 16 bytes of k per lane for A and B ----

@@ -257,6 +257,10 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(21, int(os.environ["HDU_WGRAD_NCT"]))
     if "HDU_NO_PRO_DMA" in os.environ:
         lib.hdu_set_tuning(22, int(os.environ["HDU_NO_PRO_DMA"]))
+    if "HDU_PERS" in os.environ:
+        lib.hdu_set_tuning(23, int(os.environ["HDU_PERS"]))
+    if "HDU_PERS_MIN_ITEMS" in os.environ:
+        lib.hdu_set_tuning(24, int(os.environ["HDU_PERS_MIN_ITEMS"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
         lib.hdu_set_tuning(1, int(os.environ["HDU_WGRAD_MIN_STEPS"]))
 

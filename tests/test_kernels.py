@@ -173,6 +173,87 @@ def test_conv_fprop(hdu, cs, dtype):
         ops.conv_fprop(d2)
 
 
+PERS_CASES = [c for c in CONV_CASES if c["up"] == (0, 0, 0) and not c["skip"] and c["K"][0] * c["K"][1] * c["K"][2] <= 32
+              and (not c["pro"] or c["K"] == (1, 1, 1))]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("wgs", [3, 256])
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in PERS_CASES])
+def test_conv_fprop_persistent_kernel(hdu, cs, dtype, wgs):
+    """conv_igemm_pers_kernel (round 4: one 512-thread workgroup per CU, 256-row tiles, a 3-slot operand ring that runs across
+    tile boundaries, register epilogue) forced onto every eligible CONV_CASE -- with 3 workgroups every workgroup walks
+    several (m-tile, n-tile) items, with 256 most get at most one -- against the float64 reference: plain, accumulate,
+    bias, output affine, dropout mask consistency, epilogue statistics."""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    b = build_conv_case(ops, cs, dtype)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    if cs["ldout"]:
+        big = ops.Act.alloc(N, Do, Ho, Wo, cs["ldout"], dtype, zero=True)
+        big.buf.fill_(3.0)
+        ya = big.slab(8, Cout)
+    else:
+        big, ya = None, ops.Act.alloc(N, Do, Ho, Wo, Cout, dtype)
+    pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+    bias = dev(ops, b["bias"]) if b["bias"] is not None else None
+    wp = ctypes.c_void_p(b["wt"].data_ptr())
+    d = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, pro, True, bias)
+    xe = ref_xeff(b["x"], cs["up"], None, b["pro"], True, dtype)
+    ref = ref_conv(xe, b["w"], cs["s"], cs["p"], b["bias"])
+    M = N * Do * Ho * Wo
+    try:
+        lib.hdu_set_tuning(24, 1)          # HDU_TUNE_PERS_MIN_ITEMS: every layer qualifies
+        lib.hdu_set_tuning(18, 1)          # HDU_TUNE_BM64_MAX_M: no 64-row tiles (the persistent form replaces the 128-row ones)
+        lib.hdu_set_tuning(23, wgs)        # HDU_TUNE_PERS: workgroups
+        if ops.conv_kernel_name(d, 0).startswith("conv_pw_bstat") or ops.conv_kernel_name(d, 0).startswith("conv_halo"):
+            pytest.skip("taken by a specialised kernel")
+        assert ops.conv_kernel_name(d, 0).startswith("conv_igemm_pers_kernel"), ops.conv_kernel_name(d, 0)
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), ref, dtype, what="fprop")
+        if big is not None:
+            full = big.to_torch().cpu()
+            assert float((full[..., :8] - 3.0).abs().max()) == 0.0 and float((full[..., 8 + Cout:] - 3.0).abs().max()) == 0.0
+        d.accumulate = 1
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), q(ref, dtype) * 2, dtype, scale=2 * float(ref.abs().max()), what="fprop accumulate")
+        ea, eb = rnd((Cout,), 31, 1.0).float().double() + 1.5, rnd((Cout,), 32, 0.5).float().double()
+        ea_d, eb_d = dev(ops, ea), dev(ops, eb)
+        d2 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, pro, True, bias, epi=(ea_d, eb_d, True))
+        ops.conv_fprop(d2)
+        r2 = (ref * ea + eb).clamp_min(0)
+        assert_close(ya.to_torch().cpu(), r2, dtype, scale=float(r2.abs().max()), what="fprop + output affine")
+        # epilogue statistics: sums of (y - shift), (y - shift)^2 of the STORED values over all pixels, spread over the slot rows
+        slots = 8
+        shift = rnd((Cout,), 33, 0.3).float()
+        shift_d = shift.to(ops.device())
+        part = torch.zeros(slots * 2 * Cout, dtype=torch.float32, device=ops.device())
+        d3 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, pro, True, bias)
+        d3.stats_partial, d3.stats_shift, d3.stats_slots = part.data_ptr(), shift_d.data_ptr(), slots
+        ops.conv_fprop(d3)
+        y = ya.to_torch().cpu().double().reshape(M, Cout)
+        got = part.cpu().double().reshape(slots, 2, Cout).sum(0)
+        dd = y - shift.double()
+        scale1 = float(dd.abs().sum(0).max()) + 1e-9
+        assert float((got[0] - dd.sum(0)).abs().max()) <= 1e-4 * scale1
+        assert float((got[1] - (dd * dd).sum(0)).abs().max()) <= 1e-4 * float((dd * dd).sum(0).max())
+        # dropout: the same mask as the tiled kernels draw (stateless hash of the element index)
+        seed_dev = torch.zeros(1, dtype=torch.int32, device=ops.device())
+        d4 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, pro, True, bias, False, 0.7, 1234, seed_dev)
+        ops.conv_fprop(d4)
+        got_drop = ya.to_torch().cpu().double()
+        lib.hdu_set_tuning(23, 0)
+        ops.conv_fprop(d4)
+        assert_close(got_drop, ya.to_torch().cpu().double(), dtype, scale=float(ref.abs().max()) / 0.7, what="dropout mask vs the tiled kernel")
+        kept = (got_drop != 0).double().mean()
+        assert 0.55 < float(kept) < 0.85
+    finally:
+        lib.hdu_set_tuning(24, 0)
+        lib.hdu_set_tuning(18, 0)
+        lib.hdu_set_tuning(23, 0)          # (off by default: measured slower than the two-stage kernel)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES
                                 if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "stem7x7s2")])
