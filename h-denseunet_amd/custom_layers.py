@@ -1,7 +1,12 @@
 """Drop-in for lib/custom_layers.py: `Scale` (out = in*gamma + beta per channel, lib/custom_layers.py:10-74).
-In this framework Scale never runs as its own kernel: it is folded with the preceding BatchNormalization into one
-per-channel affine applied inside the consumer conv's operand gather (engine.BNLayer).  The class keeps the
-reference's constructor signature and records the two Keras weights [gamma, beta]."""
+
+A `Scale` never runs as a kernel of its own here: the network builders (models.py) create one per reference Scale layer and
+hand it to the BatchNormalization it follows (engine.BNLayer(scale=...)), which owns the two Keras weights [gamma, beta] under
+the Scale's layer name and folds them with its own into ONE per-channel affine a = sg*g*rstd, b = sg*(beta - mean*g*rstd) + sb
+applied by the consumer (conv operand path / materialise pass); the backward produces d(gamma), d(beta) of the Scale from the
+same two sums as the BatchNormalization's (csrc/rowops.hip: bn_coef_channel).  This class is that descriptor: the reference's
+constructor signature, the layer name and the `trainable` flag (frozen in `denseunet_3d`, trainable elsewhere).
+`call` is the plain numpy statement of the layer, used by the tests as the definition of what the folded affine must equal."""
 import numpy as np
 
 
@@ -12,6 +17,7 @@ class Scale:
         self.initial_weights = weights
         self.name = kwargs.get("name")
         self.trainable = kwargs.get("trainable", True)
+        self.gamma = self.beta = None        # engine.Param objects once a BNLayer has adopted the layer
 
     def build(self, input_shape):
         c = int(input_shape[self.axis])
@@ -23,7 +29,7 @@ class Scale:
     def call(self, x):
         shape = [1] * x.ndim
         shape[self.axis] = -1
-        return x * self.gamma.reshape(shape) + self.beta.reshape(shape)
+        return x * np.asarray(self.gamma).reshape(shape) + np.asarray(self.beta).reshape(shape)
 
     def get_config(self):
         return {"momentum": self.momentum, "axis": self.axis}

@@ -561,7 +561,12 @@ class BNLayer:
     BSUM_SLOTS = int(os.environ.get("HDU_BSUM_SLOTS", "16"))      # slot rows the backward reduction spreads its float atomics over (workgroup % slots; <= 32)
 
     def __init__(self, ctx, name, C, eps=1e-3, momentum=0.99, mode="batch", trainable=True, scale_name=None,
-                 scale_trainable=True, relu=True):
+                 scale_trainable=True, relu=True, scale=None):
+        """scale: the custom_layers.Scale that follows this BatchNormalization in the reference graph (its name and trainable
+        flag are taken from it; scale_name / scale_trainable are the same two facts given directly)"""
+        if scale is not None:
+            scale_name, scale_trainable = scale.name, scale.trainable
+        self.scale_layer = scale
         self.ctx, self.name, self.C, self.eps, self.momentum, self.mode, self.relu = ctx, name, C, eps, momentum, mode, relu
         self.trainable = trainable
         self.gamma = ctx.add_param(name, "bn", 0, (C,), (C,), trainable, "ones")
@@ -573,6 +578,8 @@ class BNLayer:
         if scale_name:
             self.sg = ctx.add_param(scale_name, "scale", 0, (C,), (C,), scale_trainable, "ones")
             self.sb = ctx.add_param(scale_name, "scale", 1, (C,), (C,), scale_trainable, "zeros")
+            if scale is not None:
+                scale.gamma, scale.beta = self.sg, self.sb
         v = ctx.fvec
         self.a, self.b, self.rstd = v(C), v(C), v(C)
         self.s1, self.s2, self.k1, self.k2, self.k3 = v(C), v(C), v(C), v(C), v(C)

@@ -9,6 +9,7 @@ Layer names, weight shapes and the trainable / BN-mode matrix follow the referen
 import torch
 
 from . import ops
+from .custom_layers import Scale
 from .engine import AvgPoolLayer, BNLayer, ConvLayer, MaterializeLayer, MaxPoolLayer, StatsOp, Var
 
 EPS_DENSE = 1.1e-5
@@ -43,7 +44,7 @@ def build_dense_unet_2d(ctx, x_in, variant="denseunet", reduction=0.5, nb_layers
     assert a.D == 1 and H % 32 == 0 and W % 32 == 0, "H and W must be multiples of 32 (five stride-2 stages)"
 
     def bn_dense(name, C):
-        return BNLayer(ctx, name + "_bn", C, EPS_DENSE, 0.99, mode, tr_bn, name + "_scale", tr_scale)
+        return BNLayer(ctx, name + "_bn", C, EPS_DENSE, 0.99, mode, tr_bn, scale=Scale(axis=3, name=name + "_scale", trainable=tr_scale))
 
     nb_filter = 96
     conv1 = ConvLayer(ctx, "conv1", x_in, nb_filter, (1, 7, 7), (1, 2, 2), (0, 3, 3), use_bias=False,
@@ -147,7 +148,7 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     conv1 = ConvLayer(ctx, "3dconv1", x_in, nb_filter, (7, 7, 7), (2, 2, 2), (3, 3, 3), use_bias=False, keras_nd=3,
                       cin_logical=4, halo=3 if sharded else 0)
     st = StatsOp(ctx, conv1.out)
-    bn1 = BNLayer(ctx, "3dconv1_bn", nb_filter, EPS_DENSE, 0.99, "batch", True, "3dconv1_scale", True)
+    bn1 = BNLayer(ctx, "3dconv1_bn", nb_filter, EPS_DENSE, 0.99, "batch", True, scale=Scale(axis=4, name="3dconv1_scale"))
     st.fuse(bn1)
     z0 = MaterializeLayer(ctx, conv1.out, bn1, halo=hl).out
     d0 = conv1.out.act.D
@@ -162,12 +163,12 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
         c = c0
         for i in range(nlayers):
             base = "3dconv%d_%d" % (stage, i + 1)
-            bn_a = BNLayer(ctx, base + "_x1_bn", c, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x1_scale", True)
+            bn_a = BNLayer(ctx, base + "_x1_bn", c, EPS_DENSE, 0.99, blk_mode, blk_tr, scale=Scale(axis=4, name=base + "_x1_scale"))
             if seg_stats[0] is not None:
                 seg_stats[0].then_fold(bn_a)
             c1 = ConvLayer(ctx, base + "_x1", buf.slab(0, c), growth * 4, (1, 1, 1), bn=bn_a, use_bias=False, keras_nd=3)
             st = _stats(ctx, c1.out, blk_mode)
-            bn_b = BNLayer(ctx, base + "_x2_bn", growth * 4, EPS_DENSE, 0.99, blk_mode, blk_tr, base + "_x2_scale", True)
+            bn_b = BNLayer(ctx, base + "_x2_bn", growth * 4, EPS_DENSE, 0.99, blk_mode, blk_tr, scale=Scale(axis=4, name=base + "_x2_scale"))
             _fuse(st, bn_b)
             ConvLayer(ctx, base + "_x2", c1.out, growth, (3, 3, 3), pad=(1, 1, 1), bn=bn_b, use_bias=False,
                       out=buf.slab(c, growth), keras_nd=3, halo=hl, producer=c1)
@@ -180,7 +181,7 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
         stage = bi + 2
         nb_filter = dense_block(stage, nb_layers[bi], buf, nb_filter)
         base = "3dconv%d_blk" % stage
-        bn_t = BNLayer(ctx, base + "_bn", nb_filter, EPS_DENSE, 0.99, blk_mode, True, base + "_scale", True)
+        bn_t = BNLayer(ctx, base + "_bn", nb_filter, EPS_DENSE, 0.99, blk_mode, True, scale=Scale(axis=4, name=base + "_scale"))
         if seg_stats[0] is not None:
             seg_stats[0].then_fold(bn_t)
         seg_stats[0] = None
@@ -200,7 +201,7 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
         for i in range(nb_layers[-1]):
             StatsOp(ctx, buf.slab(c0_last + i * growth, growth))
     bn5 = BNLayer(ctx, "3dconv%d_blk_bn" % final_stage, nb_filter, EPS_DENSE, 0.99, "batch", True,
-                  "3dconv%d_blk_scale" % final_stage, True)
+                  scale=Scale(axis=4, name="3dconv%d_blk_scale" % final_stage))
     if seg_stats[0] is not None:
         seg_stats[0].then_fold(bn5)
     ups = [(0, 1, 1), (0, 1, 1), (0, 1, 1), (1, 1, 1), (1, 1, 1)]   # reference (2,2,1)x3 then (2,2,2)x2 over (H,W,D)
