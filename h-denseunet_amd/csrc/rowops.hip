@@ -1761,6 +1761,24 @@ __global__ __launch_bounds__(256) void cast_out_kernel(const T* __restrict__ src
   }
 }
 
+// score[m][j] += softmax(logits[m][0..2])[j], j < num: the per-window step of the z-sliding-window inference
+// (lib/funcs.py:31-34: K.softmax + K.eval + `score[...] += result`), one thread per voxel, logits read once
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_accumulate_kernel(const T* __restrict__ logits, long long ldl, long long M, int num,
+                                                                 float* __restrict__ score) {
+  for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+    const T* r = logits + m * ldl;
+    const float z0 = Chunk<T>::load1(r), z1 = Chunk<T>::load1(r + 1), z2 = Chunk<T>::load1(r + 2);
+    const float mx = fmaxf(z0, fmaxf(z1, z2));
+    const float e0 = expf(z0 - mx), e1 = expf(z1 - mx), e2 = expf(z2 - mx);
+    const float inv = 1.0f / (e0 + e1 + e2);
+    float* o = score + m * num;
+    o[0] += e0 * inv;
+    if (num > 1) o[1] += e1 * inv;
+    if (num > 2) o[2] += e2 * inv;
+  }
+}
+
 #define HDU_T_LAUNCH(T, kern, n, ...) \
   HDU_LAUNCH((kern<T>), dim3(hdu_grid_1d((n), 256, 4096)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 #define HDU_CHECK_DTYPE(what) \
@@ -1803,6 +1821,15 @@ extern "C" int hdu_cast_out(int dtype, const void* src, int64_t ldsrc, int64_t M
   if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, cast_out_kernel, M * C, (const bf16_t*)src, (long long)ldsrc, (long long)M, C, dst); }
   else { HDU_T_LAUNCH(float, cast_out_kernel, M * C, (const float*)src, (long long)ldsrc, (long long)M, C, dst); }
   return hdu_check_launch("cast_out");
+}
+
+extern "C" int hdu_softmax_accumulate(int dtype, const void* logits, int64_t ldl, int64_t M, int num, float* score, void* stream) {
+  if (!logits || !score || ldl < 3 || num < 1 || num > 3 || M < 0) return hdu_set_error(HDU_ERR_ARG, "softmax_accumulate: bad args (3 classes, num in 1..3)");
+  if (dtype != HDU_BF16 && dtype != HDU_F32) return hdu_set_error(HDU_ERR_ARG, "softmax_accumulate: bad dtype");
+  if (M == 0) return 0;
+  if (dtype == HDU_BF16) { HDU_T_LAUNCH(bf16_t, softmax_accumulate_kernel, M, (const bf16_t*)logits, (long long)ldl, (long long)M, num, score); }
+  else { HDU_T_LAUNCH(float, softmax_accumulate_kernel, M, (const float*)logits, (long long)ldl, (long long)M, num, score); }
+  return hdu_check_launch("softmax_accumulate");
 }
 
 // ------------------------------------------------------------------ per-step re-initialisation (include/hdu.h)

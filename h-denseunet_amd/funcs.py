@@ -5,8 +5,8 @@
    lib/funcs.py:31-32);
  * each window is copied device-to-device into the model's input buffer and run with Model.predict's launch list
    (learning_phase 0).
-The 3-class softmax and the accumulation are a handful of torch element-wise ops on the logits (post-processing, not
-part of the per-voxel network path)."""
+The 3-class softmax and the `score +=` of a window are ONE launch (hdu_softmax_accumulate) straight off the logits; how many
+windows cover a slice (`score_num`) is a function of the window starts alone and is counted on the host."""
 import numpy as np
 import torch
 
@@ -27,8 +27,11 @@ def predict_tumor_inwindow(model, imgs_test, num, mini, maxi, args):
     dev = model.ctx.dev
     # depth-major resident copy of the cropped volume: [z][deps][rows]
     vol = torch.as_tensor(np.ascontiguousarray(np.asarray(imgs_test[:img_deps, :img_rows, :], np.float32).transpose(2, 0, 1))).to(dev)
+    if not 1 <= num <= 3:
+        raise ValueError("num: 1..3 of the 3 class scores (test.py passes 3)")
     score = torch.zeros((z, img_deps, img_rows, num), dtype=torch.float32, device=dev)
-    score_num = torch.zeros((z, 1, 1, 1), dtype=torch.float32, device=dev)
+    score_num = np.zeros((z, 1, 1, 1), np.float32)
+    plane = img_deps * img_rows
     ctx = model.ctx
     a = model.logits.act
     for cols in range(left_cols, right_cols + window_cols, window_cols):
@@ -40,13 +43,12 @@ def predict_tumor_inwindow(model, imgs_test, num, mini, maxi, args):
             ctx.run_forward()
         finally:
             ctx.learning_phase = 1
-        ops.cast_out(a, 3, model.out_stage)
-        prob = torch.softmax(model.out_stage.reshape(img_cols, img_deps, img_rows, 3), dim=-1)
-        score[c0 + 1:c0 + img_cols - 1] += prob[1:-1, :, :, :num]   # first / last slice of each window dropped (:33)
+        # first / last slice of each window dropped (lib/funcs.py:33): planes 1 .. img_cols-2 of the logits onto planes c0+1 ..
+        ops.softmax_accumulate(a, plane, (img_cols - 2) * plane, num, score[c0 + 1:c0 + img_cols - 1].reshape(-1))
         score_num[c0 + 1:c0 + img_cols - 1] += 1
-    score = score / (score_num + 1e-4)
+    score = score.cpu().numpy() / (score_num + np.float32(1e-4))        # lib/funcs.py:36
     out = np.zeros((x, y, z, num), np.float32)
-    out[:img_deps, :img_rows] = score.permute(1, 2, 0, 3).cpu().numpy()
+    out[:img_deps, :img_rows] = score.transpose(1, 2, 0, 3)
     return out[:, :, :, num - 2], out[:, :, :, num - 1]
 
 

@@ -161,6 +161,7 @@ _SIGS = {
     "hdu_make_input3d_bwd": (c_int, [c_int, c_p, c_int, c_f, c_i64, c_p, c_i64, c_int, c_int, c_p]),
     "hdu_cast_pad": (c_int, [c_int, c_p, c_i64, c_int, c_p, c_i64, c_int, c_p]),
     "hdu_cast_out": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
+    "hdu_softmax_accumulate": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
     "hdu_zero_regions": (c_int, [c_p, c_int, c_u32, c_p, c_u32, c_p]),
     "hdu_zero": (c_int, [c_p, ctypes.c_uint64, c_p]),
     "hdu_profile_begin": (c_int, [c_int]),

@@ -609,3 +609,12 @@ def cast_pad(src_f32, M, C, dst):
 
 def cast_out(src, C, dst_f32):
     check(_l.get().hdu_cast_out(src.dtype, src.ptr, src.ld, src.M, C, fptr(dst_f32), stream()), "hdu_cast_out")
+
+
+def softmax_accumulate(logits, row0, M, num, score):
+    """score[m][j] += softmax(logits[row0 + m][0:3])[j], j < num (include/hdu.h: hdu_softmax_accumulate); score: float32 view [M*num]"""
+    esz = logits.buf.element_size()
+    lp = ctypes.c_void_p(logits.buf.data_ptr() + (logits.off + row0 * logits.ld) * esz)
+    assert score.dtype == torch.float32 and score.is_contiguous() and score.numel() == M * num
+    check(_l.get().hdu_softmax_accumulate(logits.dtype, lp, logits.ld, M, num, ctypes.c_void_p(score.data_ptr()), stream()),
+          "hdu_softmax_accumulate")

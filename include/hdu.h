@@ -469,6 +469,11 @@ int hdu_make_input3d_bwd(int dtype, const void* dinput3d, int Cpad, float scale,
 int hdu_cast_pad(int dtype, const float* src, int64_t M, int C, void* dst, int64_t lddst, int Cpad, void* stream);
 int hdu_cast_out(int dtype, const void* src, int64_t ldsrc, int64_t M, int C, float* dst, void* stream);
 
+/* z-sliding-window inference, per window (lib/funcs.py:31-34: `result = K.softmax(result); score[...] += K.eval(result)`):
+ * score[m][j] += softmax(logits[m][0..2])[j] for j < num (num = 3 in test.py), logits [M][ldl] in the compute dtype (3 classes
+ * in the first channels), score float32 [M][num].  One pass over the logits; nothing leaves the device. */
+int hdu_softmax_accumulate(int dtype, const void* logits, int64_t ldl, int64_t M, int num, float* score, void* stream);
+
 /* ------------------------------------------------------------------ per-step re-initialisation
  * The accumulators a training step adds into (epilogue statistics, fused BN-backward slot rows, the flat gradient buffer the
  * filter-gradient kernels atomically accumulate into, slab gradient buffers whose first writer covers only some channels,

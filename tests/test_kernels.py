@@ -1136,3 +1136,21 @@ def test_bn_bwd_finalize_batched(hdu):
                 assert float((b - 7.0).abs().max()) == 0.0       # the per-layer call left an unwanted output alone too
             else:
                 assert torch.equal(a.cpu(), b.cpu()), i
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("num", [3, 2])
+def test_softmax_accumulate(hdu, dtype, num):
+    """hdu_softmax_accumulate (lib/funcs.py:31-34): score += softmax(logits)[:, :num], logits padded to the 16-byte chunk and
+    taken from a row offset inside the tensor"""
+    ops = ops_mod()
+    M, Cp = 1000, 8 if dtype == BF16 else 4
+    lg = q(rnd((1, 1, 1, M + 7, Cp), 5, 3.0, dtype), dtype)
+    la = mkact(ops, lg, dtype)
+    score0 = rnd((M, num), 6, 1.0).float()
+    score = score0.clone().to(ops.device()).reshape(-1)
+    ops.softmax_accumulate(la, 7, M, num, score)
+    ref = score0.double() + torch.softmax(lg.reshape(-1, Cp)[7:, :3].double(), -1)[:, :num]
+    assert float((score.cpu().double().reshape(M, num) - ref).abs().max()) < 2e-6
+    with pytest.raises(hdu.lib.HduError):
+        ops.softmax_accumulate(la, 0, M, 4, torch.zeros(M * 4, device=ops.device()))
