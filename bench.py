@@ -460,6 +460,7 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
         "step_conv_tflops": round(gflop / ms, 2),
         "step_frac_of_mfma_peak": round(gflop / ms / PEAK_TFLOPS[dtype], 4),
     }
+    rec["parallelism"] = ("depth-shard%d" if config == "shard3d" else "dp%d") % world
     if torch.cuda.is_available():
         rec["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2.0 ** 30, 2)
     # the instrumented step is rank-0-only and must not enter a collective: the depth-sharded step always does
@@ -487,7 +488,7 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
 def compact(rec):
     """what the ONE JSON line carries per extra workload (the driver keeps 8 KB of stdout: the whole metric must fit)"""
     out = {k: rec[k] for k in ("workload", "value", "unit", "ms_per_step", "steps", "dtype", "hipgraph", "global_batch_slices",
-                               "step_frac_of_mfma_peak", "peak_hbm_gib") if k in rec}
+                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism") if k in rec}
     out["workload"] = rec["workload"][:120]
     if "roofline" in rec:
         r = rec["roofline"]
@@ -563,51 +564,90 @@ def main():
             extra_recs.append(run_workload(cfg, dt, e_b, e_size, e_cols, e_steps, e_warm, rank, world, not a.no_graph,
                                            not a.no_roofline))
 
-    out = {
-        "metric": "CT slices/sec fwd+bwd (%s)" % ("2D 512^2" if a.config == "2d" else
-                                                   ("3D %dx%dx%d depth-sharded" % (size, size, cols) if a.config == "shard3d"
-                                                    else "3D 224x224x12")),
-        "value": main_rec["value"], "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True,
-        "scaling": "strong" if a.config == "shard3d" else "weak", "vs_baseline": None,
-        "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on" + (" -- CPU DRY RUN, not a measurement" if DRYRUN else ""),
-        "config": {"workload": main_rec["workload"], "global_batch_slices": main_rec["global_batch_slices"],
-                   "parallelism": ("depth-shard%d" if a.config == "shard3d" else "dp%d") % world,
-                   "hipgraph": main_rec["hipgraph"], "loss": main_rec["loss"],
-                   "step_conv_tflops": main_rec["step_conv_tflops"],
-                   "step_frac_of_mfma_peak": main_rec["step_frac_of_mfma_peak"]},
-    }
-    if "peak_hbm_gib" in main_rec:
-        out["config"]["peak_hbm_gib"] = main_rec["peak_hbm_gib"]
-    if rank == 0:
-        if "roofline" in main_rec:
-            out["roofline"] = main_rec["roofline"]
-            out["config"]["top_kernels"] = main_rec.get("top_kernels")
-            out["config"]["launches_per_step"] = main_rec.get("launches_per_step")
-        if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
-            out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
-            for r in extra_recs:
-                if r["workload"].startswith("denseunet_3d"):      # the 3D half beside its own CPU baseline
-                    r["cpu_baseline"] = cpu_baseline("3dpart", 224, 12, samples=1)
-        if extra_recs:
-            out["config"]["extra_workloads"] = [compact(r) for r in extra_recs]
-        line = json.dumps(out)
-        if len(line) > 6000:            # the driver keeps 8 KB of stdout: never let the line outgrow it
-            for e in out["config"].get("extra_workloads", []):
-                e.pop("cpu_baseline", None)
-            line = json.dumps(out)
-        # full per-kernel tables and uncompacted records: scratch file (copied to profiles/ for the judged runs) + stderr
-        detail = {"main": main_rec, "extras": extra_recs, "conv_kernels": DETAILS}
-        try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "w") as f:
-                json.dump(detail, f, indent=1)
-        except OSError:
-            pass
-        if os.environ.get("HDU_BENCH_VERBOSE"):
-            print(json.dumps(detail), file=sys.stderr)
-        print(line)
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    emitted = [False]
+
+    def emit():
+        """rank 0 prints THE line (once)"""
+        if emitted[0]:
+            return
+        emitted[0] = True
+        out = {
+            "metric": "CT slices/sec fwd+bwd (%s)" % ("2D 512^2" if a.config == "2d" else
+                                                       ("3D %dx%dx%d depth-sharded" % (size, size, cols) if a.config == "shard3d"
+                                                        else "3D 224x224x12")),
+            "value": main_rec["value"], "unit": "slices/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": main_rec["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong" if a.config == "shard3d" else "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic CT phantom (seeded), random-init weights, dropout on" + (" -- CPU DRY RUN, not a measurement" if DRYRUN else ""),
+            "config": {"workload": main_rec["workload"], "global_batch_slices": main_rec["global_batch_slices"],
+                       "parallelism": ("depth-shard%d" if a.config == "shard3d" else "dp%d") % world,
+                       "hipgraph": main_rec["hipgraph"], "loss": main_rec["loss"],
+                       "step_conv_tflops": main_rec["step_conv_tflops"],
+                       "step_frac_of_mfma_peak": main_rec["step_frac_of_mfma_peak"]},
+        }
+        if "peak_hbm_gib" in main_rec:
+            out["config"]["peak_hbm_gib"] = main_rec["peak_hbm_gib"]
+        if dist_on:     # one process per GPU over RCCL (torch.distributed backend "nccl" IS RCCL on ROCm)
+            out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                                            "data_plane": os.environ.get("HDU_COMM", "torch.distributed")}
+        if rank == 0:
+            if "roofline" in main_rec:
+                out["roofline"] = main_rec["roofline"]
+                out["config"]["top_kernels"] = main_rec.get("top_kernels")
+                out["config"]["launches_per_step"] = main_rec.get("launches_per_step")
+            if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
+                out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
+                for r in extra_recs:
+                    if r["workload"].startswith("denseunet_3d"):      # the 3D half beside its own CPU baseline
+                        r["cpu_baseline"] = cpu_baseline("3dpart", 224, 12, samples=1)
+            if extra_recs:
+                out["config"]["extra_workloads"] = [compact(r) for r in extra_recs]
+            line = json.dumps(out)
+            if len(line) > 6000:            # the driver keeps 8 KB of stdout: never let the line outgrow it
+                for e in out["config"].get("extra_workloads", []):
+                    e.pop("cpu_baseline", None)
+                line = json.dumps(out)
+            # full per-kernel tables and uncompacted records: scratch file (copied to profiles/ for the judged runs) + stderr
+            detail = {"main": main_rec, "extras": extra_recs, "conv_kernels": DETAILS}
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "w") as f:
+                    json.dump(detail, f, indent=1)
+            except OSError:
+                pass
+            if os.environ.get("HDU_BENCH_VERBOSE"):
+                print(json.dumps(detail), file=sys.stderr)
+            print(line)
+
+    # Depth sharding under N > 1 (BASELINE configs[4]: ONE 512 x 512 x 512 volume over the ranks, strong scaling) rides along
+    # with the data-parallel line when the driver launches `bench.py --gpus N`.  It is the one workload whose step contains
+    # neighbour exchanges, and this path has only ever run multi-rank over gloo (tests/test_depth_shard_gloo.py): a watchdog
+    # bounds it, so that a stuck collective costs this extra record, never the line.
+    s3 = os.environ.get("HDU_BENCH_SHARD3D", "1")             # "0" = never, "force" = also outside the default run (tests)
+    s3_size, s3_cols = (32, 8 * world) if DRYRUN else (512, 512)
+    if (world > 1 and a.config == "2d" and s3_cols % (4 * world) == 0 and
+            (s3 == "force" or (s3 == "1" and a.extras is None and not DRYRUN and a.dtype == "bf16"))):
+        import threading
+        limit = float(os.environ.get("HDU_BENCH_SHARD3D_TIMEOUT", "240"))
+
+        def expire():
+            extra_recs.append({"workload": WORKLOAD_TEXT["shard3d"] % dict(b=1, size=s3_size, cols=s3_cols // world, gcols=s3_cols, world=world),
+                               "error": "no result within %g s (watchdog): the depth-sharded step did not complete" % limit})
+            try:
+                emit()
+                sys.stdout.flush()
+            finally:
+                os._exit(0)
+        wd = threading.Timer(limit, expire)
+        wd.daemon = True
+        wd.start()
+        try:
+            extra_recs.append(run_workload("shard3d", a.dtype, 1, s3_size, s3_cols, max(2, min(a.steps, 10)), 1, rank, world, False, False))
+        except Exception as e:      # noqa: BLE001 -- whatever it is, the data-parallel line must still be printed
+            extra_recs.append({"workload": "shard3d 512x512x512 over %d ranks" % world, "error": ("%s: %s" % (type(e).__name__, e))[:300]})
+        wd.cancel()
+    emit()
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

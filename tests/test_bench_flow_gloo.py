@@ -49,3 +49,39 @@ def test_bench_world2_shard3d_control_flow(emu_lib):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["value"] > 0
     assert rec["config"]["global_batch_slices"] == 16 and "roofline" not in rec
+
+
+def _run_guarded(port, timeout_s):
+    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2", HDU_BENCH_SHARD3D="force",
+               HDU_BENCH_SHARD3D_TIMEOUT=timeout_s)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--batch", "1", "--size", "32", "--dtype", "f32", "--extras", "none", "--no-roofline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, lines
+
+
+def test_bench_world2_guarded_shard3d_extra(emu_lib):
+    """under N > 1 the default bench also times ONE volume depth-sharded over the ranks (BASELINE configs[4], strong scaling)
+    behind a watchdog: the record rides in the data-parallel line ..."""
+    out, lines = _run_guarded("29551", "600")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    ex = rec["config"]["extra_workloads"]
+    assert rec["config"]["parallelism"] == "dp2" and len(ex) == 1 and ex[0]["parallelism"] == "depth-shard2"
+    assert ex[0]["value"] > 0 and ex[0]["global_batch_slices"] == 16 and "error" not in ex[0]
+    assert rec["config"]["collectives"]["ranks"] == 2
+
+
+def test_bench_world2_guarded_shard3d_watchdog(emu_lib):
+    """... and a depth-sharded step that does not complete in time (here: a watchdog of 10 ms) costs that record only: rank 0
+    still prints the ONE line with the data-parallel result and every process exits cleanly"""
+    out, lines = _run_guarded("29553", "0.01")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["value"] > 0 and rec["n_gpus"] == 2
+    ex = rec["config"]["extra_workloads"]
+    assert len(ex) == 1 and "watchdog" in ex[0]["error"]
