@@ -65,3 +65,9 @@ class Comm:
         if self._h:
             _l.get().hdu_comm_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown: the library may already be gone
+            pass

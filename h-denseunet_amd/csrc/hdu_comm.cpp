@@ -9,7 +9,9 @@
 #include "hdu_host.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #ifndef HDU_EMU
 #include <dlfcn.h>
@@ -32,20 +34,24 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-static RcclApi* rccl_api() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.handle ? &api : nullptr;
-  tried = true;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names) {
-    // RTLD_NOLOAD first: reuse the copy the process already mapped (PyTorch's), then fall back to loading one
-    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
-    if (api.handle) break;
+static void rccl_bind(RcclApi& api) {
+  // 1. the symbols a process already holds (PyTorch-ROCm maps its own, possibly renamed, librccl with global visibility):
+  //    RTLD_DEFAULT finds them whatever the file is called, and no second copy of the library enters the process
+  bool from_process = dlsym(RTLD_DEFAULT, "ncclCommInitRank") != nullptr;
+  void* h = RTLD_DEFAULT;
+  if (!from_process) {
+    // 2. an explicit library (HDU_RCCL_LIB), then the usual names: already-mapped copies first (RTLD_NOLOAD), then a load
+    const char* env = getenv("HDU_RCCL_LIB");
+    const char* names[] = {env ? env : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    h = nullptr;
+    for (const char* n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+      if (h) break;
+    }
+    for (size_t i = 0; !h && i < sizeof(names) / sizeof(names[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
   }
-  for (size_t i = 0; !api.handle && i < sizeof(names) / sizeof(names[0]); ++i) api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-  if (!api.handle) return nullptr;
-#define HDU_SYM(field, name) *(void**)(&api.field) = dlsym(api.handle, name)
+#define HDU_SYM(field, name) *(void**)(&api.field) = dlsym(h, name)
   HDU_SYM(GetUniqueId, "ncclGetUniqueId");
   HDU_SYM(CommInitRank, "ncclCommInitRank");
   HDU_SYM(CommDestroy, "ncclCommDestroy");
@@ -58,11 +64,17 @@ static RcclApi* rccl_api() {
 #undef HDU_SYM
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.Send || !api.Recv || !api.GroupStart ||
       !api.GroupEnd) {
-    dlclose(api.handle);
-    api.handle = nullptr;
-    return nullptr;
+    if (!from_process) dlclose(h);
+    return;
   }
-  return &api;
+  api.handle = from_process ? (void*)&api : h;        // non-null = bound
+}
+
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;                          // (two threads binding at the same time)
+  std::call_once(once, [] { rccl_bind(api); });
+  return api.handle ? &api : nullptr;
 }
 
 struct hdu_comm {
@@ -90,6 +102,13 @@ extern "C" int hdu_comm_init(hdu_comm** out, int rank, int world, const void* id
   RcclApi* a = rccl_api();
   if (!a) return hdu_set_error(HDU_ERR_ARG, "comm: librccl could not be loaded");
   if (!out || !id128 || world <= 0 || rank < 0 || rank >= world) return hdu_set_error(HDU_ERR_ARG, "comm_init: bad args");
+  // the communicator binds to the CALLING thread's current HIP device (one process per GPU: the caller has selected it,
+  // e.g. torch.cuda.set_device(LOCAL_RANK)); a process that has no usable device is refused here rather than inside RCCL
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+    (void)hipGetLastError();
+    return hdu_set_error(HDU_ERR_ARG, "comm_init: no current HIP device (select the rank's GPU before creating the communicator)");
+  }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   hdu_comm* c = new hdu_comm{nullptr, rank, world};
