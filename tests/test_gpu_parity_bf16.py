@@ -262,6 +262,11 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols,
                                       float(np.median(cal_coss)), float(ratios.mean()), float(cal_ratios.mean()),
                                       coef, cal_coef, worst[0], worst[1], worst[4]))
 
+    # the tensors furthest beyond their own calibration draw (which layers are they, run after run?)
+    ranked = sorted(zip(rows, cal_rows), key=lambda rc: -(rc[0][1] / max(rc[0][4], REL_FLOOR)))[:8]
+    _log("[%s] furthest beyond their calibration draw: %s" % (kind_tag, "; ".join(
+        "%s[%d] rel %.3f (noise %.3f) cos %s (oracle-bf16 %s)" % (r[0][0], r[0][1], r[1], r[4], "%.4f" % r[2] if r[2] is not None else "-",
+                                                                 "%.4f" % c[2] if c[2] is not None else "-") for r, c in ranked)))
     # ---- DIRECT comparison with the bf16-storage oracle: that run rounds where the product rounds, so
     # the product should sit much closer to it than either sits to the float32 oracle.  Independent errors of the size of
     # the storage noise would put the product at sqrt(2) x noise from it; a shared rounding pattern puts it well inside.
