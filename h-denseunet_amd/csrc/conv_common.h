@@ -139,9 +139,9 @@ __device__ __forceinline__ unsigned xcd_tile_index(unsigned bid, unsigned nblk) 
 }
 
 // Filter-gradient work grid -> this workgroup (1-D launch): k-column tiles x filter-row tiles x pixel splits, pixel split
-// slowest.  (An XCD-grouped order -- all tiles of one pixel split on one XCD -- cuts the fabric traffic 4x and was
-// measured SLOWER both per layer in round 1 and in the batched launches in round 2, profiles/r02_experiment_wgrad_plan_
-// sweep_2d.txt: these kernels are bound by DMA issue latency and atomics, not bytes.  Removed.)
+// slowest.  (Rounds 1-2 measured an XCD-grouped order SLOWER -- with 8-step workgroups the launches were bound by their float
+// atomics.  Round 4 sized the pixel splits from the whole launch (64-128 steps per workgroup), after which the bodies DO gain
+// from the grouped order: they pass xcd_tile_index(bid) here.)
 __device__ __forceinline__ bool wgrad_block(const ConvK& p, unsigned bid, unsigned* bx, unsigned* by, unsigned* bz) {
   const unsigned per = (unsigned)(p.wg_gx * p.wg_gy);
   *bz = bid / per;

@@ -1964,6 +1964,9 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
   const bool ups = (p.ud | p.uh | p.uw) != 0;
 
   unsigned wbx, wby, wbz;
+  // (XCD-major order: the k-column workgroups of one pixel split share its dy tile in one XCD's L2 -- see wgrad_halo_body;
+  // HDU_TUNE_DEBUG bit 8 restores the round-robin order)
+  if (!(p.debug_flags & 256)) bid = xcd_tile_index(bid, (unsigned)(p.wg_gx * p.wg_gy * p.wg_gz));
   if (!wgrad_block(p, bid, &wbx, &wby, &wbz)) return;
   const int kcol0 = (int)wbx * BKC;
   const int co0 = (int)wby * BCO * NCT;
@@ -2174,10 +2177,11 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
 #else
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-  const T* __restrict__ xp = (const T*)p.x;
-  const T* __restrict__ dyp = (const T*)p.y;
-  const char* zero = (const char*)hdu_zero_page;
   unsigned wbx, wby, wbz;
+  // the channel-chunk workgroups of ONE pixel split share its dy (and neighbouring x) lines: XCD-major order puts them on one
+  // XCD's L2 (round 4, PMC: 10 % L2 hits and 6.8 GB of fabric traffic for ~1 GB of operands with the round-robin order;
+  // profiles/r04_experiment_wgrad_xcd_order.txt).  HDU_TUNE_DEBUG bit 7 restores the round-robin order (A/B).
+  if (!(p.debug_flags & 128)) bid = xcd_tile_index(bid, (unsigned)(p.wg_gx * p.wg_gy * p.wg_gz));
   if (!wgrad_block(p, bid, &wbx, &wby, &wbz)) return;
   const int c0 = (int)wbx * 32;
   const int co0 = (int)wby * BCO;
@@ -2188,45 +2192,102 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
   int t_end = t_begin + tiles_per_split;
   if (t_end > ntiles) t_end = ntiles;
 
-  // dy tile lane roles (as in conv_wgrad_dma_kernel): physical chunk tid&7 of tile pixels (tid>>3)+32*j
+  // Round 4: this kernel was bound by ADDRESS ARITHMETIC, not by MFMAs or bytes (ISA of round 3: 440 VALU + 500 SALU per
+  // 4 x 32-pixel tile and wave against 60 MFMAs -- three runtime divisions for the tile position, 64-bit addresses with a
+  // zero-page select for each of the 8 DMAs, the swizzled LDS address of each of the 64 transposing reads recomputed per
+  // tile).  Everything that depends on the lane only is now computed ONCE: operands arrive through buffer resources (a lane
+  // adds its fixed element offset to the tile's base, out-of-range = zeros: hdu_platform.h), the tile position advances
+  // incrementally, and the lane's 64 LDS read addresses are kept as 16-bit offsets, two per register.
+  const hdu_bufsrd xsrd = hdu_make_srd(p.x, p.x_bytes);
+  const hdu_bufsrd dsrd = hdu_make_srd(p.y, (unsigned)((((long long)p.M - 1) * p.ldy + p.Cout) * 2));     // (host: < 4 GiB)
+  // x halo tile: instruction jj = j * 4 + wave covers halo pixels jj * 16 .. + 15, 4 lanes (16-byte chunks) per pixel
+  int xhr[4], xhc[4], xoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jj = j * 4 + wave;
+    const int hp = jj * 16 + (lane >> 2);
+    const int pc = lane & 3;                             // physical 16-byte chunk inside the pixel's 64 B
+    const int lc = ((((pc >> 1) ^ ((hp >> 3) & 1)) << 1) | (pc & 1));
+    const int hr = hp / HC, hc = hp - hr * HC;
+    const bool st = jj < HPP / 16 && hp < HP && c0 + lc * 8 < p.Cin;
+    xhr[j] = st ? hr : (1 << 20);                        // (a row far outside every image: never valid)
+    xhc[j] = hc;
+    xoff[j] = (hr * W + hc) * (int)p.ldx + c0 + lc * 8;  // element offset from the tile's (y0 - 1, x0 - 1) pixel
+  }
+  // dy tile: lane owns physical chunk (tid & 7) of tile pixels (tid >> 3) + 32 j = (row j, column tid >> 3)
   const int dpx0 = tid >> 3;
   const int gd = ((dpx0 >> 1) & 1) | (((dpx0 >> 3) & 1) << 1);
   const int dp16 = tid & 7;
   const int dcl = ((((dp16 >> 1) ^ gd) << 1) | (dp16 & 1));
   const bool dvalid = dcl * 8 < BCO && co0 + dcl * 8 < p.Cout;
+  const int doff0 = dpx0 * (int)p.ldy + co0 + dcl * 8;   // + j * W * ldy for tile row j
 
-  auto issue_tile = [&](int buf, int t) {
+  // load-side tile position, advanced incrementally
+  int l_tx, l_ty, l_n;
+  {
+    const int r = t_begin / tiles_x;
+    l_tx = t_begin - r * tiles_x;
+    l_n = r / tiles_y;
+    l_ty = r - l_n * tiles_y;
+  }
+  auto issue_tile = [&](int buf) {
     char* Xh = smem + buf * STAGE;
     char* Dt = Xh + XBYTES;
-    const int txi = t % tiles_x;
-    const int r = t / tiles_x;
-    const int tyi = r % tiles_y;
-    const int n = r / tiles_y;
-    const int y0 = tyi * TH, x0 = txi * TW;
-    // input halo tile: instruction jj covers halo pixels jj*16 .. jj*16+15 (4 x 16-byte chunks each)
+    const int y0 = l_ty * TH, x0 = l_tx * TW;
+    const int xbase = ((l_n * H + y0 - 1) * W + x0 - 1) * (int)p.ldx;       // may be negative; valid pixels give >= 0 sums
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int jj = j * 4 + wave;
       if (jj < HPP / 16) {                                  // wave-uniform
-        const int hp = jj * 16 + (lane >> 2);
-        const int pc = lane & 3;                           // physical 16-byte chunk inside the pixel's 64 B
-        const int lc = ((((pc >> 1) ^ ((hp >> 3) & 1)) << 1) | (pc & 1));
-        const int hr = hp / HC, hc = hp - hr * HC;
-        const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
-        const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const char* g = ok ? (const char*)(xp + ((long long)(n * H + iy) * W + ix) * p.ldx + c0 + lc * 8) : zero;
-        hdu_glds16(g, Xh + jj * 1024);
+        const bool ok = (unsigned)(y0 - 1 + xhr[j]) < (unsigned)H && (unsigned)(x0 - 1 + xhc[j]) < (unsigned)W;
+        hdu_bufload_lds16(xsrd, ok ? (unsigned)(xbase + xoff[j]) * 2u : HDU_OOB, Xh + jj * 1024);
       }
     }
+    const int dbase = ((l_n * H + y0) * W + x0) * (int)p.ldy;
+    const bool colok = dvalid && x0 + dpx0 < W;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int tp = dpx0 + j * 32;                        // tile pixel = ty*32 + tx
-      const int oy = y0 + (tp >> 5), ox = x0 + (tp & 31);
-      const bool ok = dvalid && oy < H && ox < W;
-      const char* g = ok ? (const char*)(dyp + ((long long)(n * H + oy) * W + ox) * p.ldy + co0 + dcl * 8) : zero;
-      hdu_glds16(g, Dt + (j * 32 + wave * 8) * DROWB);
+      const bool ok = colok && y0 + j < H;
+      hdu_bufload_lds16(dsrd, ok ? (unsigned)(dbase + j * W * (int)p.ldy + doff0) * 2u : HDU_OOB, Dt + (j * 32 + wave * 8) * DROWB);
+    }
+    if (++l_tx == tiles_x) {
+      l_tx = 0;
+      if (++l_ty == tiles_y) {
+        l_ty = 0;
+        ++l_n;
+      }
     }
   };
+
+  // ---- the lane's LDS read addresses (tile-invariant), relative to the stage base
+  const int li = lane & 15, lg = lane >> 4, q4 = li >> 2;
+  // dy fragment i, k-group kg, half h: pixel row kg * 32 + lg * 8 + q4 + 4 h; tr_off<128>'s swizzle bits depend on the lane only
+  int dbase_i[TMc];
+  {
+    const int swz = ((q4 >> 1) & 1) | ((lg & 1) << 1);
+#pragma unroll
+    for (int i = 0; i < TMc; ++i) dbase_i[i] = XBYTES + (lg * 8 + q4) * DROWB + ((i ^ swz) << 5) + (li & 3) * 8;
+  }
+  // x fragment of combo (tap, ct), k-group kg, half h: halo pixel (kg + kh) * HC + kw + 4 h + lg * 8 + q4; its swizzle bit is
+  // bit 3 of that ABSOLUTE pixel index, so the offsets are enumerated once: [q][kg][h] as 16-bit halves, two per register
+  unsigned xadr[NQ][TH];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    // (waves 2 and 3 have no fifth combo: they multiply combo `wave` once more into an accumulator set nobody stores -- a
+    // branch-free k loop lets every transposing read of a k-group be requested before its first MFMA; with the wave-uniform
+    // `if (combo < 18)` of round 3 each pair of reads was followed by a full LDS round trip)
+    const int combo = wave + 4 * q < 18 ? wave + 4 * q : wave;
+    const int tap = combo >> 1, ct = combo & 1;
+    const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+    for (int kg = 0; kg < TH; ++kg) {
+      const int hp = (kg + kh) * HC + lg * 8 + q4 + kw;
+      const int hp2 = hp + 4;
+      const unsigned lo = (unsigned)(hp * 64 + ((ct ^ ((hp >> 3) & 1)) << 5) + (li & 3) * 8);
+      const unsigned hi = (unsigned)(hp2 * 64 + ((ct ^ ((hp2 >> 3) & 1)) << 5) + (li & 3) * 8);
+      xadr[q][kg] = lo | (hi << 16);                     // both < XBYTES = 13312
+    }
+  }
 
   f32x4 acc[NQ][TMc];
 #pragma unroll
@@ -2234,41 +2295,35 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
 #pragma unroll
     for (int i = 0; i < TMc; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (t_begin < t_end) issue_tile(0, t_begin);
+  if (t_begin < t_end) issue_tile(0);
   __syncthreads();
-  const int li = lane & 15, lg = lane >> 4;
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = (t - t_begin) & 1;
-    if (t + 1 < t_end) issue_tile(buf ^ 1, t + 1);
+    if (t + 1 < t_end) issue_tile(buf ^ 1);
     {
-      const char* Xh = smem + buf * STAGE;
-      const char* Dt = Xh + XBYTES;
+      const char* St = smem + buf * STAGE;
 #pragma unroll
       for (int kg = 0; kg < TH; ++kg) {                    // k-group = tile row kg: 32 pixels
         u32x4 af[TMc];
-        const int prow = kg * 32 + lg * 8 + (li >> 2);
 #pragma unroll
         for (int i = 0; i < TMc; ++i) {
-          const int bc = (i * 16 + (li & 3) * 4) * 2;
-          const u32x2 lo = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow, bc));
-          const u32x2 hi = hdu_lds_tr16_b64(Dt + tr_off<DROWB>(prow + 4, bc));
+          const char* a0 = St + dbase_i[i] + kg * 32 * DROWB;
+          const u32x2 lo = hdu_lds_tr16_b64(a0);
+          const u32x2 hi = hdu_lds_tr16_b64(a0 + 4 * DROWB);
           af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
         }
+        u32x4 bf[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const int combo = wave + 4 * q;
-          if (combo < 18) {                                // wave-uniform
-            const int tap = combo >> 1, ct = combo & 1;
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int hp = (kg + kh) * HC + lg * 8 + (li >> 2) + kw;
-            const int hp2 = hp + 4;
-            const u32x2 lo = hdu_lds_tr16_b64(Xh + hp * 64 + ((ct ^ ((hp >> 3) & 1)) << 5) + (li & 3) * 8);
-            const u32x2 hi = hdu_lds_tr16_b64(Xh + hp2 * 64 + ((ct ^ ((hp2 >> 3) & 1)) << 5) + (li & 3) * 8);
-            const u32x4 bf = u32x4{lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-            for (int i = 0; i < TMc; ++i) acc[q][i] = Mma<T>::kgroup(af[i], bf, acc[q][i]);
-          }
+          const unsigned pr = xadr[q][kg];
+          const u32x2 lo = hdu_lds_tr16_b64(St + (pr & 0xffffu));
+          const u32x2 hi = hdu_lds_tr16_b64(St + (pr >> 16));
+          bf[q] = u32x4{lo.x, lo.y, hi.x, hi.y};
         }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int i = 0; i < TMc; ++i) acc[q][i] = Mma<T>::kgroup(af[i], bf[q], acc[q][i]);
       }
     }
     __syncthreads();
@@ -3265,7 +3320,10 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
 static bool wgrad_halo_ok(const ConvK& k) {
   return !g_tuning[HDU_TUNE_NO_HALO] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 && k.KH == 3 && k.KW == 3 &&
          k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 && (k.ud | k.uh | k.uw) == 0 &&
-         k.Di == 1 && k.Cin % 32 == 0 && k.We >= 32;
+         k.Di == 1 && k.Cin % 32 == 0 && k.We >= 32 &&
+         // operands through buffer resources with 32-bit byte offsets (tensors of 4 GiB and more take the im2col form)
+         k.x_bytes != 0 && (((long long)k.M - 1) * k.ldy + k.Cout) * 2 < (1ll << 32) &&
+         (long long)k.N * k.He * k.We * k.ldx < (1ll << 31) - (long long)(k.We + 2) * k.ldx;
 }
 
 // work grid of the halo-tile filter gradient: 32-channel chunks x filter-row tiles x splits of the spatial tiles
