@@ -1816,7 +1816,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_pers_kernel(ConvK p, int t
 // lines.  Waves: 2 (pixels) x 2 (channels), 32 x 64 outputs each -- a wave's staging rows are whole cache lines, so the
 // epilogue needs no workgroup barrier.  Traffic per output element: the activation tile once per 128 channels, the filter
 // once per workgroup.
-template <int KS, int BN>
+// BNB (round 4): the launch is the data gradient of a bottleneck whose INPUT went through BN(+Scale)+ReLU (ConvK::bnb_*): the
+// staged dz patch is turned into a * g (g = dz masked by the forward ReLU, recomputed from the BN input u) and stored / added
+// straight onto the gradient slab, and S1 = sum g, S2 = sum g * uhat accumulate in registers over ALL tiles of the workgroup (a
+// lane owns the same 8 channels for the whole launch) -- one set of float atomics per wave at the end.  The u / old-gradient
+// chunks of a tile are requested before its MFMAs (and before the next operand tile's DMAs, so that the counted waits hold).
+// This is the streaming form of epilogue_bn_backward: the dz round trip and the separate reduction + apply passes over the
+// O(L^2)-wide slab go (14 -> 6 bytes per element); the reduction-dependent part of du follows later as -k3 * u + k4
+// (hdu_bn_bwd_finalize / hdu_bn_bwd_correct).
+template <int KS, int BN, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_per_wg) {
   typedef bf16_t T;
   constexpr int CH = 8, BM = 64, NSA = 3;
@@ -1877,12 +1885,48 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
     if (pre < ntiles) issue_tile(pre);
 
   T* __restrict__ yp = (T*)p.y;
+  // ---- BNB: this lane's 8 output channels are the same for every tile: coefficients once, S1 / S2 in registers
+  constexpr int NCCE = WN / CH;                        // 16-byte chunks per row of a wave's patch (8)
+  constexpr int EIT = WM * NCCE / 64;                  // chunks per lane and tile (4)
+  const int ecc = lane % NCCE;
+  const int en = n0 + wn * WN + ecc * CH;
+  const bool en_ok = en < p.Cout;
+  float ba[CH], bb[CH], bmu[CH], brs[CH], bs1[CH], bs2[CH];
+  const bool bsums = BNB && p.bnb_partial != nullptr;
+  if constexpr (BNB) {
+    const int nc = en_ok ? en : 0;
+    const float* pmu = bsums ? p.bnb_mean : p.bnb_a;
+    const float* prs = bsums ? p.bnb_rstd : p.bnb_a;
+#pragma unroll
+    for (int j = 0; j < CH; j += 4) {
+      const f32x4 va = *(const f32x4*)(p.bnb_a + nc + j), vb = *(const f32x4*)(p.bnb_b + nc + j);
+      const f32x4 vm = *(const f32x4*)(pmu + nc + j), vr = *(const f32x4*)(prs + nc + j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ba[j + r] = va[r]; bb[j + r] = vb[r]; bmu[j + r] = bsums ? vm[r] : 0.f; brs[j + r] = bsums ? vr[r] : 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { bs1[j] = 0.f; bs2[j] = 0.f; }
+  }
+  const T* __restrict__ bup = (const T*)p.bnb_u;
   for (int t = 0; t < ntiles; ++t) {
     // tile t (and, the first time, the filter rows: older than every tile) has landed once at most the DMAs of ONE
     // younger tile are outstanding.  The epilogue's global stores share the counter: they only make the wait more
     // conservative (the bound below holds whether or not stores retire in order with the loads).
     if (t + 1 < ntiles) hdu_wait_vmcnt_n<LA>(); else hdu_wait_vmcnt_n<0>();
     HDU_RAW_BARRIER();
+    u32x4 euv[BNB ? EIT : 1], eov[BNB ? EIT : 1];
+    if constexpr (BNB) {      // unconditional loads at clamped addresses (see bnb_issue_loads), OLDER than the next tile's DMAs.
+      // (Requesting them one whole tile ahead instead -- 32 more registers -- measured no gain: profiles/r04_experiment_bn_backward_streaming.txt)
+#pragma unroll
+      for (int it = 0; it < EIT; ++it) {
+        const int row = (lane + it * 64) / NCCE;
+        const long long m = m_begin + (long long)t * BM + wm * WM + row;
+        const bool ok = en_ok && m < m_end;
+        euv[it] = *(const u32x4*)(bup + (ok ? m * p.bnb_ldu + en : 0));
+        eov[it] = *(const u32x4*)(yp + ((ok && p.accumulate) ? m * p.ldy + en : 0));
+      }
+      HDU_SCHED_BARRIER();
+    }
     if (t + NSA - 1 < ntiles) issue_tile(t + NSA - 1);      // refills the slot tile t-1 was read from (all reads are behind the barrier)
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -1925,9 +1969,50 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
       const long long m = m_begin + (long long)t * BM + wm * WM + row;
       const int n = n0 + wn * WN + cc * CH;
       const u32x4 v = *(const u32x4*)(stg + row * CROWB + cc * 16);
-      if (m < m_end && n < p.Cout) *(u32x4*)(yp + m * p.ldy + n) = v;
+      if constexpr (BNB) {
+        const bool ok = m < m_end && n < p.Cout;
+        float dz[CH], u[CH], o[CH];
+        Chunk<T>::unpack(v, dz);
+        Chunk<T>::unpack(euv[it], u);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float sj = ba[j] * u[j] + bb[j];
+          const float g = (ok && (!p.bnb_relu || sj > 0.f)) ? dz[j] : 0.f;
+          bs1[j] += g;
+          bs2[j] += g * ((u[j] - bmu[j]) * brs[j]);
+          o[j] = ba[j] * g;
+        }
+        if (p.accumulate) {
+          float old[CH];
+          Chunk<T>::unpack(eov[it], old);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) o[j] += old[j];
+        }
+        if (ok) *(u32x4*)(yp + m * p.ldy + n) = Chunk<T>::pack(o);
+      } else {
+        if (m < m_end && n < p.Cout) *(u32x4*)(yp + m * p.ldy + n) = v;
+      }
     }
     HDU_WAVE_LDS_SYNC();                               // (the patch is rewritten only after the next tile's barrier + MFMAs)
+  }
+  if constexpr (BNB) {
+    if (bsums) {
+      // lanes ecc, ecc + 8, ... of a wave own the same 8 channels: butterfly over lane bits 3..5, then lanes 0..7 add the wave's
+      // 8 x 2 x 8 totals to this workgroup's slot row (the two pixel waves of a channel half meet in the atomics)
+#pragma unroll
+      for (int mask = NCCE; mask < 64; mask <<= 1) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { bs1[j] += __shfl_xor(bs1[j], mask); bs2[j] += __shfl_xor(bs2[j], mask); }
+      }
+      float* dst = p.bnb_partial + (long long)(blockIdx.x % (unsigned)p.bnb_slots) * 2 * p.Cout;
+      if (lane < NCCE && en_ok) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          atomicAdd(dst + en + j, bs1[j]);
+          atomicAdd(dst + p.Cout + en + j, bs2[j]);
+        }
+      }
+    }
   }
 }
 
@@ -3170,7 +3255,8 @@ static void launch_halo_fprop(const ConvK& k, hipStream_t s) {
 static bool pw_bstat_ok(const ConvK& k, int dtype) {
   return dtype == HDU_BF16 && !g_tuning[HDU_TUNE_NO_PW_BSTAT] && k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 &&
          (k.pd | k.ph | k.pw) == 0 && (k.ud | k.uh | k.uw) == 0 && k.pro_a == nullptr && k.skip == nullptr && k.bias == nullptr &&
-         k.epi_a == nullptr && k.stats_partial == nullptr && k.bnb_u == nullptr && !k.accumulate && k.drop_scale == 0.f &&
+         k.epi_a == nullptr && k.stats_partial == nullptr && (k.bnb_u != nullptr ? !g_tuning[HDU_TUNE_NO_PW_BSTAT_BNB] : !k.accumulate) &&
+         k.drop_scale == 0.f &&
          (k.Ktot == 128 || k.Ktot == 192) && k.Cout >= 256 && k.M >= 64 && k.x_bytes != 0 &&
          (long long)k.Cout * k.Ktot * 2 < (1ll << 31) && k.Do == k.De && k.Ho == k.He && k.Wo == k.We;
 }
@@ -3185,6 +3271,11 @@ static void launch_pw_bstat(const ConvK& k, hipStream_t s) {
   if (splits > tiles) splits = tiles;
   const long long rows = ((tiles + splits - 1) / splits) * 64;
   const unsigned gx = (unsigned)((k.M + rows - 1) / rows);
+  if (k.bnb_u != nullptr) {
+    if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN, true>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+    else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN, true>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+    return;
+  }
   if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
   else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
 }
@@ -3564,7 +3655,7 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     else if (d->dtype == HDU_BF16) snprintf(buf, buflen, "conv_wgrad_tr_kernel<%d>", choose_wgrad(k));
     else snprintf(buf, buflen, "conv_wgrad_kernel<float, %d>", choose_wgrad(k));
   } else if (pw_bstat_ok(k, d->dtype)) {
-    snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 128>", k.Ktot / 64);
+    snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 128, %s>", k.Ktot / 64, k.bnb_u ? "true" : "false");
   } else if (fprop_halo_ok(k, d->dtype)) {
     snprintf(buf, buflen, "conv_halo_fprop_kernel<%d>", choose_halo_bn(k));
   } else {

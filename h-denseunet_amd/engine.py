@@ -174,6 +174,7 @@ class Ctx:
         self.bn_bwd_fused = os.environ.get("HDU_BN_BWD_FUSED", "1") == "1"      # two-launch BN backward (hdu_bn_bwd_fused)
         self.fuse_bn_bwd_mode = int(os.environ.get("HDU_FUSE_BN_BWD", "1"))
         self.fuse_bn_bwd = self.fuse_bn_bwd_mode > 0
+        self.fuse_bn_bwd_pw = os.environ.get("HDU_FUSE_BN_BWD_PW", "1") == "1"
         self.fuse_bn_bwd_now = False
         self.bnb_sinks = []          # (layer, offset into bnb_acc)
         self.bnb_acc = None
@@ -757,9 +758,15 @@ class ConvLayer:
         self.strided = stride != (1, 1, 1)
         # the consumer BN's backward runs in the epilogue of this layer's data-gradient launch when dz IS that launch's
         # output: no up-sampling in between, no skip add, no depth halo, no dropout on the BN input
+        # Round 4: the bottleneck data gradients (dz[M x Cin] = dt[M x 128|192] . W^T, Cin >= 256) run on the filter-stationary
+        # STREAMING kernel, whose tile epilogue takes the BN backward at no extra pass (conv_pw_bstat_kernel<.., BNB>): there the
+        # fusion pays for batch-statistics BNs too -- the dz round trip and the reduction + apply passes over the O(L^2)-wide slab
+        # go, the deferred part of du follows as a correction over the producer's own channels (HDU_FUSE_BN_BWD_PW=0: off).
+        pw_stream = bool(ctx.fuse_bn_bwd_pw and dt == HDU_BF16 and K == (1, 1, 1) and pad == (0, 0, 0) and cout_p in (128, 192)
+                         and cin_p >= 256 and xa.M >= 64)
         self.bnb_fused = bool(ctx.fuse_bn_bwd and need_input_grad and bn is not None and up == (0, 0, 0) and skip is None
                               and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None
-                              and (ctx.fuse_bn_bwd_mode >= 2 or bn.mode != "batch"))
+                              and (ctx.fuse_bn_bwd_mode >= 2 or bn.mode != "batch" or pw_stream))
         self.bnb_off = None
         self._s2 = None
         self._s2_ok = (os.environ.get("HDU_STRIDE2_DGRAD", "1") == "1" and all(v in (1, 2) for v in stride)

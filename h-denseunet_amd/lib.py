@@ -260,6 +260,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(22, int(os.environ["HDU_NO_PRO_DMA"]))
     if "HDU_PERS" in os.environ:
         lib.hdu_set_tuning(23, int(os.environ["HDU_PERS"]))
+    if "HDU_NO_PW_BSTAT_BNB" in os.environ:
+        lib.hdu_set_tuning(26, int(os.environ["HDU_NO_PW_BSTAT_BNB"]))
     if "HDU_PERS_MIN_ITEMS" in os.environ:
         lib.hdu_set_tuning(24, int(os.environ["HDU_PERS_MIN_ITEMS"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:

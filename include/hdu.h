@@ -86,6 +86,7 @@ int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
 #define HDU_TUNE_PERS 23             /* 0 = two-stage implicit GEMM on large grids (default: the persistent 256-row kernel was measured 10-20 %
                                         slower per launch, profiles/r04_experiment_persistent_gemm.txt), 1 = persistent kernel, one
                                         workgroup per CU (256), N > 1 = persistent kernel with N workgroups */
+#define HDU_TUNE_NO_PW_BSTAT_BNB 26   /* 1 = a bottleneck data gradient with a fused BN backward takes the tiled kernels (round 3; A/B) */
 #define HDU_TUNE_PERS_MIN_ITEMS 24   /* (m-tile, n-tile) pairs a layer needs to take the persistent form (default 512) */
 #define HDU_TUNE_WGRAD_NCT 21        /* 1 = one filter-row tile per pointwise filter-gradient workgroup (round 2's form; A/B) */
 int hdu_set_tuning(int key, int value);

@@ -512,6 +512,12 @@ BNB_CASES = [
     dict(N=1, D=3, H=5, W=6, Cdy=32, Cu=128, K=(3, 3, 3), p=(1, 1, 1), ldu=None, acc=False, sums=True, relu=True, id="x2_3x3x3"),
     dict(N=1, D=1, H=16, W=16, Cdy=192, Cu=1056, K=(1, 1, 1), p=(0, 0, 0), ldu=None, acc=True, sums=False, relu=True, id="frozen_no_sums_wide"),
     dict(N=1, D=1, H=6, W=6, Cdy=24, Cu=40, K=(1, 1, 1), p=(0, 0, 0), ldu=56, acc=False, sums=True, relu=False, id="no_relu_ragged_n"),
+    # round 4: the filter-stationary streaming kernel (bf16, K = 192 / 128, >= 256 dz channels) with the BN backward in its tile
+    # epilogue: ragged pixel count (several tiles per workgroup + a tail), channels that do not fill the last 128-group, slab
+    # output with accumulation, a 3D bottleneck, and the overwrite form
+    dict(N=2, D=1, H=13, W=11, Cdy=192, Cu=328, K=(1, 1, 1), p=(0, 0, 0), ldu=344, acc=True, sums=True, relu=True, id="pw_bstat_k192_slab_acc"),
+    dict(N=1, D=3, H=9, W=10, Cdy=128, Cu=256, K=(1, 1, 1), p=(0, 0, 0), ldu=None, acc=False, sums=True, relu=True, id="pw_bstat_k128_3d"),
+    dict(N=1, D=1, H=40, W=33, Cdy=192, Cu=1056, K=(1, 1, 1), p=(0, 0, 0), ldu=None, acc=True, sums=True, relu=True, id="pw_bstat_many_tiles"),
 ]
 
 
@@ -546,6 +552,8 @@ def test_conv_fused_bn_backward(hdu, cs, dtype):
     d.bnb_a, d.bnb_b, d.bnb_relu = keep[0].data_ptr(), keep[1].data_ptr(), 1 if cs["relu"] else 0
     if cs["sums"]:
         d.bnb_mean, d.bnb_rstd, d.bnb_partial, d.bnb_slots = keep[2].data_ptr(), keep[3].data_ptr(), partial.data_ptr(), slots
+    if cs["id"].startswith("pw_bstat") and dtype == BF16:
+        assert ops.conv_kernel_name(d, 0).startswith("conv_pw_bstat_kernel") and ops.conv_kernel_name(d, 0).endswith("true>")
     ops.conv_fprop(d)
     # reference: dz = conv(dy, w) in the storage dtype (the tile is staged in it), then the masked scale
     dz = q(ref_conv(dy, w, (1, 1, 1), p, None), dtype)
