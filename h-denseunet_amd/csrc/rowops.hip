@@ -22,6 +22,7 @@ struct FinK {
   // kind 3 (sums of a fused conv-epilogue BN backward): parameter gradients as kind 2, and the deferred part of du
   // accumulated per stored channel: corr3 += k3, corr4 += k3*mean - k2
   const float* mean_in; float* corr3; float* corr4;
+  int skip_lo, skip_hi;     // kind 3: channels [skip_lo, skip_hi) leave corr3 / corr4 alone (hdu_bn_bwd_finalize_correct consumes them in the same launch)
 };
 
 // Sum of (a1, a2) over the 32 "partial lanes" of a channel in the 8-channel x 32-lane finalize geometry (thread = pl * 8 + cl):
@@ -141,7 +142,7 @@ __device__ __forceinline__ void finalize_channel(int c, double a1, double a2, lo
       if (fin.dsbeta) fin.dsbeta[c] = S1;
       if (fin.kind == 2) {
         fin.k1[c] = kk; fin.k2[c] = k2; fin.k3[c] = k3;
-      } else if (fin.batch_stats) {      // kind 3: the deferred part of du, accumulated per stored channel
+      } else if (fin.batch_stats && !(c >= fin.skip_lo && c < fin.skip_hi)) {      // kind 3: the deferred part of du, accumulated per stored channel
         fin.corr3[c] += k3;
         fin.corr4[c] += k3 * pre.mu - k2;
       }
@@ -924,6 +925,120 @@ __global__ __launch_bounds__(256) void bn_bwd_correct_kernel(RowK p) {
   for (; m < r_end; m += ROWS) body(m, *(const u32x4*)(xp + m * p.ldx + c0), *(const u32x4*)(op + m * p.ldo + c0));
 }
 
+// hdu_bn_bwd_finalize_correct (round 4): ONE launch for two things that follow each other in the backward chain of a dense
+// block -- the finalize of the fused BN backward of layer i (slot sums -> parameter gradients, corr3 / corr4 += for all its
+// channels) and the correction  du += -corr3 * u + corr4  of the 48 channels layer i-1 produced, right before layer i-1 reads
+// its gradient.  Workgroups [0, nfin): the ordinary finalize, 8 channels each, except that they leave the accumulators of the
+// corrected channels [cs0, cs0 + Cc) alone.  Workgroups nfin ..: row blocks of the correction; each derives the FINAL
+// coefficients of its own channel chunk itself: the stored accumulators (all earlier consumers) + this BN's share from the
+// slot sums (32 slot rows x 16 values per chunk: the row lanes take one slot each, an LDS column sum in slot order).
+struct FinCorK {
+  const float* partial; int slots; int C; long long M;      // the BN's slot sums [slots][2][C]
+  FinK fin;
+  int nfin;
+  int cs0, Cc;                                              // corrected channels, relative to the BN's channel 0
+  const void* u; void* du; long long ldu, lddu, rows_per_block;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_correct_kernel(FinCorK p) {
+  constexpr int CH = Chunk<T>::CH;
+  __shared__ double red[2][4][8];
+  __shared__ float slotv[32][8][2 * CH];                    // [slot][chunk column][S1 x CH | S2 x CH]
+  __shared__ float tot[8][2 * CH];
+  if ((int)blockIdx.x < p.nfin) {                           // ---- finalize part (reduce_finalize_kernel<float, RED_BNBWD>)
+    if (blockIdx.y != 0) return;                            // (the grid's second dimension belongs to the correction part)
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    const FinPre pre = fin_prefetch(p.fin, c < p.C ? c : 0, pl == 0 && c < p.C);
+    double a1 = 0.0, a2 = 0.0;
+    if (c < p.C)
+      for (int b = pl; b < p.slots; b += 32) {
+        a1 += (double)p.partial[((long long)b * 2 + 0) * p.C + c];
+        a2 += (double)p.partial[((long long)b * 2 + 1) * p.C + c];
+      }
+    fin_reduce32(a1, a2, red);
+    if (pl == 0 && c < p.C) finalize_channel<float, RED_BNBWD>(c, a1, a2, p.M, nullptr, nullptr, nullptr, p.fin, pre);
+    return;
+  }
+  // ---- correction part: 8 chunk columns x 32 row lanes; blockIdx.y = group of 8 chunk columns
+  const int cc = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c0 = (blockIdx.y * 8 + cc) * CH;                // relative to cs0
+  const bool active = c0 < p.Cc;
+  const int cb = p.cs0 + (active ? c0 : 0);                 // BN channel of this thread's chunk
+  {
+    float v[2 * CH];
+#pragma unroll
+    for (int j = 0; j < 2 * CH; ++j) v[j] = 0.f;
+    if (active && rl < p.slots) {
+#pragma unroll
+      for (int j = 0; j < CH; j += 4) {
+        const f32x4 q1 = *(const f32x4*)(p.partial + ((long long)rl * 2 + 0) * p.C + cb + j);
+        const f32x4 q2 = *(const f32x4*)(p.partial + ((long long)rl * 2 + 1) * p.C + cb + j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[j + r] = q1[r]; v[CH + j + r] = q2[r]; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * CH; ++j) slotv[rl][cc][j] = v[j];
+  }
+  // parameters of the chunk, requested before the barrier
+  float g[CH], sg[CH], rs[CH], mu[CH], o3[CH], o4[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    g[j] = p.fin.gamma ? p.fin.gamma[cb + j] : 1.f;
+    sg[j] = p.fin.sgamma ? p.fin.sgamma[cb + j] : 1.f;
+    rs[j] = p.fin.rstd_in[cb + j];
+    mu[j] = p.fin.mean_in[cb + j];
+    o3[j] = p.fin.corr3[cb + j];
+    o4[j] = p.fin.corr4[cb + j];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 * 2 * CH) {                           // thread (column cq, value vq): sum over the slots in slot order
+    const int cq = threadIdx.x / (2 * CH), vq = threadIdx.x % (2 * CH);
+    float t = 0.f;
+    for (int b = 0; b < p.slots && b < 32; ++b) t += slotv[b][cq][vq];
+    tot[cq][vq] = t;
+  }
+  __syncthreads();
+  if (!active) return;
+  float k3[CH], k4[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) {
+    const float S1 = tot[cc][j], S2 = tot[cc][CH + j];
+    const float kk = sg[j] * g[j] * rs[j];
+    const float k2 = kk * S1 * p.fin.invM;
+    const float kk3 = kk * rs[j] * S2 * p.fin.invM;
+    k3[j] = o3[j] + kk3;
+    k4[j] = o4[j] + (kk3 * mu[j] - k2);
+  }
+  const T* __restrict__ xp = (const T*)p.u;
+  T* __restrict__ op = (T*)p.du;
+  const long long r_begin = (long long)(blockIdx.x - p.nfin) * p.rows_per_block;
+  long long r_end = r_begin + p.rows_per_block;
+  if (r_end > p.M) r_end = p.M;
+  auto body = [&](long long m, const u32x4& xv, const u32x4& ov) {
+    float f[CH], o[CH];
+    Chunk<T>::unpack(xv, f);
+    Chunk<T>::unpack(ov, o);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) o[j] += k4[j] - k3[j] * f[j];
+    *(u32x4*)(op + m * p.lddu + c0) = Chunk<T>::pack(o);
+  };
+  long long m = r_begin + rl;
+  for (; m + (ROW_UNROLL - 1) * 32 < r_end; m += ROW_UNROLL * 32) {
+    u32x4 xv[ROW_UNROLL], ov[ROW_UNROLL];
+#pragma unroll
+    for (int q = 0; q < ROW_UNROLL; ++q) xv[q] = *(const u32x4*)(xp + (m + q * 32) * p.ldu + c0);
+#pragma unroll
+    for (int q = 0; q < ROW_UNROLL; ++q) ov[q] = *(const u32x4*)(op + (m + q * 32) * p.lddu + c0);
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int q = 0; q < ROW_UNROLL; ++q) body(m + q * 32, xv[q], ov[q]);
+  }
+  for (; m < r_end; m += 32) body(m, *(const u32x4*)(xp + m * p.ldu + c0), *(const u32x4*)(op + m * p.lddu + c0));
+}
+
 // geometry shared by the row kernels: column groups of COLS chunks, row blocks sized to ~512 workgroups
 static void row_geometry(int dtype, long long M, int C, int* cols, unsigned* gx, unsigned* gy, long long* rpb) {
   const int ch = dtype == HDU_BF16 ? 8 : 4;
@@ -1281,6 +1396,34 @@ extern "C" int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t
   if (dtype == HDU_BF16) { HDU_ROW_LAUNCH(bn_bwd_correct_kernel, bf16_t, cols, gx, gy, stream, k); }
   else { HDU_ROW_LAUNCH(bn_bwd_correct_kernel, float, cols, gx, gy, stream, k); }
   return hdu_check_launch("bn_bwd_correct");
+}
+
+extern "C" int hdu_bn_bwd_finalize_correct(int dtype, const float* partial, int slots, int64_t M, int C, const float* gamma,
+                                           const float* beta, const float* sgamma, const float* mean, const float* rstd,
+                                           float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, float* corr3, float* corr4,
+                                           int cs0, int Cc, const void* u, int64_t ldu, void* du, int64_t lddu, void* stream) {
+  const int ch = dtype == HDU_BF16 ? 8 : 4;
+  if ((dtype != HDU_BF16 && dtype != HDU_F32) || !partial || slots <= 0 || slots > 32 || M <= 0 || C <= 0 || !rstd || !mean || !corr3 ||
+      !corr4 || !u || !du || cs0 < 0 || Cc <= 0 || cs0 + Cc > C || cs0 % ch || Cc % ch || C % 4 || ldu % ch || lddu % ch ||
+      ((uintptr_t)u | (uintptr_t)du | (uintptr_t)partial) % 16)
+    return hdu_set_error(HDU_ERR_ARG, "bn_bwd_finalize_correct: bad args (corrected channels inside the BN's, chunk-aligned; <= 32 slots)");
+  FinCorK k{};
+  k.partial = partial; k.slots = slots; k.C = C; k.M = M;
+  k.fin.kind = 3; k.fin.gamma = gamma; k.fin.beta = beta; k.fin.sgamma = sgamma; k.fin.rstd_in = rstd; k.fin.invM = 1.0f / (float)M;
+  k.fin.batch_stats = 1; k.fin.dgamma = dgamma; k.fin.dbeta = dbeta; k.fin.dsgamma = dsgamma; k.fin.dsbeta = dsbeta;
+  k.fin.mean_in = mean; k.fin.corr3 = corr3; k.fin.corr4 = corr4; k.fin.skip_lo = cs0; k.fin.skip_hi = cs0 + Cc;
+  k.nfin = (C + 7) / 8;
+  k.cs0 = cs0; k.Cc = Cc; k.u = u; k.du = du; k.ldu = ldu; k.lddu = lddu;
+  const unsigned gy = (unsigned)((Cc / ch + 7) / 8);
+  long long want = (g_tuning[HDU_TUNE_ROW_WGS] > 0 ? g_tuning[HDU_TUNE_ROW_WGS] : 512) / gy;
+  long long maxb = (M + 127) / 128;                        // >= 4 rows per row lane
+  if (want > maxb) want = maxb;
+  if (want < 1) want = 1;
+  k.rows_per_block = (M + want - 1) / want;
+  const unsigned gxc = (unsigned)((M + k.rows_per_block - 1) / k.rows_per_block);
+  if (dtype == HDU_BF16) HDU_LAUNCH((bn_bwd_finalize_correct_kernel<bf16_t>), dim3((unsigned)k.nfin + gxc, gy), dim3(256), 0, (hipStream_t)stream, k);
+  else HDU_LAUNCH((bn_bwd_finalize_correct_kernel<float>), dim3((unsigned)k.nfin + gxc, gy), dim3(256), 0, (hipStream_t)stream, k);
+  return hdu_check_launch("bn_bwd_finalize_correct");
 }
 
 // ====================================================================== pooling / resampling

@@ -81,10 +81,19 @@ class Var:
         reduction-dependent part of the BN backward of every fused consumer of these channels (`-k3*u + k4`, summed over
         the consumers in corr3 / corr4 by hdu_bn_bwd_finalize) is added -- once, over just these channels."""
         r = self.root
-        if r.corr_off is not None and self.ctx.corr_acc is not None and self.ctx.fuse_bn_bwd_now:
+        ctx = self.ctx
+        if r.corr_off is not None and ctx.corr_acc is not None and ctx.fuse_bn_bwd_now:
+            pend = ctx._pending_fin
+            if pend is not None and pend["root"] is r and pend["c0"] <= self.c0 and self.c0 + self.C <= pend["c0"] + pend["C"] \
+                    and self.act.M == pend["M"]:
+                # the finalize of the consumer BN that ran last and this correction: one launch (hdu_bn_bwd_finalize_correct)
+                ctx._pending_fin = None
+                ops.bn_bwd_finalize_correct(*pend["args"], self.c0 - pend["c0"], self.act, self.grad)
+                return self.grad
+            ctx.flush_pending_finalize()
             ld = r.act.ld
             base = r.corr_off + self.c0
-            acc = self.ctx.corr_acc
+            acc = ctx.corr_acc
             ops.bn_bwd_correct(self.act, acc[base:base + self.C], acc[base + ld:base + ld + self.C], self.grad)
         return self.grad
 
@@ -170,6 +179,8 @@ class Ctx:
         # Default 1 = inference-mode BNs only; 2 = every BN (tests cover both); 0 = off.
         self.defer_bnb_finalize = os.environ.get("HDU_DEFER_BNB_FINALIZE", "1") == "1"
         self._bnb_deferred, self._bnb_plan = [], None
+        self._pending_fin = None
+        self.merge_fin_correct = os.environ.get("HDU_MERGE_FIN_CORRECT", "1") == "1"
         self.absorb_stats = os.environ.get("HDU_ABSORB_STATS", "1") == "1"     # BN fold inside the consumer's materialize pass
         self.bn_bwd_fused = os.environ.get("HDU_BN_BWD_FUSED", "1") == "1"      # two-launch BN backward (hdu_bn_bwd_fused)
         self.fuse_bn_bwd_mode = int(os.environ.get("HDU_FUSE_BN_BWD", "1"))
@@ -345,6 +356,14 @@ class Ctx:
             plan.finalize()
             self.wgrad_plan = plan
 
+    def flush_pending_finalize(self):
+        """the finalize of a fused batch-statistics BN backward is held back until the next reader of its tensor's gradient, so
+        that both run as one launch (Var.dy); whatever is still pending runs on its own here"""
+        pend, self._pending_fin = self._pending_fin, None
+        if pend is not None:
+            (part, slots, M, C, g, be, sg, mean, rstd, dg, db, dsg, dsb, c3, c4) = pend["args"]
+            ops.bn_bwd_finalize(part, slots, M, C, True, g, be, sg, mean, rstd, dg, db, dsg, dsb, c3, c4)
+
     def unprime_stats(self):
         """new weights: the stored means are no longer a good shift for the one-pass epilogue moments"""
         for st in self.stats_sinks:
@@ -516,6 +535,7 @@ class Ctx:
             self._bnb_deferred = []
         for f in order[lo:hi]:
             f()
+        self.flush_pending_finalize()
         if hi == len(self.bwd) and self._bnb_deferred:
             keys = tuple(k for k, _ in self._bnb_deferred)
             if self._bnb_plan is None or self._bnb_plan[0] != keys:       # (the set is fixed by the model: built once)
@@ -997,6 +1017,13 @@ def _conv_backward_fused_bn(self, dy):
                                                  bn.sg.data if bn.sg else None, bn.gamma.grad if tr_bn else None,
                                                  bn.beta.grad if tr_bn else None, bn.sg.grad if tr_sc else None,
                                                  bn.sb.grad if tr_sc else None)))
+            return
+        fin_args = (part, self.BNB_SLOTS, x.M, bn.C, bn.gamma.data, bn.beta.data, bn.sg.data if bn.sg else None, bn.mean_used, bn.rstd,
+                    bn.gamma.grad if tr_bn else None, bn.beta.grad if tr_bn else None,
+                    bn.sg.grad if tr_sc else None, bn.sb.grad if tr_sc else None, c3, c4)
+        if bn.batch_now and ctx.merge_fin_correct and self.BNB_SLOTS <= 32 and bn.C % 4 == 0:
+            ctx.flush_pending_finalize()
+            ctx._pending_fin = dict(root=xv.root, c0=xv.c0, C=bn.C, M=x.M, args=fin_args)      # runs with the next reader's correction (Var.dy)
             return
         ops.bn_bwd_finalize(part, self.BNB_SLOTS, x.M, bn.C, bn.batch_now, bn.gamma.data, bn.beta.data,
                             bn.sg.data if bn.sg else None, bn.mean_used, bn.rstd,

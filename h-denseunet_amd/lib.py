@@ -100,6 +100,8 @@ _SIGS = {
     "hdu_conv_fprop": (c_int, [ctypes.POINTER(ConvDesc), c_p]),
     "hdu_bn_bwd_finalize": (c_int, [c_p, c_int, c_i64, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "hdu_bn_bwd_correct": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_p, c_i64, c_p]),
+    "hdu_bn_bwd_finalize_correct": (c_int, [c_int, c_p, c_int, c_i64, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                            c_int, c_int, c_p, c_i64, c_p, c_i64, c_p]),
     "hdu_conv_splitk_ws_bytes": (c_sz, [ctypes.POINTER(ConvDesc)]),
     "hdu_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_p, c_p]),
     "hdu_conv_dgrad_strided": (c_int, [ctypes.POINTER(ConvDesc), c_p]),

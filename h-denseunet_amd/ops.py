@@ -487,6 +487,16 @@ def bn_bwd_finalize(partial, slots, M, C, batch_stats, gamma, beta, sgamma, mean
                                        fptr(dsbeta), fptr(corr3), fptr(corr4), stream()), "hdu_bn_bwd_finalize")
 
 
+def bn_bwd_finalize_correct(partial, slots, M, C, gamma, beta, sgamma, mean, rstd, dgamma, dbeta, dsgamma, dsbeta, corr3, corr4,
+                            cs0, u, du):
+    """hdu_bn_bwd_finalize (batch statistics) of a BN over C channels + hdu_bn_bwd_correct of the channels [cs0, cs0 + u.C) of the
+    tensor it normalises (u / du: Act slabs starting at channel cs0), one launch"""
+    check(_l.get().hdu_bn_bwd_finalize_correct(u.dtype, fptr(partial), slots, M, C, fptr(gamma), fptr(beta), fptr(sgamma), fptr(mean),
+                                               fptr(rstd), fptr(dgamma), fptr(dbeta), fptr(dsgamma), fptr(dsbeta), fptr(corr3),
+                                               fptr(corr4), cs0, u.C, u.ptr, u.ld, du.ptr, du.ld, stream()),
+          "hdu_bn_bwd_finalize_correct")
+
+
 def bn_bwd_correct(u, corr3, corr4, du):
     check(_l.get().hdu_bn_bwd_correct(u.dtype, u.ptr, u.ld, u.M, u.C, fptr(corr3), fptr(corr4), du.ptr, du.ld, stream()),
           "hdu_bn_bwd_correct")

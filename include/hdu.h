@@ -192,6 +192,15 @@ int hdu_bn_bwd_finalize_batched(const hdu_bnbwd_entry* table, const uint32_t* be
  * of these channels, applied ONCE, right before their producer reads the gradient. */
 int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t M, int C, const float* corr3, const float* corr4,
                        void* du, int64_t lddu, void* stream);
+/* hdu_bn_bwd_finalize(batch_stats = 1) of one BN and hdu_bn_bwd_correct of the channels [cs0, cs0 + Cc) of the tensor it
+ * normalises, in ONE launch (in a dense block the two follow each other: layer i's fused BN backward is finalized, then layer
+ * i-1 -- the producer of the last slab that BN reads -- takes its gradient).  corr3 / corr4: the accumulators of the BN's C
+ * channels; the corrected channels use (stored value + this BN's share) and their accumulators are NOT updated (they are never
+ * read again).  u / du point at channel cs0 of the stored tensor / its gradient. */
+int hdu_bn_bwd_finalize_correct(int dtype, const float* partial, int slots, int64_t M, int C, const float* gamma, const float* beta,
+                                const float* sgamma, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                float* dsgamma, float* dsbeta, float* corr3, float* corr4, int cs0, int Cc, const void* u,
+                                int64_t ldu, void* du, int64_t lddu, void* stream);
 
 /* bytes of split-K scratch hdu_conv_fprop would use for this descriptor (0 = it would not split) */
 size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d);

@@ -1162,3 +1162,51 @@ def test_softmax_accumulate(hdu, dtype, num):
     assert float((score.cpu().double().reshape(M, num) - ref).abs().max()) < 2e-6
     with pytest.raises(hdu.lib.HduError):
         ops.softmax_accumulate(la, 0, M, 4, torch.zeros(M * 4, device=ops.device()))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("geom", [(1000, 304, 256, 48), (77, 128, 96, 32), (4100, 64, 0, 64)])
+def test_bn_bwd_finalize_correct(hdu, dtype, geom):
+    """hdu_bn_bwd_finalize_correct == hdu_bn_bwd_finalize (batch statistics) followed by hdu_bn_bwd_correct of the channels
+    [cs0, cs0 + Cc): same parameter gradients, same corrected gradient, the accumulators of every OTHER channel updated, those
+    of the corrected channels left alone"""
+    ops = ops_mod()
+    dev_ = ops.device()
+    M, C, cs0, Cc = geom
+    slots = 32
+    g = torch.Generator().manual_seed(9)
+    rn = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float32)
+    partial = (rn(slots, 2, C) * 3).to(dev_).reshape(-1)
+    gamma, beta, sg = (rn(C) * 0.2 + 1.0).to(dev_), rn(C).to(dev_), (rn(C) * 0.2 + 1.0).to(dev_)
+    mean, rstd = (rn(C) * 0.3).to(dev_), (rn(C).abs() + 0.5).to(dev_)
+    u = q(rnd((1, 1, 1, M, C + 8), 3, 1.0, dtype), dtype)
+    du0 = q(rnd((1, 1, 1, M, C + 8), 4, 1.0, dtype), dtype)
+    outs = []
+    c3_init, c4_init = rn(C).abs() * 0.1, rn(C) * 0.1
+    for merged in (True, False):
+        ua, dua = mkact(ops, u, dtype), mkact(ops, du0, dtype)
+        z = lambda: torch.zeros(C, dtype=torch.float32, device=dev_)
+        dg, db, dsg, dsb = z(), z(), z(), z()
+        c3, c4 = c3_init.clone().to(dev_), c4_init.clone().to(dev_)
+        c3_0, c4_0 = c3.clone(), c4.clone()
+        us, dus = ua.slab(cs0, Cc), dua.slab(cs0, Cc)
+        if merged:
+            ops.bn_bwd_finalize_correct(partial, slots, M, C, gamma, beta, sg, mean, rstd, dg, db, dsg, dsb, c3, c4, cs0, us, dus)
+        else:
+            ops.bn_bwd_finalize(partial, slots, M, C, True, gamma, beta, sg, mean, rstd, dg, db, dsg, dsb, c3, c4)
+            ops.bn_bwd_correct(us, c3[cs0:cs0 + Cc], c4[cs0:cs0 + Cc], dus)
+        outs.append([t.cpu().double() for t in (dg, db, dsg, dsb, c3, c4)] + [dua.to_torch().cpu().double(), c3_0.cpu().double(), c4_0.cpu().double()])
+    mg, sp = outs
+    for i, nm in enumerate(["dgamma", "dbeta", "dsgamma", "dsbeta"]):
+        assert float((mg[i] - sp[i]).abs().max()) <= 1e-5 * max(1.0, float(sp[i].abs().max())), nm
+    keep = torch.ones(C, dtype=torch.bool)
+    keep[cs0:cs0 + Cc] = False
+    for i in (4, 5):
+        if keep.any():
+            assert float((mg[i][keep] - sp[i][keep]).abs().max()) <= 1e-5 * max(1.0, float(sp[i].abs().max()))
+        assert torch.equal(mg[i][~keep], mg[7 if i == 4 else 8][~keep])            # corrected channels: accumulators untouched
+    tol = 2e-2 if dtype == BF16 else 2e-5
+    assert float((mg[6] - sp[6]).abs().max()) <= tol * max(1.0, float(sp[6].abs().max()))
+    untouched = torch.cat([mg[6][..., :cs0] - du0[..., :cs0].double(), mg[6][..., cs0 + Cc:] - du0[..., cs0 + Cc:].double()], -1)
+    assert float(untouched.abs().max()) == 0.0
+    assert float((mg[6][..., cs0:cs0 + Cc] - du0[..., cs0:cs0 + Cc].double()).abs().max()) > 0.01
