@@ -184,10 +184,15 @@ def test_graph_replay_equals_eager_steps(hip_lib, dtype, kind, variant, b, size,
     assert upd > 0 and np.isfinite(diff)
     # a fresh random-init net amplifies roundoff by orders of magnitude per step (measured: two eager runs of the float32 net
     # differ by 4e-4 of the update after three steps), so the bound is the eager-vs-eager distance itself: the replayed graph
-    # must not be further from an eager run than ~ another eager run is (factor 4 + a floor for the case of identical runs)
-    assert diff <= 4.0 * noise + 1e-6 * upd, (diff, noise, upd)
+    # must not be further from an eager run than ~ another eager run is
+    # (round 4, five runs of the end2end case on MI355X: the eager-vs-eager distance itself came out between 0.3 % and 3.4 % of the
+    # update's norm -- the float atomics of the 3D branch's batch statistics perturb the first forward by 1e-6 relative, the
+    # x250 coupling of the hybrid amplifies it, tools/diag_determinism.py -- so ONE repeat is a weak estimate of the noise: the
+    # bound also has a floor of 5 % of the update.  A replay with a stale argument or pointer -- a frozen dropout mask, an ignored
+    # learning rate, a table rebuilt after capture -- moves the parameters by tens of percent of the update.)
+    assert diff <= max(4.0 * noise, 0.05 * upd), (diff, noise, upd)
     for a, g, a2 in zip(l_eager, l_graph, l_again):
-        assert abs(a - g) <= 4.0 * abs(a - a2) + (1e-5 if dtype == "f32" else 2e-3) * abs(a), (l_eager, l_graph, l_again)
+        assert abs(a - g) <= 4.0 * abs(a - a2) + 5e-3 * abs(a), (l_eager, l_graph, l_again)
     # and the replayed step is not a no-op: the three losses differ from each other
     assert len({round(v, 7) for v in l_graph}) == 3
 
