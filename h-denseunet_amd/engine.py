@@ -323,7 +323,6 @@ class Ctx:
         self._shift_copies = [(r.shift, r.mean) for r in self.stat_roots] if self.stats_sinks else []
         self._zp_arena = ops.ZeroPlan([self.arena], self._shift_copies)
         self._zp_bwd = ops.ZeroPlan([self.arena[o_bnb:total]]) if total > o_bnb else None
-        self._desc_scope()
         for cv in self.convs:
             cv.bind()
         self._build_prep_table()
@@ -342,11 +341,11 @@ class Ctx:
             if not (cv.trainable and cv.out.root.needs_grad):
                 continue
             if cv.xin is not None:          # materialised input
-                d = ops.conv_desc(cv.xin.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.conv_up)
+                d = self.conv_desc(cv.xin.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.conv_up)
             elif cv.bn is None and cv.skip is None:      # the conv reads its producer directly (stems, 1x1 heads)
-                d = ops.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up)
+                d = self.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up)
             elif cv.pw_fused:                            # pointwise over relu(a * x + b): recomputed on the x fragments
-                d = ops.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up, None,
+                d = self.conv_desc(cv.x.act, cv.wf_ptr, cv.out.grad, cv.K, cv.stride, cv.pad, cv.up, None,
                                   (cv.bn.a, cv.bn.b), cv.bn.relu)
             else:
                 continue                    # fused prologue: per-layer launch
@@ -502,12 +501,14 @@ class Ctx:
             self._fold_plans[phase] = ops.FoldPlan(ents) if ents else None
         return self._fold_plans[phase]
 
-    def _desc_scope(self):
-        """descriptors built from here on belong to this model: a depth shard computes 1/world of every layer"""
-        ops.SHARD_WORLD = self.shard.world if (self.shard is not None and self.shard.world > 1) else 1
+    def shard_world(self):
+        return self.shard.world if (self.shard is not None and self.shard.world > 1) else 1
+
+    def conv_desc(self, *a, **k):
+        """ops.conv_desc for a layer of THIS model: a depth shard computes 1 / world of every layer and decides like the whole layer"""
+        return ops.conv_desc(*a, shard_world=self.shard_world(), **k)
 
     def run_forward(self):
-        self._desc_scope()
         self.pass_id += 1
         if self.batch_fold and self.finalized:
             plan = self._fold_plan(self.learning_phase)
@@ -522,7 +523,6 @@ class Ctx:
     def run_backward(self, seg=None):
         """the whole backward pass, or positions [seg[0], seg[1]) of it (in execution order) -- see grad_buckets"""
         lo, hi = seg if seg is not None else (0, len(self.bwd))
-        self._desc_scope()
         if lo == 0:
             for v in self.vars:
                 v.written = False
@@ -828,21 +828,21 @@ class ConvLayer:
             # grid (the scalar gather form took 9.7 of the 27 ms of an end2end step for 0.4 % of its FLOPs)
             xa = self.x.act
             self._s2 = ops.Stride2Dgrad(ctx.dtype, self.kernel.data, self.out.grad, (xa.N, xa.D, xa.H, xa.W), xa.C, self.K,
-                                        self.stride, self.pad)
-        self.d_f = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu, bias)
+                                        self.stride, self.pad, shard_world=ctx.shard_world())
+        self.d_f = ctx.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu, bias)
         self.d_f_drop = None
         if self.dropout > 0:
-            self.d_f_drop = ops.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu,
+            self.d_f_drop = ctx.conv_desc(x, self.wf_ptr, out, self.K, self.stride, self.pad, up, skip, pro, relu,
                                           bias, False, 1.0 - self.dropout, self.drop_seed, ctx.seed_dev)
         # variants that apply the consumer's BN(+Scale)+ReLU in the epilogue and write the consumer's operand buffer
         self.d_f_epi = self.d_f_drop_epi = None
         cons = self.epi_consumer
         if cons is not None:
             epi = (cons.bn.a, cons.bn.b, cons.bn.relu)
-            self.d_f_epi = ops.conv_desc(x, self.wf_ptr, cons.xin.act, self.K, self.stride, self.pad, up, skip, pro, relu, bias,
+            self.d_f_epi = ctx.conv_desc(x, self.wf_ptr, cons.xin.act, self.K, self.stride, self.pad, up, skip, pro, relu, bias,
                                          epi=epi)
             if self.dropout > 0:
-                self.d_f_drop_epi = ops.conv_desc(x, self.wf_ptr, cons.xin.act, self.K, self.stride, self.pad, up, skip, pro,
+                self.d_f_drop_epi = ctx.conv_desc(x, self.wf_ptr, cons.xin.act, self.K, self.stride, self.pad, up, skip, pro,
                                                   relu, bias, False, 1.0 - self.dropout, self.drop_seed, ctx.seed_dev, epi=epi)
         # training-phase variants that also accumulate the output's moments for the StatsOp that follows this conv
         self.d_f_st = self.d_f_drop_st = None
@@ -924,9 +924,9 @@ class ConvLayer:
                 ops.colsum(dy, self.bias.grad, ctx.ws)
         elif self.trainable:
             if self.xin is not None:
-                d = ops.conv_desc(self.xin.act, self.wf_ptr, dy, self.K, self.stride, self.pad, self.conv_up)
+                d = ctx.conv_desc(self.xin.act, self.wf_ptr, dy, self.K, self.stride, self.pad, self.conv_up)
             else:
-                d = ops.conv_desc(x, self.wf_ptr, dy, self.K, self.stride, self.pad, self.up,
+                d = ctx.conv_desc(x, self.wf_ptr, dy, self.K, self.stride, self.pad, self.up,
                                   self.skip.act if self.skip is not None else None,
                                   (self.bn.a, self.bn.b) if self.bn is not None else None,
                                   self.bn.relu if self.bn is not None else False)
@@ -956,10 +956,10 @@ class ConvLayer:
             if self._s2 is not None:
                 self._s2.run(tgt_act, accumulate=acc)
             else:
-                d = ops.conv_desc(tgt_act, self.wf_ptr, dy, K, self.stride, pad, accumulate=acc)
+                d = ctx.conv_desc(tgt_act, self.wf_ptr, dy, K, self.stride, pad, accumulate=acc)
                 ops.conv_dgrad_strided(d)
         else:
-            d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K,
+            d = ctx.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K,
                               (1, 1, 1), (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)
             ops.conv_fprop(d)
         if self.skip is not None and self.skip.root.needs_grad and not skip_first:
@@ -989,7 +989,7 @@ def _conv_backward_fused_bn(self, dy):
     K, pad = self.K, self.pad
     acc = xv.grad_mode()
     tgt = xv.grad
-    d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, x.D, x.H, x.W, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
+    d = ctx.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, x.D, x.H, x.W, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
                       (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)
     d.bnb_u, d.bnb_ldu = x.ptr, x.ld
     d.bnb_a, d.bnb_b, d.bnb_relu = bn.a.data_ptr(), bn.b.data_ptr(), 1 if bn.relu else 0
@@ -1044,11 +1044,11 @@ def _conv_backward_halo(self, dy):
     De, He, We = (x.D + 2 * h) << self.up[0], x.H << self.up[1], x.W << self.up[2]
     tgt = self._dxe()
     if self.strided:      # the 7x7x7 stride-2 stem of a depth-sharded end-to-end hybrid: gradient w.r.t. (CT, 250*logits2d)
-        d = ops.conv_desc(ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), self.wf_ptr, dy, K,
+        d = ctx.conv_desc(ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), self.wf_ptr, dy, K,
                           self.stride, pad)
         ops.conv_dgrad_strided(d)
     else:
-        d = ops.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
+        d = ctx.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K, (1, 1, 1),
                           (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), halo_out=(2 * h) << self.up[0])
         ops.conv_fprop(d)
     dz = tgt

@@ -94,9 +94,6 @@ class Act:
 # Sized for the library's worst case (tile count x 16 splits x 64x128 float32 outputs).
 _SPLITK = None
 SPLITK_BYTES = 320 * 16 * 64 * 128 * 4
-# Number of depth shards the layers of the descriptors built next are split over: the engine sets it while it builds / runs a
-# depth-sharded model (engine.Ctx._desc_scope), 1 otherwise.  conv_desc turns it into hdu_conv_desc.layer_rows.
-SHARD_WORLD = 1
 PRO_CMAX = 2304      # conv_igemm.hip HDU_PRO_CMAX: widest contraction whose BN prologue the async-DMA pointwise kernels take
 
 
@@ -109,13 +106,16 @@ def splitk_scratch():
 
 
 def conv_desc(x, w_ptr, y, K, stride=(1, 1, 1), pad=(0, 0, 0), up=(0, 0, 0), skip=None, pro=None, relu=True,
-              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None, splitk=None, halo_out=0):
+              bias=None, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, epi=None, splitk=None, halo_out=0,
+              shard_world=1):
     """x: Act (stored input), y: Act (output), K=(KD,KH,KW); epi = (a, b, relu): output affine of the BN that follows;
     splitk = (float32 scratch tensor of SPLITK_BYTES, int32[512] zeroed counters) for launches on another stream;
-    halo_out = depth planes of y that a neighbouring depth shard computes too (data gradient w.r.t. an input with halos)."""
+    halo_out = depth planes of y that a neighbouring depth shard computes too (data gradient w.r.t. an input with halos);
+    shard_world = depth shards the layer is split over (the OWNING model's: engine.Ctx.conv_desc passes it -- ADVICE r3: a
+    process-wide setting leaked into descriptors of other models)."""
     d = ConvDesc()
-    if SHARD_WORLD > 1:      # the unsharded layer's output pixels: the library decides tiles / split-K for those
-        d.layer_rows = y.N * (y.D - halo_out) * SHARD_WORLD * y.H * y.W
+    if shard_world > 1:      # the unsharded layer's output pixels: the library decides tiles / split-K for those
+        d.layer_rows = y.N * (y.D - halo_out) * shard_world * y.H * y.W
     ws, cnt = splitk if splitk is not None else splitk_scratch()
     d.splitk_ws, d.splitk_ws_bytes, d.splitk_counters = ws.data_ptr(), SPLITK_BYTES, cnt.data_ptr()
     d.dtype = x.dtype
@@ -288,7 +288,7 @@ class Stride2Dgrad:
     """Data gradient of a stride-2 (per axis: 1 or 2) convolution as 2^d stride-1 implicit GEMMs (include/hdu.h,
     hdu_stride2_dgrad_filters / hdu_parity_interleave): built once per layer, run() per backward pass."""
 
-    def __init__(self, dtype, w_master, dy, dx_dims, Cin_p, K, stride, pad):
+    def __init__(self, dtype, w_master, dy, dx_dims, Cin_p, K, stride, pad, shard_world=1):
         """w_master: float32 master filter [Cout_p][KD][KH][KW][Cin_p] (flat tensor view); dy: Act of the output gradient;
         dx_dims = (N, Di, Hi, Wi) of the input"""
         N, Di, Hi, Wi = dx_dims
@@ -320,7 +320,7 @@ class Stride2Dgrad:
         self.descs = []
         for i, (nt, pl, woff) in enumerate(classes):
             y = Act(self.cls, i * cls_elems, N, q[0], q[1], q[2], Cin_p, Cin_p, dtype)
-            self.descs.append(conv_desc(dy, ctypes.c_void_p(self.wsub.data_ptr() + woff * esz), y, nt, (1, 1, 1), pl))
+            self.descs.append(conv_desc(dy, ctypes.c_void_p(self.wsub.data_ptr() + woff * esz), y, nt, (1, 1, 1), pl, shard_world=shard_world))
 
     def run(self, dx, accumulate=False):
         lib = _l.get()
