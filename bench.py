@@ -312,7 +312,7 @@ def pmc_traffic(kernel, config, dtype):
     """HBM bytes per launch of `kernel` from the committed PMC summaries (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     passes over this same bench command, profiles/): FETCH_SIZE [KB] x2 (gfx950 counts a 128-B request as 64 B,
     MI355X_MICROARCH.md "HBM") + WRITE_SIZE [KB].  None when no summary of this config / kernel is committed."""
-    for rnd in (PROFILE_ROUND, "r03"):
+    for rnd in (PROFILE_ROUND,):          # (summaries of THIS round's kernels only: an older round's figures belong to other code)
         vals = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             path = os.path.join(ROOT, "profiles", "%s_pmc_%s_%s_%s.txt" % (rnd, ctr, config, dtype))
