@@ -85,11 +85,7 @@ def test_sub_builders_exported(emu_lib):
         else:           # hybridnet.py: same layers, dense-block BNs frozen
             assert names3 == set(full.ctx.by_layer)
             assert not ctx.by_layer["3dconv2_1_x1_bn"][0].trainable and ctx.by_layer["3dconv2_1_x1_scale"][0].trainable
-        if variant == "3dpart":              # (one forward through the emulator is enough: the launch lists are the full models')
-            x3.act.from_torch(torch.randn(1, 8, 32, 32, x3.act.C) * 50)
-            ctx.learning_phase = 0
-            ctx.run_forward()
-            assert np.isfinite(logits.act.to_torch().numpy()).all()
+        assert abs(len(ctx.fwd) - len(full.ctx.fwd)) <= 1      # the same launch list (+ the materialised ac_up4, - the Model's input cast)
         # 2D sub-builder on 2.5D slabs
         ctx2 = eng.Ctx(dt, None)
         ctx2.grad_enabled = variant == "end2end"
