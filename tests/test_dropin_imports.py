@@ -85,7 +85,10 @@ def test_sub_builders_exported(emu_lib):
         else:           # hybridnet.py: same layers, dense-block BNs frozen
             assert names3 == set(full.ctx.by_layer)
             assert not ctx.by_layer["3dconv2_1_x1_bn"][0].trainable and ctx.by_layer["3dconv2_1_x1_scale"][0].trainable
-        assert abs(len(ctx.fwd) - len(full.ctx.fwd)) <= 1      # the same launch list (+ the materialised ac_up4, - the Model's input cast)
+        if variant == "3dpart":
+            assert abs(len(ctx.fwd) - len(full.ctx.fwd)) <= 1  # the same launch list (+ the materialised ac_up4, - the Model's input cast)
+        else:
+            assert len(ctx.fwd) < len(full.ctx.fwd)            # hybridnet.py: frozen dense-block BNs need no statistics launches
         # 2D sub-builder on 2.5D slabs
         ctx2 = eng.Ctx(dt, None)
         ctx2.grad_enabled = variant == "end2end"
