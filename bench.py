@@ -30,7 +30,10 @@ sys.path.insert(0, ROOT)
 
 # conv FLOPs (2*MAC) per slice, fwd + dgrad + wgrad (stem dgrad skipped)
 TRAIN_GFLOP_PER_SLICE = {"2d": 580.5, "3dpart": 156.6, "end2end": 227.3, "shard3d": 121.3}
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,   # MI355X_MICROARCH.md: dense MFMA peaks
+               # "f32x3" = float32 storage, bf16 hi/lo split operands, THREE v_mfma_f32_16x16x16_bf16 per product (lib.set_f32_contraction):
+               # the K=16 form moves half the K of the K=32 form per issue, so a product-equivalent peak of 2500 / 2 / 3
+               "f32x3": 2500.0 / 6.0}
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 PROFILE_ROUND = "r04"
 
@@ -394,6 +397,18 @@ def top_kernels(agg, dtype, k=4):
 
 
 def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline):
+    """dtype "f32x3": the float32 network with the split-bf16 contraction mode switched on for the duration of the workload"""
+    if dtype != "f32x3":
+        return _run_workload(config, dtype, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline)
+    lib = importlib.import_module("h-denseunet_amd").lib
+    prev = lib.set_f32_contraction("bf16x3")
+    try:
+        return _run_workload(config, dtype, "f32", b, size, cols, steps, warmup, rank, world, use_graph, roofline)
+    finally:
+        lib.set_f32_contraction(prev)
+
+
+def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, world, use_graph, roofline):
     """build, make resident, (capture,) warm up, time `steps` steps between barriers, MAX over ranks.  Returns the
     record of this workload (rank 0 adds the roofline of its dominant conv kernel)."""
     par = importlib.import_module("h-denseunet_amd.parallel")
@@ -409,7 +424,7 @@ def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_g
             use_graph = False
     if torch.cuda.is_available():
         torch.cuda.reset_peak_memory_stats()
-    m = build(config, dtype, b, size, cols)
+    m = build(config, store, b, size, cols)
     if (world > 1 or os.environ.get("HDU_FORCE_DP") == "1") and config != "shard3d":
         par.attach_data_parallel(m)
     kind = "2d" if config == "2d" else "hybrid"
@@ -506,7 +521,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="2d", choices=["2d", "3dpart", "end2end", "shard3d"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
@@ -515,7 +530,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", default=None,
                     help="comma list of extra workloads timed after the main one (config[:dtype]); default for the "
-                         "default 2d/bf16 run: 3dpart,end2end,shard3d,2d:f32 (shard3d = the 512x512x64 per-GPU shard of "
+                         "default 2d/bf16 run: 3dpart,end2end,shard3d,2d:f32,2d:f32x3 (shard3d = the 512x512x64 per-GPU shard of "
                          "BASELINE configs[4], single GPU only); 'none' disables")
     a = ap.parse_args()
 
@@ -545,7 +560,7 @@ def main():
         if default_run and not DRYRUN:
             # the 512x512x64 shard shape runs where a whole 512^3 volume cannot (one GPU); under N > 1 the driver's
             # weak-scaling run keeps to the data-parallel workloads
-            extras = "3dpart,end2end,shard3d,2d:f32" if world == 1 else "3dpart,end2end,2d:f32"
+            extras = "3dpart,end2end,shard3d,2d:f32,2d:f32x3" if world == 1 else "3dpart,end2end,2d:f32,2d:f32x3"
     extra_recs = []
     if extras != "none":
         for spec in extras.split(","):

@@ -38,6 +38,7 @@ struct ConvK {
   int wg_gx, wg_gy, wg_gz;      // filter-gradient work grid (k-column tiles, filter-row tiles, pixel splits); 1-D launch
   int debug_flags;            // developer experiments only (HDU_TUNE_DEBUG): 1 = skip operand DMA, 2 = skip MFMA
   int vec_out;                // output rows are 16-byte addressable (DMA kernels' vector epilogue)
+  int f32_split;              // float32 launches: 0 = exact f32 MFMA, 1 = bf16 hi/lo operand split, three bf16 MFMAs (Mma<float>)
   // optional per-channel statistics of the OUTPUT, accumulated by the epilogue (saves the separate reduction pass over
   // a tensor that is still in LDS): partial[slot][0][c] += sum(y - shift[c]), partial[slot][1][c] += sum((y - shift[c])^2)
   float* stats_partial;       // [stats_slots][2][Cout] float, zeroed by the caller; NULL = off

@@ -25,8 +25,8 @@ template <typename T, int BM, int BN> struct BnbGeom {
   static_assert(NCC <= 32, "tile shape");
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+template <bool SPLIT, typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void conv_igemm_body(const ConvK& p, char* smem) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
   constexpr int A_IT = BM / 32;
@@ -39,7 +39,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BM % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::template kgroup<SPLIT>(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     if (more) store_tile(buf ^ 1);
@@ -233,6 +232,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE, false>(p, acc, smem, m0, n0, wm, wn, lane, tid, no_uv, no_ov, false);
 }
 
+// the float32 instantiations carry both contraction forms (ConvK::f32_split, Mma<float>): one uniform branch at entry
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
+  if constexpr (sizeof(T) == 4) {
+    if (p.f32_split) { conv_igemm_body<true, T, BM, BN, WAVES_M, WAVES_N>(p, smem); return; }
+  }
+  conv_igemm_body<false, T, BM, BN, WAVES_M, WAVES_N>(p, smem);
+}
+
 // =====================================================================================
 // filter gradient.  GEMM view: rows = Cout, cols = k (tap*Cin + c), contraction over output pixels.
 // Both operands are channel-contiguous in HBM but the MFMA wants them pixel-contiguous per lane, so the
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 // The pixel range is split across blockIdx.z; partial results are accumulated with float atomics.
 __device__ __forceinline__ int wg_swz(int row) { return (row ^ (row >> 3)) & 7; }
 
-template <typename T, int BCO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+template <bool SPLIT, typename T, int BCO>
+__device__ __forceinline__ void conv_wgrad_body(const ConvK& p, float* __restrict__ dw, long long rows_per_split, char* smem) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int PX = 8 * CH;          // pixels per step = elements per 128-byte LDS row
   constexpr int BKC = 128;            // k columns per workgroup
@@ -252,7 +261,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
   constexpr int TM = BCO / 16;
   constexpr int TN = 2;
   constexpr int STAGE = (BCO + BKC) * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::template kgroup<SPLIT>(af[i], bf[j], acc[i][j]);
       }
     }
     if (more) store_tile(buf ^ 1);
@@ -466,6 +474,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restr
         if (kcol < p.Ktot) atomicAdd(dw + (long long)co * p.Ktot + kcol, acc[i][j][r]);
       }
     }
+}
+
+// the float32 instantiations carry both contraction forms (ConvK::f32_split, Mma<float>): one uniform branch at entry
+template <typename T, int BCO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvK p, float* __restrict__ dw, long long rows_per_split) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BCO + 128) * 128];
+  if constexpr (sizeof(T) == 4) {
+    if (p.f32_split) { conv_wgrad_body<true, T, BCO>(p, dw, rows_per_split, smem); return; }
+  }
+  conv_wgrad_body<false, T, BCO>(p, dw, rows_per_split, smem);
 }
 
 // =====================================================================================
@@ -679,7 +697,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(ConvK p, float* __re
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::template kgroup<false>(af[i], bf[j], acc[i][j]);
       }
     }
     if (more) store_tile(buf ^ 1);
@@ -1088,8 +1106,8 @@ __device__ __forceinline__ void pro_table_issue(const ConvK& p, char* tab, int w
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool BNB = false, int PROC = 0>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
+template <bool SPLIT, typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool BNB, int PROC>
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvK& p, char* smem) {
   constexpr bool PRO = PROC > 0;
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
@@ -1102,7 +1120,6 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   constexpr int STAGE = (BM + BN) * 128;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(!(PRO && BNB), "the operand prologue belongs to forward launches, the fused BN backward to data gradients");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + 2 * PROC * 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1252,7 +1269,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::template kgroup<SPLIT>(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     __syncthreads();
@@ -1262,6 +1279,16 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
   HDU_TP(5);
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 2 * STAGE, BNB>(p, acc, smem, m0, n0, wm, wn, lane, tid, bnb_uv, bnb_ov, bnb_pre);
   HDU_TP(6);
+}
+
+// the float32 instantiations carry both contraction forms (ConvK::f32_split, Mma<float>): one uniform branch at entry
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool FAST, bool BNB = false, int PROC = 0>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvK p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128 + 2 * PROC * 4];
+  if constexpr (sizeof(T) == 4) {
+    if (p.f32_split) { conv_igemm_dma_body<true, T, BM, BN, WAVES_M, WAVES_N, FAST, BNB, PROC>(p, smem); return; }
+  }
+  conv_igemm_dma_body<false, T, BM, BN, WAVES_M, WAVES_N, FAST, BNB, PROC>(p, smem);
 }
 
 // NS-stage ring variant: tiles t+1 .. t+NS-1 stay in flight while tile t is multiplied.  Per iteration: counted
@@ -1321,8 +1348,8 @@ template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_n() {
 #endif
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST, bool BNB = false, int PROC = 0>
-__global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
+template <bool SPLIT, typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST, bool BNB, int PROC>
+__device__ __forceinline__ void conv_igemm_ring_body(const ConvK& p, char* smem) {
   constexpr bool PRO = PROC > 0;
   constexpr int CH = Chunk<T>::CH;
   constexpr int BK = 8 * CH;
@@ -1337,7 +1364,6 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   constexpr int L = A_IT + B_IT;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(!(PRO && BNB), "the operand prologue belongs to forward launches, the fused BN backward to data gradients");
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + 2 * PROC * 4];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1499,7 +1525,7 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::kgroup(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
+          for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::template kgroup<SPLIT>(bf[j], af[i], acc[i][j]);   // transposed tile: see igemm_epilogue
       }
     }
     slot = slot == NS - 1 ? 0 : slot + 1;
@@ -1516,6 +1542,16 @@ __global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
   HDU_TP(5);
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NS * STAGE, BNB>(p, acc, smem, m0, n0, wm, wn, lane, tid, bnb_uv, bnb_ov, bnb_pre);
   HDU_TP(6);
+}
+
+// the float32 instantiations carry both contraction forms (ConvK::f32_split, Mma<float>): one uniform branch at entry
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool FAST, bool BNB = false, int PROC = 0>
+__global__ __launch_bounds__(256) void conv_igemm_ring_kernel(ConvK p) {
+  __shared__ __attribute__((aligned(16))) char smem[NS * (BM + (BN + 31) / 32 * 32) * 128 + 2 * PROC * 4];
+  if constexpr (sizeof(T) == 4) {
+    if (p.f32_split) { conv_igemm_ring_body<true, T, BM, BN, WAVES_M, WAVES_N, NS, FAST, BNB, PROC>(p, smem); return; }
+  }
+  conv_igemm_ring_body<false, T, BM, BN, WAVES_M, WAVES_N, NS, FAST, BNB, PROC>(p, smem);
 }
 
 // =====================================================================================
@@ -2994,6 +3030,7 @@ static int fill_convk(const hdu_conv_desc* d, ConvK* k, bool wgrad, bool exact_g
   k->xcd_swizzle = g_tuning[HDU_TUNE_XCD_SWIZZLE];
   k->vec_out = 1;
   k->debug_flags = g_tuning[HDU_TUNE_DEBUG];
+  k->f32_split = (d->dtype == HDU_F32 && g_tuning[HDU_TUNE_F32_SPLIT]) ? 1 : 0;
   if (!wgrad && d->y && (d->Cout % ch || d->ldy % ch || (uintptr_t)d->y % 16))
     return hdu_set_error(HDU_ERR_ARG, "conv: Cout / output pixel stride must be multiples of the 16-byte chunk and y 16-byte aligned");
   return 0;

@@ -153,7 +153,7 @@ template <> struct Chunk<bf16_t> {
 template <typename T> struct Mma;
 
 template <> struct Mma<bf16_t> {
-  __device__ __forceinline__ static f32x4 kgroup(u32x4 a, u32x4 b, f32x4 c) {
+  template <bool SPLIT = false> __device__ __forceinline__ static f32x4 kgroup(u32x4 a, u32x4 b, f32x4 c) {
 #ifdef HDU_EMU
     return hipemu_mfma_16x16x32_bf16(__builtin_bit_cast(hipemu_u16x8, a), __builtin_bit_cast(hipemu_u16x8, b), c);
 #else
@@ -162,8 +162,38 @@ template <> struct Mma<bf16_t> {
 #endif
   }
 };
+
+// float32 operands as bf16 hi + lo (x = hi + lo + r, |r| <= 2^-18 |x|: both parts round to nearest even)
+__device__ __forceinline__ void hdu_split_bf16(u32x4 v, u32x2& hi, u32x2& lo) {
+  const float f0 = hdu_u2f(v.x), f1 = hdu_u2f(v.y), f2 = hdu_u2f(v.z), f3 = hdu_u2f(v.w);
+  hi = u32x2{hdu_pack_bf16x2(f0, f1), hdu_pack_bf16x2(f2, f3)};
+  lo = u32x2{hdu_pack_bf16x2(f0 - hdu_u2f(hi.x << 16), f1 - hdu_u2f(hi.x & 0xffff0000u)),
+             hdu_pack_bf16x2(f2 - hdu_u2f(hi.y << 16), f3 - hdu_u2f(hi.y & 0xffff0000u))};
+}
+// v_mfma_f32_16x16x16_bf16: a lane holds 4 consecutive k of its row / column, lane group g the k block 4g..4g+3 -- the
+// k order of the float32 k-group above
+__device__ __forceinline__ f32x4 hdu_mfma_16x16x16_bf16(u32x2 a, u32x2 b, f32x4 c) {
+#ifdef HDU_EMU
+  return hipemu_mfma_16x16x16_bf16(__builtin_bit_cast(hipemu_u16x4, a), __builtin_bit_cast(hipemu_u16x4, b), c);
+#else
+  typedef short hdu_s16x4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(hdu_s16x4, a), __builtin_bit_cast(hdu_s16x4, b), c, 0, 0, 0);
+#endif
+}
+
+// SPLIT (chosen per launch from ConvK::f32_split): false = exact float32 (four v_mfma_f32_16x16x4_f32, 4 x 32 cycles);
+// true = "bf16 x 3": a.b ~ ah.bh + ah.bl + al.bh on three v_mfma_f32_16x16x16_bf16 with the float32 accumulator -- the
+// dropped terms (al.bl and the two split remainders) are <= 3 * 2^-18 of |a.b| per product
 template <> struct Mma<float> {
-  __device__ __forceinline__ static f32x4 kgroup(u32x4 a, u32x4 b, f32x4 c) {
+  template <bool SPLIT = false> __device__ __forceinline__ static f32x4 kgroup(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (SPLIT) {
+      u32x2 ah, al, bh, bl;
+      hdu_split_bf16(a, ah, al);
+      hdu_split_bf16(b, bh, bl);
+      c = hdu_mfma_16x16x16_bf16(al, bh, c);
+      c = hdu_mfma_16x16x16_bf16(ah, bl, c);
+      return hdu_mfma_16x16x16_bf16(ah, bh, c);
+    }
 #ifdef HDU_EMU
     c = hipemu_mfma_16x16x4_f32(hdu_u2f(a.x), hdu_u2f(b.x), c);
     c = hipemu_mfma_16x16x4_f32(hdu_u2f(a.y), hdu_u2f(b.y), c);

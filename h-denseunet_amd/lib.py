@@ -264,6 +264,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(23, int(os.environ["HDU_PERS"]))
     if "HDU_NO_PW_BSTAT_BNB" in os.environ:
         lib.hdu_set_tuning(26, int(os.environ["HDU_NO_PW_BSTAT_BNB"]))
+    if os.environ.get("HDU_F32_CONTRACTION", "exact") != "exact":
+        lib.hdu_set_tuning(TUNE_F32_SPLIT, {"bf16x3": 1}[os.environ["HDU_F32_CONTRACTION"]])
     if "HDU_PERS_MIN_ITEMS" in os.environ:
         lib.hdu_set_tuning(24, int(os.environ["HDU_PERS_MIN_ITEMS"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
@@ -322,6 +324,25 @@ class _CallLog:
 
 
 _call_log = None
+
+TUNE_F32_SPLIT = 27     # include/hdu.h: HDU_TUNE_F32_SPLIT
+
+
+def set_f32_contraction(mode):
+    """how the float32 networks (dtype "f32": float32 storage, statistics, row kernels) contract in their convolutions,
+    process-wide and read at launch time: "exact" (default) = float32 MFMA, the parity mode; "bf16x3" = every operand split
+    into bf16 hi + lo, a.b ~ ah.bh + ah.bl + al.bh on the bf16 MFMA with the float32 accumulator (<= 3 * 2^-18 relative per
+    product).  Environment: HDU_F32_CONTRACTION=bf16x3.  Returns the previous mode."""
+    global _f32_contraction
+    if mode not in ("exact", "bf16x3"):
+        raise ValueError("f32 contraction mode: 'exact' or 'bf16x3'")
+    prev = _f32_contraction
+    check(get().hdu_set_tuning(TUNE_F32_SPLIT, 1 if mode == "bf16x3" else 0), "hdu_set_tuning")
+    _f32_contraction = mode
+    return prev
+
+
+_f32_contraction = os.environ.get("HDU_F32_CONTRACTION", "exact")
 
 
 def profile_begin(max_records=1 << 16):

@@ -158,10 +158,33 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x
   return d;
 }
 
+// D = A(16x16) * B(16x16) + C, bf16 operands (v_mfma_f32_16x16x16_bf16): lane l holds A[l&15][(l>>4)*4+j] / B[(l>>4)*4+j][l&15].
+typedef unsigned short hipemu_u16x4 __attribute__((ext_vector_type(4)));
+static inline hipemu_f32x4 hipemu_mfma_16x16x16_bf16(hipemu_u16x4 a, hipemu_u16x4 b, hipemu_f32x4 c) {
+  struct Slot { unsigned short a[4], b[4]; } mine;
+  for (int j = 0; j < 4; ++j) { mine.a[j] = a[j]; mine.b[j] = b[j]; }
+  size_t stride;
+  const char* all = hipemu::wave_exchange(&mine, sizeof(mine), &stride);
+  const int lane = hipemu::g_cur->lane;
+  const int col = lane & 15;
+  hipemu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (lane >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const Slot* sa = (const Slot*)(all + (size_t)(row + 16 * (k >> 2)) * stride);
+      const Slot* sb = (const Slot*)(all + (size_t)(col + 16 * (k >> 2)) * stride);
+      acc += hipemu_bf16_to_f32(sa->a[k & 3]) * hipemu_bf16_to_f32(sb->b[k & 3]);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_release();
+  return d;
+}
+
 // ds_read_b64_tr_b16 (gfx950 LDS transpose read), lane map measured on MI355X with tools/probe_tr.hip:
 // within each 16-lane group the lanes' 8-byte pieces form a 4x16 row-major bf16 tile (lane i supplies row i>>2,
 // columns (i&3)*4..+3); lane i receives column i, rows 0..3.
-typedef unsigned short hipemu_u16x4 __attribute__((ext_vector_type(4)));
 static inline hipemu_u16x4 hipemu_ds_read_tr16_b64(const void* lds_addr) {
   unsigned short mine[4];
   std::memcpy(mine, lds_addr, 8);

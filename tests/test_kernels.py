@@ -299,6 +299,59 @@ def test_conv_wgrad(hdu, cs, dtype):
     assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
 
 
+SPLIT_CASES = [c for c in CONV_CASES if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "decoder_up_skip_2d", "dense3x3x3", "stem7x7s2",
+                                                     "wide_bn128", "pw_pro_two_stage", "pw_pro_wide_table_splitk")]
+
+
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in SPLIT_CASES])
+def test_conv_f32_bf16x3_contraction(hdu, cs):
+    """HDU_TUNE_F32_SPLIT (lib.set_f32_contraction("bf16x3")): float32 storage, every operand split into bf16 hi + lo and contracted
+    as ah.bh + ah.bl + al.bh on the bf16 MFMA with the float32 accumulator.  Per product the dropped terms are <= 3 * 2^-18 =
+    1.1e-5 relative, so the result is held to 1.2e-5 * sum|a||b| (the float64 reference of the absolute products) -- and it is
+    NOT the exact-float32 result, which the same launches give again after the mode is switched back."""
+    import ctypes
+    ops = ops_mod()
+    b = build_conv_case(ops, cs, F32, seed=300)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    ya = ops.Act.alloc(N, Do, Ho, Wo, Cout, F32)
+    pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), ya, cs["K"], cs["s"], cs["p"], cs["up"], b["sa"], pro, True, None)
+    dy = rnd((N, Do, Ho, Wo, Cout), 778, 1.0, F32)
+    dya = mkact(ops, dy, F32)
+    dg = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"], b["sa"], pro, True, None)
+
+    def run():
+        ops.conv_fprop(d)
+        dw = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+        ops.conv_wgrad(dg, dw)
+        return ya.to_torch().cpu().double(), dw.cpu().double()
+
+    y_exact, dw_exact = run()
+    assert hdu.lib.set_f32_contraction("bf16x3") == "exact"
+    try:
+        y_split, dw_split = run()
+    finally:
+        assert hdu.lib.set_f32_contraction("exact") == "bf16x3"
+    y_again, dw_again = run()
+    assert torch.equal(y_again, y_exact)
+    xe = ref_xeff(b["x"], cs["up"], b["skip"], b["pro"], True, F32).requires_grad_(True)
+    wref = b["w"].clone().requires_grad_(True)
+    ref = ref_conv(xe, wref, cs["s"], cs["p"], None)
+    (ref * dy).sum().backward()
+    mag_y = ref_conv(xe.detach().abs(), b["w"].abs(), cs["s"], cs["p"], None)                  # sum |a| |b| per output
+    xa2 = xe.detach().abs().requires_grad_(False)
+    wabs = b["w"].abs().clone().requires_grad_(True)
+    (ref_conv(xa2, wabs, cs["s"], cs["p"], None) * dy.abs()).sum().backward()
+    mag_w = wabs.grad
+    for what, got, exact, r, mag in (("fprop", y_split, y_exact, ref.detach(), mag_y), ("wgrad", dw_split, dw_exact, wref.grad, mag_w)):
+        err = (got - r).abs()
+        lim = 1.2e-5 * mag + 1e-6 * float(r.abs().max())
+        assert not (err > lim).any(), "%s: max err %.3e, max bound ratio %.3f" % (what, float(err.max()), float((err / lim).max()))
+        assert not torch.equal(got, exact), "%s: the split form did not run" % what
+        e_exact = float((exact - r).abs().max())
+        assert float(err.max()) > e_exact, (what, float(err.max()), e_exact)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES
                                 if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "stem7x7s2", "wide_bn128",

@@ -28,6 +28,17 @@ for stage in "$@"; do
     parity8)
       timeout 1800 python -m pytest -m gpu -x -q "tests/test_gpu_parity.py::test_full_forward_parity_f32[2d-denseunet-8-512-None-True]" \
         "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[2d-8x512-mid]" -s > gpurun_out/${tag}_parity8.log 2>&1 ;;
+    kernels_all)
+      timeout 900 python -m pytest tests/test_kernels.py -m gpu -x -q > gpurun_out/${tag}_kernels_all.log 2>&1 ;;
+    split_parity)
+      timeout 900 python -m pytest -m gpu -x -q -s tests/test_gpu_parity.py \
+        -k "test_f32_absolute_logit_error_from_trained_weights and (2d-denseunet or (3d and not 3dpart))" > gpurun_out/${tag}_split_parity.log 2>&1 ;;
+    split)      # float32 storage with the split-bf16 contraction: logits beside the exact mode, then the timed steps
+      HDU_PARITY_LOG=gpurun_out/${tag}_split_parity.txt timeout 900 python -m pytest -m gpu -x -q -s tests/test_gpu_parity.py \
+        -k "test_f32_absolute_logit_error_from_trained_weights and (2d-denseunet or (3d and not 3dpart))" > gpurun_out/${tag}_split_parity.log 2>&1
+      timeout 900 python bench.py --steps ${SPLIT_STEPS:-20} --warmup 3 --extras 2d:f32,2d:f32x3 --no-cpu-baseline \
+        > gpurun_out/${tag}_split_bench.json 2> gpurun_out/${tag}_split_bench.err
+      cp gpurun_out/bench_details.json gpurun_out/${tag}_split_bench_details.json 2>/dev/null ;;
     full)
       timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/${tag}_gpu_tests.log 2>&1
       python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" >> gpurun_out/${tag}_gpu_tests.log 2>&1 ;;
