@@ -849,6 +849,7 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
   const int n = n0 + cc * CH;
   const bool col_ok = cc < NCC && n < p.Cout;
   const bool sums = p.bnb_partial != nullptr;
+  const bool relu = (p.bnb_relu & 1) != 0, from_z = (p.bnb_relu & 2) != 0;
   float a[CH], b[CH], mu[CH], rs[CH], s1[CH], s2[CH];
   {
     // unconditional vector loads at a clamped channel index (see bnb_issue_loads): four loads in flight together instead
@@ -862,6 +863,12 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
       const f32x4 vm = *(const f32x4*)(pmu + nc + j), vr = *(const f32x4*)(prs + nc + j);
 #pragma unroll
       for (int r = 0; r < 4; ++r) { a[j + r] = va[r]; b[j + r] = vb[r]; mu[j + r] = sums ? vm[r] : 0.f; rs[j + r] = sums ? vr[r] : 0.f; }
+    }
+    if (from_z) {
+      // bnb_u holds z = relu(a*u + b): the normalised input is (u - mean) * rstd = (z - (b + a*mean)) * (rstd / a) wherever z > 0,
+      // the only elements that count (a channel with a == 0 has no recoverable input: its S2 stays 0)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { mu[j] = b[j] + a[j] * mu[j]; rs[j] = a[j] != 0.f ? rs[j] / a[j] : 0.f; }
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -884,8 +891,8 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
       Chunk<T>::unpack(uq, u);
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        const float sj = a[j] * u[j] + b[j];
-        const float g = (!p.bnb_relu || sj > 0.f) ? dz[j] : 0.f;
+        const float sj = from_z ? u[j] : a[j] * u[j] + b[j];
+        const float g = (!relu || sj > 0.f) ? dz[j] : 0.f;
         s1[j] += g;
         s2[j] += g * ((u[j] - mu[j]) * rs[j]);
         o[j] = a[j] * g;
@@ -3292,7 +3299,7 @@ static void launch_halo_fprop(const ConvK& k, hipStream_t s) {
 static bool pw_bstat_ok(const ConvK& k, int dtype) {
   return dtype == HDU_BF16 && !g_tuning[HDU_TUNE_NO_PW_BSTAT] && k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 &&
          (k.pd | k.ph | k.pw) == 0 && (k.ud | k.uh | k.uw) == 0 && k.pro_a == nullptr && k.skip == nullptr && k.bias == nullptr &&
-         k.epi_a == nullptr && k.stats_partial == nullptr && (k.bnb_u != nullptr ? !g_tuning[HDU_TUNE_NO_PW_BSTAT_BNB] : !k.accumulate) &&
+         k.epi_a == nullptr && k.stats_partial == nullptr && (k.bnb_u != nullptr ? (!g_tuning[HDU_TUNE_NO_PW_BSTAT_BNB] && !(k.bnb_relu & 2)) : !k.accumulate) &&
          k.drop_scale == 0.f &&
          (k.Ktot == 128 || k.Ktot == 192) && k.Cout >= 256 && k.M >= 64 && k.x_bytes != 0 &&
          (long long)k.Cout * k.Ktot * 2 < (1ll << 31) && k.Do == k.De && k.Ho == k.He && k.Wo == k.We;

@@ -200,6 +200,7 @@ class Ctx:
         self.dropout_enabled = True
         self.grad_enabled = True
         self.fuse_bn_epilogue = os.environ.get("HDU_FUSE_BN_EPILOGUE", "1") == "1"
+        self.fuse_bn_epilogue_train = os.environ.get("HDU_FUSE_BN_EPILOGUE_TRAIN", "1") == "1"
         self.fold_next = os.environ.get("HDU_FOLD_NEXT", "1") == "1"
         self.shard = None          # shard.ShardInfo when one volume is split on the depth axis
         self.fuse_prologue = os.environ.get("HDU_FUSE_PROLOGUE", "0") == "1"
@@ -520,13 +521,18 @@ class Ctx:
         for f in self.fwd:
             f()
 
+    def bnb_fusable(self):
+        """do the data-gradient launches of the pass carry their consumer BN's backward? (not under depth sharding: the halo
+        planes of dz are reduced across ranks before the BN backward)"""
+        return self.fuse_bn_bwd and (self.shard is None or self.shard.world == 1)
+
     def run_backward(self, seg=None):
         """the whole backward pass, or positions [seg[0], seg[1]) of it (in execution order) -- see grad_buckets"""
         lo, hi = seg if seg is not None else (0, len(self.bwd))
         if lo == 0:
             for v in self.vars:
                 v.written = False
-            self.fuse_bn_bwd_now = self.fuse_bn_bwd and (self.shard is None or self.shard.world == 1)
+            self.fuse_bn_bwd_now = self.bnb_fusable()
             if self._zeroed_bwd_pass != self.pass_id and self._zp_bwd is not None:
                 self._zp_bwd.run()         # (a training step's head launch has already cleared the whole arena)
                 self._zeroed_bwd_pass = self.pass_id
@@ -874,7 +880,13 @@ class ConvLayer:
         ctx, bn = self.ctx, self.bn
         if self.epi_producer is None or (bn.mode == "batch" and ctx.learning_phase == 1):
             return False
-        return ctx.learning_phase == 0 or not (self.need_input_grad or bn.any_trainable())    # (phase 1 = a backward pass follows)
+        if ctx.learning_phase == 0 or not (self.need_input_grad or bn.any_trainable()):      # (phase 1 = a backward pass follows)
+            return True
+        # Round 4: a stored-statistics BN WITH a backward pass (dense_rnn_net: every dense-block BN, hybridnet.py:11-97,182-354).
+        # The fused BN-backward epilogue of this conv's data gradient needs the mask and the normalised input only, and both
+        # follow from z = relu(a*u + b) alone (hdu_conv_desc.bnb_relu bit 1): the producer writes z, u never exists, the
+        # materialise launch goes (HDU_FUSE_BN_EPILOGUE_TRAIN=0: off).
+        return ctx.fuse_bn_epilogue_train and self.bnb_fused and self.need_input_grad and ctx.bnb_fusable()
 
     def forward(self):
         ctx = self.ctx
@@ -993,6 +1005,10 @@ def _conv_backward_fused_bn(self, dy):
                       (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)
     d.bnb_u, d.bnb_ldu = x.ptr, x.ld
     d.bnb_a, d.bnb_b, d.bnb_relu = bn.a.data_ptr(), bn.b.data_ptr(), 1 if bn.relu else 0
+    if self.epi_producer is not None and self.epi_active():
+        # the producer's epilogue wrote z = relu(a*u + b) into this conv's operand buffer and u was never stored
+        d.bnb_u, d.bnb_ldu = self.xin.act.ptr, self.xin.act.ld
+        d.bnb_relu |= 2
     need_sums = bn.batch_now or bn.any_trainable()
     part = None
     if need_sums:

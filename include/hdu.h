@@ -149,7 +149,10 @@ typedef struct hdu_conv_desc {
    *   - accumulates S1[c] += sum g and S2[c] += sum g*(u - bnb_mean[c])*bnb_rstd[c] into bnb_partial[slot][0|1][c]
    *     (float atomics, slot = workgroup % bnb_slots; caller zeroes it; NULL = no sums wanted), finished by
    *     hdu_bn_bwd_finalize.
-   * Replaces, per BN, the dz round trip through HBM, the reduction pass and the full-width apply pass. */
+   * Replaces, per BN, the dz round trip through HBM, the reduction pass and the full-width apply pass.
+   * bnb_relu: bit 0 = the BN is followed by ReLU; bit 1 (value 2) = `bnb_u` holds the BN's OUTPUT z = relu(a*u + b) instead
+   * of its input (a producer whose epilogue applied the stored-statistics BN, epi_*, never wrote u): the mask is z > 0 and
+   * the normalised input is recovered as (z - (b + a*mean)) * (rstd / a) where z > 0.  Tile kernels only. */
   const void* bnb_u;  int64_t bnb_ldu;
   const float* bnb_a; const float* bnb_b; const float* bnb_mean; const float* bnb_rstd;
   int bnb_relu;

@@ -644,6 +644,56 @@ def test_conv_fused_bn_backward(hdu, cs, dtype):
     assert_close(outa.to_torch().cpu(), want, dtype, scale=float(want.abs().max()), what="correct")
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in BNB_CASES if not c["id"].startswith("pw_bstat")])
+def test_conv_fused_bn_backward_from_output(hdu, cs, dtype):
+    """hdu_conv_desc.bnb_relu bit 1: `bnb_u` holds z = relu(a*u + b) -- what a producer with the BN in its epilogue stored -- and
+    the epilogue takes the ReLU mask (z > 0) and the normalised input ((z - (b + a*mean)) * rstd / a) from it: same a*g, and
+    S2 equal to the float64 evaluation of that formula on the stored z (and, within the storage rounding of z, to the u form)."""
+    import ctypes
+    ops = ops_mod()
+    N, D, H, W, Cdy, Cu, K, p = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cdy"], cs["Cu"], cs["K"], cs["p"]
+    M = N * D * H * W
+    dy = rnd((N, D, H, W, Cdy), 1, 1.0, dtype)
+    w = rnd((Cu,) + K + (Cdy,), 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cdy), dtype)
+    u = rnd((N, D, H, W, Cu), 7, 1.0, dtype)
+    old = rnd((N, D, H, W, Cu), 8, 0.5, dtype)
+    a = (rnd((Cu,), 9, 1.0).abs() + 0.3).float().double() * torch.where(torch.arange(Cu) % 3 == 0, -1.0, 1.0)   # both signs
+    b = rnd((Cu,), 10, 0.4).float().double()
+    mean = rnd((Cu,), 11, 0.3).float().double()
+    rstd = (rnd((Cu,), 12, 0.5).abs() + 0.5).float().double()
+    s = a * u + b
+    z = q(s.clamp_min(0) if cs["relu"] else s, dtype)
+    dya = mkact(ops, dy, dtype)
+    za = mkact(ops, z, dtype, cs["ldu"], 8 if cs["ldu"] else 0)
+    outa = mkact(ops, old, dtype, cs["ldu"], 8 if cs["ldu"] else 0)
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    slots = 5
+    keep = [dev(ops, t) for t in (a, b, mean, rstd)]
+    partial = torch.zeros(slots * 2 * Cu, dtype=torch.float32, device=ops.device())
+    d = ops.conv_desc(dya, ctypes.c_void_p(wt.data_ptr()), outa, K, (1, 1, 1), p, accumulate=cs["acc"])
+    d.bnb_u, d.bnb_ldu = za.ptr, za.ld
+    d.bnb_a, d.bnb_b, d.bnb_relu = keep[0].data_ptr(), keep[1].data_ptr(), (1 if cs["relu"] else 0) | 2
+    if cs["sums"]:
+        d.bnb_mean, d.bnb_rstd, d.bnb_partial, d.bnb_slots = keep[2].data_ptr(), keep[3].data_ptr(), partial.data_ptr(), slots
+    assert not ops.conv_kernel_name(d, 0).startswith("conv_pw_bstat_kernel")
+    ops.conv_fprop(d)
+    dz = q(ref_conv(dy, w, (1, 1, 1), p, None), dtype)
+    g = torch.where(z > 0, dz, torch.zeros_like(dz)) if cs["relu"] else dz
+    ref = a * g + (q(old, dtype) if cs["acc"] else 0.0)
+    assert_close(outa.to_torch().cpu(), ref, dtype, scale=float(ref.abs().max()), what="a*g from z")
+    if not cs["sums"]:
+        return
+    S = partial.cpu().double().reshape(slots, 2, Cu).sum(0)
+    uhat_z = (z - (b + a * mean)) * (rstd / a)
+    S1, S2 = g.reshape(M, Cu).sum(0), (g * uhat_z).reshape(M, Cu).sum(0)
+    tol = 2e-5 if dtype == F32 else 2e-3
+    sc = float(max(S1.abs().max(), S2.abs().max()))
+    assert float((S[0] - S1).abs().max()) <= tol * sc and float((S[1] - S2).abs().max()) <= tol * sc
+    S2_u = (g * (u - mean) * rstd).reshape(M, Cu).sum(0)            # the form that reads u: equal up to the rounding of the stored z
+    assert float((S[1] - S2_u).abs().max()) <= (1e-4 if dtype == F32 else 2e-2) * sc
+
+
 SPLITK_CASES = [
     # dense-block shapes whose output grid cannot fill the chip (include/hdu.h, hdu_conv_desc.splitk_ws)
     dict(N=2, D=1, H=16, W=15, Cin=192, Cout=48, K=(1, 3, 3), p=(0, 1, 1), bias=False, ldout=96, id="block5_3x3_192to48"),

@@ -284,6 +284,39 @@ def test_bn_in_producer_epilogue_equals_materialize_pass(emu_lib, monkeypatch, k
     assert float((g1 - g0).norm() / g0.norm()) <= 1e-4
 
 
+def test_frozen_bn_epilogue_in_training_equals_materialize_pass(emu_lib, monkeypatch):
+    """Round 4: in dense_rnn_net (end2end) every dense-block BN runs on stored statistics AND has a backward pass
+    (hybridnet.py:11-97,182-354).  The bottleneck 1x1 conv applies the following BN(+Scale)+ReLU in its epilogue in the
+    TRAINING step too: it stores z = relu(a*u + b), u is never written, and the fused BN backward of the 3x3 data gradient takes
+    the mask and the normalised input from z (hdu_conv_desc.bnb_relu bit 1).  Same loss and gradients as the materialise pass
+    (HDU_FUSE_BN_EPILOGUE_TRAIN=0), and one launch per dense layer fewer."""
+    kind, variant, b, size, cols = "hybrid", "end2end", 1, 32, 8
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("HDU_FUSE_BN_EPILOGUE_TRAIN", on)
+        m = U.build_pair(kind, variant, b, size, cols, "f32", NB2D, NB3D, odtype=torch.float32)[0]
+        m.ctx.dropout_enabled = False
+        fused = [c for c in m.ctx.convs if c.epi_consumer is not None]
+        act = [c for c in fused if c.epi_consumer.epi_active()]                  # (learning phase 1)
+        grad_through = [c for c in act if c.epi_consumer.need_input_grad]
+        assert (len(grad_through) >= 8) == (on == "1"), (len(fused), len(act), len(grad_through))
+        m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy])
+        x, y = U.synthetic_batch(kind, b, size, cols)
+        U.pkg("lib").profile_begin()
+        loss = m.train_on_batch(x, y)
+        recs, _ = U.pkg("lib").profile_end()
+        res.append((loss, m.ctx.G[:m.ctx.n_trainable].clone(), len(recs), m.get_grads_dict()))
+    (l1, g1, n1, d1), (l0, g0, n0, d0) = res
+    assert n1 <= n0 - 8, (n1, n0)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert float((g1 - g0).norm() / g0.norm()) <= 1e-4
+    gmax = max(float(np.abs(a).max()) for gs in d0.values() for a in gs)
+    for n, gs in d0.items():
+        for i, a in enumerate(gs):
+            sc = max(float(np.abs(a).max()), 1e-3 * gmax)
+            assert float(np.abs(d1[n][i] - a).max()) <= 5e-4 * sc, (n, i)
+
+
 @pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 2, 64, None)])     # (3D dense blocks: same StatsOp code)
 def test_finalize_folds_next_bn_equals_two_launches(emu_lib, monkeypatch, kind, variant, b, size, cols):
     """hdu_bn_stats_finalize_fold_next (the finalize launch of a dense layer's epilogue statistics also folds the next

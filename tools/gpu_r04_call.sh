@@ -30,6 +30,10 @@ for stage in "$@"; do
         "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[2d-8x512-mid]" -s > gpurun_out/${tag}_parity8.log 2>&1 ;;
     kernels_all)
       timeout 900 python -m pytest tests/test_kernels.py -m gpu -x -q > gpurun_out/${tag}_kernels_all.log 2>&1 ;;
+    fromz)       # frozen-BN epilogue fusion in the training step: kernel test, the end2end bf16 / f32 parity gates
+      timeout 600 python -m pytest tests/test_kernels.py -m gpu -x -q -k "fused_bn_backward" > gpurun_out/${tag}_fromz_kernels.log 2>&1
+      timeout 900 python -m pytest -m gpu -x -q -s "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[end2end]" \
+        > gpurun_out/${tag}_fromz_parity.log 2>&1 ;;
     split_parity)
       timeout 900 python -m pytest -m gpu -x -q -s tests/test_gpu_parity.py \
         -k "test_f32_absolute_logit_error_from_trained_weights and (2d-denseunet or (3d and not 3dpart))" > gpurun_out/${tag}_split_parity.log 2>&1 ;;
