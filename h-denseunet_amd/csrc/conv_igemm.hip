@@ -2278,7 +2278,7 @@ __device__ __forceinline__ void wgrad_dma_body(const ConvK& p, float* __restrict
 }
 
 // =====================================================================================
-// Halo-tile filter gradient for 2D 3x3 stride-1 "same" convolutions (bf16).
+// Halo-tile filter gradient for 2D 3x3 -- and, as three plane-shifted 2D problems, 3D 3x3x3 -- stride-1 "same" convolutions (bf16).
 // The im2col view used by conv_wgrad_dma_kernel re-loads every input pixel once per tap and the output gradient
 // once per k-column tile: measured, that kernel is bound by L2->LDS DMA traffic.  Here a workgroup owns a spatial
 // tile of 4 x 32 output pixels and 32 input channels: it DMAs the (4+2) x (32+2) input halo tile and the dy tile
@@ -2315,8 +2315,16 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
   const int co0 = (int)wby * BCO;
   const int H = p.He, W = p.We;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  const int ntiles = p.N * tiles_y * tiles_x;
-  const int t_begin = (int)wbz * tiles_per_split;
+  // 3 x 3 x 3 layers (round 4): a depth tap kd pairs output plane d with input plane d + kd - 1, and for a fixed kd the nine
+  // (kh, kw) taps are a 2D filter gradient between those planes.  The planes of the volume are the "images" here, the splits
+  // of the spatial tiles come in KD groups (wbz = split * KD + kd: the three workgroups of a split are neighbours in the
+  // launch order and share the dy tiles and two of their three x planes in L2), planes outside the volume load as zeros.
+  const int KDn = p.KD, Dn = p.De;
+  const int kd = (int)(wbz % (unsigned)KDn);
+  const int xshift = kd - p.pd;                           // input plane = output plane + xshift (2D: 0)
+  const int tap0 = kd * 9;
+  const int ntiles = p.N * Dn * tiles_y * tiles_x;
+  const int t_begin = (int)(wbz / (unsigned)KDn) * tiles_per_split;
   int t_end = t_begin + tiles_per_split;
   if (t_end > ntiles) t_end = ntiles;
 
@@ -2340,7 +2348,9 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
     const bool st = jj < HPP / 16 && hp < HP && c0 + lc * 8 < p.Cin;
     xhr[j] = st ? hr : (1 << 20);                        // (a row far outside every image: never valid)
     xhc[j] = hc;
-    xoff[j] = (hr * W + hc) * (int)p.ldx + c0 + lc * 8;  // element offset from the tile's (y0 - 1, x0 - 1) pixel
+    // element offset from the tile's origin pixel in the STORED input.  A nearest-neighbour up-sampling in front of the conv
+    // (p.uh / p.uw) is taken here: tile origins are multiples of 4 x 32, so floor((y0 + r) / 2) = y0 / 2 + floor(r / 2)
+    xoff[j] = (((hr - 1) >> p.uh) * p.Wi + ((hc - 1) >> p.uw)) * (int)p.ldx + c0 + lc * 8;
   }
   // dy tile: lane owns physical chunk (tid & 7) of tile pixels (tid >> 3) + 32 j = (row j, column tid >> 3)
   const int dpx0 = tid >> 3;
@@ -2351,23 +2361,27 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
   const int doff0 = dpx0 * (int)p.ldy + co0 + dcl * 8;   // + j * W * ldy for tile row j
 
   // load-side tile position, advanced incrementally
-  int l_tx, l_ty, l_n;
+  int l_tx, l_ty, l_n, l_d, l_v;
   {
     const int r = t_begin / tiles_x;
     l_tx = t_begin - r * tiles_x;
     l_n = r / tiles_y;
     l_ty = r - l_n * tiles_y;
+    l_v = l_n / Dn;                                       // volume and depth plane of image l_n
+    l_d = l_n - l_v * Dn;
   }
   auto issue_tile = [&](int buf) {
     char* Xh = smem + buf * STAGE;
     char* Dt = Xh + XBYTES;
     const int y0 = l_ty * TH, x0 = l_tx * TW;
-    const int xbase = ((l_n * H + y0 - 1) * W + x0 - 1) * (int)p.ldx;       // may be negative; valid pixels give >= 0 sums
+    const bool plane_ok = (unsigned)(l_d + xshift) < (unsigned)Dn;
+    const int xplane = l_v * p.Di + ((l_d + xshift) >> p.ud);                           // stored input plane
+    const int xbase = ((xplane * p.Hi + (y0 >> p.uh)) * p.Wi + (x0 >> p.uw)) * (int)p.ldx;       // valid pixels give >= 0 sums
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int jj = j * 4 + wave;
       if (jj < HPP / 16) {                                  // wave-uniform
-        const bool ok = (unsigned)(y0 - 1 + xhr[j]) < (unsigned)H && (unsigned)(x0 - 1 + xhc[j]) < (unsigned)W;
+        const bool ok = plane_ok && (unsigned)(y0 - 1 + xhr[j]) < (unsigned)H && (unsigned)(x0 - 1 + xhc[j]) < (unsigned)W;
         hdu_bufload_lds16(xsrd, ok ? (unsigned)(xbase + xoff[j]) * 2u : HDU_OOB, Xh + jj * 1024);
       }
     }
@@ -2383,6 +2397,7 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
       if (++l_ty == tiles_y) {
         l_ty = 0;
         ++l_n;
+        if (++l_d == Dn) { l_d = 0; ++l_v; }
       }
     }
   };
@@ -2468,7 +2483,7 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
-        if (co < p.Cout && c < p.Cin) atomicAdd(dw + (long long)co * p.Ktot + tap * p.Cin + c, acc[q][i][r]);
+        if (co < p.Cout && c < p.Cin) atomicAdd(dw + (long long)co * p.Ktot + (tap0 + tap) * p.Cin + c, acc[q][i][r]);
       }
   }
 }
@@ -3453,25 +3468,30 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
 }
 
 static bool wgrad_halo_ok(const ConvK& k) {
-  return !g_tuning[HDU_TUNE_NO_HALO] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 && k.KH == 3 && k.KW == 3 &&
-         k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 && (k.ud | k.uh | k.uw) == 0 &&
-         k.Di == 1 && k.Cin % 32 == 0 && k.We >= 32 &&
+  // 2D 3 x 3 "same" layers, and (round 4, HDU_TUNE_NO_HALO bit 1 = off) 3 x 3 x 3 "same" layers as three plane-shifted 2D problems
+  const bool d2 = k.KD == 1 && k.pd == 0 && k.Di == 1;
+  const bool d3 = k.KD == 3 && k.pd == 1 && k.Do == k.De && !(g_tuning[HDU_TUNE_NO_HALO] & 2);
+  return !(g_tuning[HDU_TUNE_NO_HALO] & 1) && k.pro_a == nullptr && k.skip == nullptr && (d2 || d3) && k.KH == 3 && k.KW == 3 &&
+         k.sd == 1 && k.sh == 1 && k.sw == 1 && k.ph == 1 && k.pw == 1 &&
+         // (a nearest-neighbour up-sampling in front of the conv is resolved in the tile's addressing: bit 2 of the knob = off)
+         ((k.ud | k.uh | k.uw) == 0 || !(g_tuning[HDU_TUNE_NO_HALO] & 4)) &&
+         k.Cin % 32 == 0 && k.We >= 32 &&
          // operands through buffer resources with 32-bit byte offsets (tensors of 4 GiB and more take the im2col form)
          k.x_bytes != 0 && (((long long)k.M - 1) * k.ldy + k.Cout) * 2 < (1ll << 32) &&
-         (long long)k.N * k.He * k.We * k.ldx < (1ll << 31) - (long long)(k.We + 2) * k.ldx;
+         (long long)k.N * k.De * k.He * k.We * k.ldx < (1ll << 31) - (long long)(k.He * k.We + k.We + 2) * k.ldx;
 }
 
 // work grid of the halo-tile filter gradient: 32-channel chunks x filter-row tiles x splits of the spatial tiles
 // (>= 2 tiles per workgroup).  Returns the tiles per split.
 static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk) {
-  const int tiles = k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32);
+  const int tiles = k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32);
   const unsigned gx = (unsigned)(k.Cin / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
-  int want = target / (int)(gx * gy);
+  int want = target / (int)(gx * gy * (unsigned)k.KD);
   if (want < 1) want = 1;
   if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;
   if (want < 1) want = 1;
   const int per = (tiles + want - 1) / want;
-  const unsigned gz = (unsigned)((tiles + per - 1) / per);
+  const unsigned gz = (unsigned)((tiles + per - 1) / per) * (unsigned)k.KD;      // (split, depth tap) pairs: wgrad_halo_body
   *kk = k;
   kk->wg_gx = (int)gx; kk->wg_gy = (int)gy; kk->wg_gz = (int)gz;
   return per;
@@ -3556,8 +3576,8 @@ extern "C" int hdu_wgrad_plan_shape(const hdu_conv_desc* d, int* variant, uint32
   const int bi = best == 64 ? 0 : (best == 48 ? 1 : 2);
   if (wgrad_halo_ok(k)) {
     *variant = 8 + bi;
-    *tiles = (uint32_t)(k.Cin / 32) * (uint32_t)((k.Cout + best - 1) / best);
-    *steps = (uint32_t)(k.N * ((k.He + 3) / 4) * ((k.We + 31) / 32));
+    *tiles = (uint32_t)(k.Cin / 32) * (uint32_t)((k.Cout + best - 1) / best) * (uint32_t)k.KD;
+    *steps = (uint32_t)(k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32));
   } else {
     const int nct = wgrad_nct(k, best);
     *variant = nct == 3 ? 6 : (nct == 2 ? 7 : bi * 2 + (wgrad_pointwise(k) ? 1 : 0));

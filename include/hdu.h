@@ -71,7 +71,7 @@ int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
 #define HDU_TUNE_RED_WGS 11          /* workgroups a per-channel reduction aims for (default 512) */
 #define HDU_TUNE_ROW_WGS 12          /* workgroups an element-wise row kernel aims for (default 512 = 2 per CU; rounds 1-2: 2048) */
 #define HDU_TUNE_NO_HALO_FPROP 9     /* 1 = disable the halo-tile forward / data-gradient kernel (A/B) */
-#define HDU_TUNE_NO_HALO 8           /* 1 = disable the halo-tile filter-gradient kernel (A/B) */
+#define HDU_TUNE_NO_HALO 8           /* bit 0 = disable the halo-tile filter-gradient kernel, bit 1 = for 3 x 3 x 3 layers only, bit 2 = for layers with a fused up-sampling only (A/B) */
 #define HDU_TUNE_WGRAD_TARGET_WGS 2  /* workgroups a filter-gradient launch aims for */
 #define HDU_TUNE_SPLITK 13           /* 0 = library default (split small grids), 1 = never split, N >= 2 = force N splits where possible (tests) */
 #define HDU_TUNE_BM64_MAX_M 18        /* layers with at most this many output pixels use 64-row tiles (default 16384) */

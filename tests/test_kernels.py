@@ -97,6 +97,14 @@ CONV_CASES = [
     dict(N=1, D=1, H=130, W=128, Cin=8, Cout=128, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="tile128x128_ragged_m"),
     dict(N=2, D=1, H=10, W=37, Cin=64, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=96, ldout=64, id="halo_tile_ragged_slab"),
     dict(N=1, D=1, H=8, W=64, Cin=32, Cout=64, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="halo_tile_exact"),
+    # round 4: 3 x 3 x 3 layers on the halo-tile filter gradient (three plane-shifted 2D problems): ragged tile grid, two volumes
+    # (the plane before volume 1's first plane is volume 0's last: it must read as padding), slab input / output
+    dict(N=1, D=3, H=6, W=33, Cin=32, Cout=48, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="halo_tile_3d_ragged"),
+    dict(N=2, D=2, H=5, W=32, Cin=64, Cout=40, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=80, ldout=56, id="halo_tile_3d_two_volumes_slab"),
+    # ... and with the decoder's nearest-neighbour up-sampling in front of the conv resolved in the tile addressing
+    dict(N=2, D=1, H=5, W=17, Cin=32, Cout=64, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 1, 1), skip=False, pro=False, bias=False, ldin=48, ldout=None, id="halo_tile_up2d"),
+    dict(N=1, D=2, H=3, W=16, Cin=32, Cout=24, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(1, 1, 1), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="halo_tile_up222_3d"),
+    dict(N=2, D=3, H=4, W=20, Cin=64, Cout=32, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 1, 1), skip=False, pro=False, bias=False, ldin=None, ldout=48, id="halo_tile_up221_3d"),
     # the filter-stationary pointwise kernel (bf16: K = 192 / 128, no prologue / bias, >= 256 output channels): ragged pixel
     # count, a channel count that is not a multiple of its 128-channel groups, slab input and output
     dict(N=2, D=1, H=13, W=11, Cin=192, Cout=328, K=(1, 1, 1), s=(1, 1, 1), p=(0, 0, 0), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=208, ldout=344, id="pw_bstat_k192_ragged"),

@@ -34,6 +34,13 @@ for stage in "$@"; do
       timeout 600 python -m pytest tests/test_kernels.py -m gpu -x -q -k "fused_bn_backward" > gpurun_out/${tag}_fromz_kernels.log 2>&1
       timeout 900 python -m pytest -m gpu -x -q -s "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[end2end]" \
         > gpurun_out/${tag}_fromz_parity.log 2>&1 ;;
+    halo3d)      # 3 x 3 x 3 filter gradients on the halo-tile kernel: kernel tests, then the 3D workloads incl. the shard shape
+      timeout 600 python -m pytest tests/test_kernels.py -m gpu -x -q -k "wgrad" > gpurun_out/${tag}_halo3d_kernels.log 2>&1
+      for arm in ${HALO_ARMS:-2 0}; do
+        HDU_NO_HALO=$arm timeout 600 python bench.py --config shard3d --steps 8 --warmup 2 --no-cpu-baseline --extras none \
+          > gpurun_out/${tag}_halo3d_shard_$arm.json 2> gpurun_out/${tag}_halo3d_shard_$arm.err
+        cp gpurun_out/bench_details.json gpurun_out/${tag}_halo3d_shard_details_$arm.json 2>/dev/null
+      done ;;
     split_parity)
       timeout 900 python -m pytest -m gpu -x -q -s tests/test_gpu_parity.py \
         -k "test_f32_absolute_logit_error_from_trained_weights and (2d-denseunet or (3d and not 3dpart))" > gpurun_out/${tag}_split_parity.log 2>&1 ;;
