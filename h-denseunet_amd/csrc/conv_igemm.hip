@@ -3475,7 +3475,7 @@ static bool wgrad_halo_ok(const ConvK& k) {
          k.sd == 1 && k.sh == 1 && k.sw == 1 && k.ph == 1 && k.pw == 1 &&
          // (a nearest-neighbour up-sampling in front of the conv is resolved in the tile's addressing: bit 2 of the knob = off)
          ((k.ud | k.uh | k.uw) == 0 || !(g_tuning[HDU_TUNE_NO_HALO] & 4)) &&
-         k.Cin % 32 == 0 && k.We >= 32 &&
+         k.Cin % 8 == 0 && k.We >= (g_tuning[HDU_TUNE_HALO_MIN_W] > 0 ? g_tuning[HDU_TUNE_HALO_MIN_W] : 24) &&      // (swept 32 / 24 / 14: r04_experiment_halo_wgrad_3d.txt)
          // operands through buffer resources with 32-bit byte offsets (tensors of 4 GiB and more take the im2col form)
          k.x_bytes != 0 && (((long long)k.M - 1) * k.ldy + k.Cout) * 2 < (1ll << 32) &&
          (long long)k.N * k.De * k.He * k.We * k.ldx < (1ll << 31) - (long long)(k.He * k.We + k.We + 2) * k.ldx;
@@ -3485,7 +3485,7 @@ static bool wgrad_halo_ok(const ConvK& k) {
 // (>= 2 tiles per workgroup).  Returns the tiles per split.
 static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk) {
   const int tiles = k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32);
-  const unsigned gx = (unsigned)(k.Cin / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
+  const unsigned gx = (unsigned)((k.Cin + 31) / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);      // (a ragged last chunk: zero-filled lanes)
   int want = target / (int)(gx * gy * (unsigned)k.KD);
   if (want < 1) want = 1;
   if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;
@@ -3576,7 +3576,7 @@ extern "C" int hdu_wgrad_plan_shape(const hdu_conv_desc* d, int* variant, uint32
   const int bi = best == 64 ? 0 : (best == 48 ? 1 : 2);
   if (wgrad_halo_ok(k)) {
     *variant = 8 + bi;
-    *tiles = (uint32_t)(k.Cin / 32) * (uint32_t)((k.Cout + best - 1) / best) * (uint32_t)k.KD;
+    *tiles = (uint32_t)((k.Cin + 31) / 32) * (uint32_t)((k.Cout + best - 1) / best) * (uint32_t)k.KD;
     *steps = (uint32_t)(k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32));
   } else {
     const int nct = wgrad_nct(k, best);

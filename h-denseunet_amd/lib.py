@@ -240,6 +240,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(9, int(os.environ["HDU_NO_HALO_FPROP"]))
     if "HDU_NO_HALO" in os.environ:
         lib.hdu_set_tuning(8, int(os.environ["HDU_NO_HALO"]))
+    if "HDU_HALO_MIN_W" in os.environ:
+        lib.hdu_set_tuning(28, int(os.environ["HDU_HALO_MIN_W"]))
     if "HDU_HALO_TARGET" in os.environ:
         lib.hdu_set_tuning(7, int(os.environ["HDU_HALO_TARGET"]))
     if "HDU_MAX_BN" in os.environ:

@@ -88,6 +88,7 @@ int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
                                         workgroup per CU (256), N > 1 = persistent kernel with N workgroups */
 #define HDU_TUNE_NO_PW_BSTAT_BNB 26   /* 1 = a bottleneck data gradient with a fused BN backward takes the tiled kernels (round 3; A/B) */
 #define HDU_TUNE_PERS_MIN_ITEMS 24   /* (m-tile, n-tile) pairs a layer needs to take the persistent form (default 512) */
+#define HDU_TUNE_HALO_MIN_W 28       /* narrowest layer (pixels per row) that takes the halo-tile filter gradient (tiles are 4 x 32 pixels; default 24) */
 #define HDU_TUNE_F32_SPLIT 27        /* float32 convolutions: 0 = exact f32 MFMA (default; the parity mode), 1 = every operand split into bf16
                                         hi + lo and contracted as ah.bh + ah.bl + al.bh on the bf16 MFMA with the float32 accumulator
                                         ("bf16 x 3": <= 3 * 2^-18 relative per product; storage, statistics and every row kernel stay float32) */

@@ -104,6 +104,7 @@ CONV_CASES = [
     # ... and with the decoder's nearest-neighbour up-sampling in front of the conv resolved in the tile addressing
     dict(N=2, D=1, H=5, W=17, Cin=32, Cout=64, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 1, 1), skip=False, pro=False, bias=False, ldin=48, ldout=None, id="halo_tile_up2d"),
     dict(N=1, D=2, H=3, W=16, Cin=32, Cout=24, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(1, 1, 1), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="halo_tile_up222_3d"),
+    dict(N=1, D=1, H=7, W=35, Cin=40, Cout=48, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=56, ldout=None, id="halo_tile_ragged_channel_chunk"),
     dict(N=2, D=3, H=4, W=20, Cin=64, Cout=32, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 1, 1), skip=False, pro=False, bias=False, ldin=None, ldout=48, id="halo_tile_up221_3d"),
     # the filter-stationary pointwise kernel (bf16: K = 192 / 128, no prologue / bias, >= 256 output channels): ragged pixel
     # count, a channel count that is not a multiple of its 128-channel groups, slab input and output
