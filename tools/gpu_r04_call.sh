@@ -41,6 +41,11 @@ for stage in "$@"; do
           > gpurun_out/${tag}_halo3d_shard_$arm.json 2> gpurun_out/${tag}_halo3d_shard_$arm.err
         cp gpurun_out/bench_details.json gpurun_out/${tag}_halo3d_shard_details_$arm.json 2>/dev/null
       done ;;
+    closing_parity)   # the model-level GPU gates of the paths changed last (frozen-BN epilogue in training, halo filter gradients in 3D)
+      timeout 1200 python -m pytest -m gpu -x -q -s tests/test_gpu_parity.py -k "test_full_forward_parity_f32 and end2end" > gpurun_out/${tag}_closing_f32.log 2>&1
+      timeout 1200 python -m pytest -m gpu -x -q -s "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[3dpart]" \
+        "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[end2end]" \
+        "tests/test_gpu_parity_bf16.py::test_bf16_train_step_parity_full_size[3d]" > gpurun_out/${tag}_closing_bf16.log 2>&1 ;;
     split_parity)
       timeout 900 python -m pytest -m gpu -x -q -s tests/test_gpu_parity.py \
         -k "test_f32_absolute_logit_error_from_trained_weights and (2d-denseunet or (3d and not 3dpart))" > gpurun_out/${tag}_split_parity.log 2>&1 ;;
