@@ -3483,12 +3483,13 @@ static bool wgrad_halo_ok(const ConvK& k) {
 
 // work grid of the halo-tile filter gradient: 32-channel chunks x filter-row tiles x splits of the spatial tiles
 // (>= 2 tiles per workgroup).  Returns the tiles per split.
-static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk) {
+static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk, int min_tiles = 2) {
   const int tiles = k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32);
   const unsigned gx = (unsigned)((k.Cin + 31) / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);      // (a ragged last chunk: zero-filled lanes)
   int want = target / (int)(gx * gy * (unsigned)k.KD);
   if (want < 1) want = 1;
-  if (want > (tiles + 1) / 2) want = (tiles + 1) / 2;
+  if (min_tiles < 1) min_tiles = 1;
+  if (want > (tiles + min_tiles - 1) / min_tiles) want = (tiles + min_tiles - 1) / min_tiles;      // every workgroup ends with 9 x 32 x BCO float atomics
   if (want < 1) want = 1;
   const int per = (tiles + want - 1) / want;
   const unsigned gz = (unsigned)((tiles + per - 1) / per) * (unsigned)k.KD;      // (split, depth tap) pairs: wgrad_halo_body
@@ -3553,7 +3554,7 @@ extern "C" int hdu_wgrad_plan_fill(const hdu_conv_desc* d, float* dw, int target
   const int bi = best == 64 ? 0 : (best == 48 ? 1 : 2);
   if (wgrad_halo_ok(k)) {
     const int target = target_wgs > 0 ? target_wgs : (g_tuning[HDU_TUNE_HALO_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_HALO_TARGET_WGS] : 512);
-    e->per = wgrad_halo_geometry(k, best, target, &e->k);
+    e->per = wgrad_halo_geometry(k, best, target, &e->k, min_steps > 0 ? min_steps : 2);      // (batched: min_steps = spatial tiles per workgroup)
     *variant = 8 + bi;
   } else {
     const int target = target_wgs > 0 ? target_wgs : (g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 768);

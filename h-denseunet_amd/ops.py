@@ -200,7 +200,12 @@ class WgradPlan:
         self.steps_of = {}
         for v, w in work.items():
             if v >= 8:
-                self.steps_of[v] = 0                      # halo families: spatial tiles, library default
+                # halo families: `steps` counts 4 x 32-pixel spatial tiles (two 64-pixel steps each); the same whole-launch rule,
+                # 4 ... 64 tiles per workgroup (HDU_WGRAD_HALO_TILES forces a count; 2 = the per-layer sizing of rounds 2-3)
+                ht = os.environ.get("HDU_WGRAD_HALO_TILES")
+                wgs = int(os.environ.get("HDU_WGRAD_LAUNCH_WGS", self.LAUNCH_WGS))
+                self.steps_of[v] = int(ht) if ht else (int(self.min_steps) if self.min_steps is not None
+                                                      else max(4, min(64, (w + wgs - 1) // wgs)))
             elif forced:
                 self.steps_of[v] = int(forced)
             elif self.min_steps is not None:

@@ -227,8 +227,8 @@ int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream);
  *   hdu_wgrad_plan_entry_bytes(): size of one opaque table entry.
  *   hdu_wgrad_plan_fill(): fills ONE host-side entry for (desc, dw) as hdu_conv_wgrad(desc, dw) would run it;
  *     *variant = kernel family of the entry (entries of one family go into one table), *nblocks = workgroups it needs.
- *     target_wgs <= 0: the single-launch default split.  min_steps > 0 (DMA families): every workgroup keeps at least that
- *     many 64-pixel steps -- the caller sizes it from the WHOLE launch (hdu_wgrad_plan_shape of every layer of the family):
+ *     target_wgs <= 0: the single-launch default split.  min_steps > 0: every workgroup keeps at least that many 64-pixel
+ *     steps (DMA families) / 4x32-pixel spatial tiles (halo families) -- the caller sizes it from the WHOLE launch (hdu_wgrad_plan_shape of every layer of the family):
  *     a partial tile costs Cout x 128 float atomics, and in a batched launch the other layers fill the GPU, so a layer needs
  *     far fewer pixel splits than it would alone (measured round 4: 8 -> ~100 steps, 2D step 18.1 -> 17.6 ms).
  *   hdu_wgrad_plan_shape(): *variant as above, *tiles = output tiles of the layer (workgroups per pixel split), *steps = its
