@@ -2319,7 +2319,9 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
   // (kh, kw) taps are a 2D filter gradient between those planes.  The planes of the volume are the "images" here, the splits
   // of the spatial tiles come in KD groups (wbz = split * KD + kd: the three workgroups of a split are neighbours in the
   // launch order and share the dy tiles and two of their three x planes in L2), planes outside the volume load as zeros.
-  const int KDn = p.KD, Dn = p.De;
+  // (depth "same": pd = 1, as many input as output planes; depth "valid": pd = 0 and two more input planes -- the depth-sharded
+  // layers, whose halo planes are part of the stored input)
+  const int KDn = p.KD, Dn = p.Do, Dx = p.De;
   const int kd = (int)(wbz % (unsigned)KDn);
   const int xshift = kd - p.pd;                           // input plane = output plane + xshift (2D: 0)
   const int tap0 = kd * 9;
@@ -2374,7 +2376,7 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
     char* Xh = smem + buf * STAGE;
     char* Dt = Xh + XBYTES;
     const int y0 = l_ty * TH, x0 = l_tx * TW;
-    const bool plane_ok = (unsigned)(l_d + xshift) < (unsigned)Dn;
+    const bool plane_ok = (unsigned)(l_d + xshift) < (unsigned)Dx;
     const int xplane = l_v * p.Di + ((l_d + xshift) >> p.ud);                           // stored input plane
     const int xbase = ((xplane * p.Hi + (y0 >> p.uh)) * p.Wi + (x0 >> p.uw)) * (int)p.ldx;       // valid pixels give >= 0 sums
 #pragma unroll
@@ -3470,7 +3472,8 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
 static bool wgrad_halo_ok(const ConvK& k) {
   // 2D 3 x 3 "same" layers, and (round 4, HDU_TUNE_NO_HALO bit 1 = off) 3 x 3 x 3 "same" layers as three plane-shifted 2D problems
   const bool d2 = k.KD == 1 && k.pd == 0 && k.Di == 1;
-  const bool d3 = k.KD == 3 && k.pd == 1 && k.Do == k.De && !(g_tuning[HDU_TUNE_NO_HALO] & 2);
+  const bool d3 = k.KD == 3 && ((k.pd == 1 && k.Do == k.De) || (k.pd == 0 && k.Do == k.De - 2)) && k.Ho == k.He && k.Wo == k.We &&
+                  !(g_tuning[HDU_TUNE_NO_HALO] & 2);
   return !(g_tuning[HDU_TUNE_NO_HALO] & 1) && k.pro_a == nullptr && k.skip == nullptr && (d2 || d3) && k.KH == 3 && k.KW == 3 &&
          k.sd == 1 && k.sh == 1 && k.sw == 1 && k.ph == 1 && k.pw == 1 &&
          // (a nearest-neighbour up-sampling in front of the conv is resolved in the tile's addressing: bit 2 of the knob = off)
@@ -3484,7 +3487,7 @@ static bool wgrad_halo_ok(const ConvK& k) {
 // work grid of the halo-tile filter gradient: 32-channel chunks x filter-row tiles x splits of the spatial tiles
 // (>= 2 tiles per workgroup).  Returns the tiles per split.
 static int wgrad_halo_geometry(const ConvK& k, int BCO, int target, ConvK* kk, int min_tiles = 2) {
-  const int tiles = k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32);
+  const int tiles = k.N * k.Do * ((k.He + 3) / 4) * ((k.We + 31) / 32);
   const unsigned gx = (unsigned)((k.Cin + 31) / 32), gy = (unsigned)((k.Cout + BCO - 1) / BCO);      // (a ragged last chunk: zero-filled lanes)
   int want = target / (int)(gx * gy * (unsigned)k.KD);
   if (want < 1) want = 1;
@@ -3578,7 +3581,7 @@ extern "C" int hdu_wgrad_plan_shape(const hdu_conv_desc* d, int* variant, uint32
   if (wgrad_halo_ok(k)) {
     *variant = 8 + bi;
     *tiles = (uint32_t)((k.Cin + 31) / 32) * (uint32_t)((k.Cout + best - 1) / best) * (uint32_t)k.KD;
-    *steps = (uint32_t)(k.N * k.De * ((k.He + 3) / 4) * ((k.We + 31) / 32));
+    *steps = (uint32_t)(k.N * k.Do * ((k.He + 3) / 4) * ((k.We + 31) / 32));
   } else {
     const int nct = wgrad_nct(k, best);
     *variant = nct == 3 ? 6 : (nct == 2 ? 7 : bi * 2 + (wgrad_pointwise(k) ? 1 : 0));
