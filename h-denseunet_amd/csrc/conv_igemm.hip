@@ -3472,7 +3472,9 @@ static void launch_wgrad_tr(const ConvK& k, float* dw, hipStream_t s) {
 static bool wgrad_halo_ok(const ConvK& k) {
   // 2D 3 x 3 "same" layers, and (round 4, HDU_TUNE_NO_HALO bit 1 = off) 3 x 3 x 3 "same" layers as three plane-shifted 2D problems
   const bool d2 = k.KD == 1 && k.pd == 0 && k.Di == 1;
-  const bool d3 = k.KD == 3 && ((k.pd == 1 && k.Do == k.De) || (k.pd == 0 && k.Do == k.De - 2)) && k.Ho == k.He && k.Wo == k.We &&
+  // depth: "same" (pd 1), "valid" over stored halo planes (pd 0: the depth-sharded layers), or valid behind a depth up-sampling of
+  // the stored halo planes (pd -1: their decoder) -- input plane = output plane + kd - pd in every case
+  const bool d3 = k.KD == 3 && k.pd >= -1 && k.pd <= 1 && k.Do == k.De + 2 * k.pd - 2 && k.Ho == k.He && k.Wo == k.We &&
                   !(g_tuning[HDU_TUNE_NO_HALO] & 2);
   return !(g_tuning[HDU_TUNE_NO_HALO] & 1) && k.pro_a == nullptr && k.skip == nullptr && (d2 || d3) && k.KH == 3 && k.KW == 3 &&
          k.sd == 1 && k.sh == 1 && k.sw == 1 && k.ph == 1 && k.pw == 1 &&

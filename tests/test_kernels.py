@@ -75,6 +75,9 @@ def ref_xeff(x, up, skip, pro, relu, dtype):
 
 
 def ref_conv(xe, w, stride, pad, bias):
+    if pad[0] < 0:          # negative depth padding = the outer planes are cropped (depth-sharded decoder layers: engine.ConvLayer halo mode)
+        xe = xe[:, -pad[0]:xe.shape[1] + pad[0]]
+        pad = (0, pad[1], pad[2])
     y = F.conv3d(xe.permute(0, 4, 1, 2, 3), w.permute(0, 4, 1, 2, 3), stride=stride, padding=pad)
     y = y.permute(0, 2, 3, 4, 1)
     if bias is not None:
@@ -103,6 +106,7 @@ CONV_CASES = [
     dict(N=2, D=2, H=5, W=32, Cin=64, Cout=40, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=True, ldin=80, ldout=56, id="halo_tile_3d_two_volumes_slab"),
     # depth "valid" (pad 0 in depth, two more input than output planes): the depth-sharded layers, whose halo planes are stored
     dict(N=2, D=4, H=5, W=33, Cin=32, Cout=48, K=(3, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 0, 0), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="halo_tile_3d_valid_depth"),
+    dict(N=1, D=3, H=3, W=16, Cin=32, Cout=24, K=(3, 3, 3), s=(1, 1, 1), p=(-1, 1, 1), up=(1, 1, 1), skip=False, pro=False, bias=False, ldin=None, ldout=None, id="halo_tile_3d_sharded_decoder"),
     # ... and with the decoder's nearest-neighbour up-sampling in front of the conv resolved in the tile addressing
     dict(N=2, D=1, H=5, W=17, Cin=32, Cout=64, K=(1, 3, 3), s=(1, 1, 1), p=(0, 1, 1), up=(0, 1, 1), skip=False, pro=False, bias=False, ldin=48, ldout=None, id="halo_tile_up2d"),
     dict(N=1, D=2, H=3, W=16, Cin=32, Cout=24, K=(3, 3, 3), s=(1, 1, 1), p=(1, 1, 1), up=(1, 1, 1), skip=False, pro=False, bias=True, ldin=None, ldout=None, id="halo_tile_up222_3d"),
