@@ -165,6 +165,34 @@ def test_batched_filter_gradients_equal_per_layer_launches(emu_lib):
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("kind,variant,b,size,cols", [("3d", "3dpart", 1, 32, 8), ("2d", "denseunet", 2, 32, None)])
+def test_halo_tile_filter_gradients_equal_im2col_form(emu_lib, kind, variant, b, size, cols):
+    """Round 4: 3 x 3 x 3 layers and convs behind a fused up-sampling take the halo-tile filter gradient (three plane-shifted
+    2D problems / the up-sampling resolved in the tile addressing).  bf16 training step of the 3D net and of the 2D net
+    (conv_up4): same flat gradient as with those layers on the im2col form (HDU_TUNE_NO_HALO bits 1 + 2), and the halo families
+    of the plan really hold such layers."""
+    lib = emu_lib.lib.get()
+    grads, fams = [], []
+    try:
+        for off in (0, 6):
+            lib.hdu_set_tuning(8, off)
+            m = U.build_pair(kind, variant, b, size, cols, "bf16", NB2D, NB3D)[0]
+            m.ctx.dropout_enabled = False
+            lossf = U.pkg("loss").weighted_crossentropy if kind != "2d" else U.pkg("loss").weighted_crossentropy_2ddense
+            m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[lossf])
+            x, y = U.synthetic_batch(kind, b, size, cols)
+            m.train_on_batch(x, y)
+            grads.append(m.ctx.G[:m.ctx.n_trainable].clone())
+            plan = m.ctx.wgrad_plan
+            fams.append(sum(1 for v, ds in plan.descs.items() if v >= 8 for d in ds if d.KD == 3 or (d.ud | d.uh | d.uw)))
+    finally:
+        lib.hdu_set_tuning(8, 0)
+    assert fams[0] >= 1 and fams[1] == 0, fams
+    a, c = grads
+    assert float(c.abs().max()) > 0
+    assert float((a - c).abs().max()) <= 1e-4 * float(c.abs().max())
+
+
 def test_epilogue_statistics_equal_reduction_pass(emu_lib, monkeypatch):
     """second training step (the first one primes the shift): batch statistics taken in the conv epilogues give the same
     logits, loss and gradient as the separate reduction pass (HDU_EPILOGUE_STATS=0).  64x64, batch 2: at 32x32 the
