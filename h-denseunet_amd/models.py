@@ -15,6 +15,14 @@ from .engine import AvgPoolLayer, BNLayer, ConvLayer, MaterializeLayer, MaxPoolL
 EPS_DENSE = 1.1e-5
 
 
+def _FORCE_HALO():
+    """HDU_FORCE_DEPTH_HALO=1 (tests / timing): a world-1 ShardInfo builds the depth-halo form of the network as well -- every
+    3D layer over an input that stores its halo planes, which stay zero without neighbours, i.e. the unsharded network computed
+    by the sharded launch list"""
+    import os
+    return os.environ.get("HDU_FORCE_DEPTH_HALO") == "1"
+
+
 def _stats(ctx, var, mode):
     """returns the StatsOp (or None) so that a unique consumer BN can be fused into it"""
     if mode == "batch":
@@ -141,7 +149,7 @@ def build_dense_net_3d(ctx, x_in, variant="3dpart", reduction=0.5, nb_layers=(3,
     N, D, H, W = a.N, a.D, a.H, a.W
     assert H % 32 == 0 and W % 32 == 0 and D % 4 == 0, "H,W multiples of 32 and D a multiple of 4 (SURVEY.md A.2)"
     nb_filter = 96
-    sharded = ctx.shard is not None and ctx.shard.world > 1
+    sharded = ctx.shard is not None and (ctx.shard.world > 1 or _FORCE_HALO())
     hl = 1 if sharded else 0      # depth halo of every 3x3x3 conv / of the max pool; the 7x7x7 stride-2 stem needs 3
     if sharded:
         assert D % 4 == 0, "local depth must be a multiple of 4"
@@ -254,7 +262,7 @@ def as3d(ctx, v2d):
 def build_hybrid(ctx, vol, D, H, W, variant="3dpart", nb_layers2d=(6, 12, 36, 24), nb_layers3d=(3, 4, 12, 8)):
     """vol: float32 device tensor [D][H][W].  Returns logits Var [1][D][H][W][cpad(3)]."""
     dt = ctx.dtype
-    sharded = ctx.shard is not None and ctx.shard.world > 1
+    sharded = ctx.shard is not None and (ctx.shard.world > 1 or _FORCE_HALO())
     hl = 1 if sharded else 0
     if sharded:
         # depth-sharded hybrid (SURVEY.md section 8e, third row): this rank holds D planes of the volume plus ONE raw CT

@@ -193,6 +193,45 @@ def test_halo_tile_filter_gradients_equal_im2col_form(emu_lib, kind, variant, b,
     assert float((a - c).abs().max()) <= 1e-4 * float(c.abs().max())
 
 
+def test_depth_halo_form_world1_equals_unsharded_and_its_halo_filter_gradients(emu_lib, monkeypatch):
+    """The depth-sharded launch list in ONE process (HDU_FORCE_DEPTH_HALO=1, world-1 ShardInfo: every 3D layer over an input that
+    stores its halo planes, which stay zero without neighbours = the unsharded network).  float32: logits / loss / gradients of
+    the halo form equal the unsharded net's.  bf16: the halo form's 3 x 3 x 3 filter gradients on the halo-tile kernel (depth
+    "valid", and depth padding -1 behind the decoder's depth up-sampling) equal the im2col form's."""
+    shard_mod = U.pkg("shard")
+    ctor = U.pkg("densenet3d_sharded").dense_net3d
+    lib = emu_lib.lib.get()
+    x, y = U.synthetic_batch("hybrid", 1, 32, 8, seed=5)
+    x = np.concatenate([x, np.random.default_rng(3).normal(0, 60, x.shape[:4] + (3,)).astype(np.float32)], -1)   # 4 input channels
+
+    def step(dtype, halo, no_halo_wgrad=0):
+        monkeypatch.setenv("HDU_FORCE_DEPTH_HALO", "1" if halo else "0")
+        lib.hdu_set_tuning(8, no_halo_wgrad)
+        try:
+            m = ctor(U.make_args(1, 32, 8), dtype=dtype, nb_layers3d=NB3D, seed=9,
+                     shard=shard_mod.ShardInfo(0, 1) if halo else None)
+            assert any(cv.halo for cv in m.ctx.convs) == halo
+            m.ctx.dropout_enabled = False
+            m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy])
+            loss = m.train_on_batch(x, y)
+            fam = 0
+            if m.ctx.wgrad_plan is not None:
+                fam = sum(1 for v, ds in m.ctx.wgrad_plan.descs.items() if v >= 8 for d in ds if d.KD == 3 and d.pd <= 0)
+            return loss, m._download_logits().cpu().numpy(), m.ctx.G[:m.ctx.n_trainable].clone(), fam
+        finally:
+            lib.hdu_set_tuning(8, 0)
+
+    l_h, z_h, g_h, _ = step("f32", True)
+    l_u, z_u, g_u, _ = step("f32", False)
+    assert float(np.abs(z_h - z_u).max()) <= 1e-4 * max(1.0, float(np.abs(z_u).max()))
+    assert abs(l_h - l_u) <= 1e-5 * abs(l_u)
+    assert float((g_h - g_u).norm() / g_u.norm()) <= 1e-3
+    _, _, g_on, fam_on = step("bf16", True)
+    _, _, g_off, fam_off = step("bf16", True, no_halo_wgrad=1)
+    assert fam_on >= 1 and fam_off == 0, (fam_on, fam_off)
+    assert float((g_on - g_off).abs().max()) <= 1e-4 * float(g_off.abs().max())
+
+
 def test_epilogue_statistics_equal_reduction_pass(emu_lib, monkeypatch):
     """second training step (the first one primes the shift): batch statistics taken in the conv epilogues give the same
     logits, loss and gradient as the separate reduction pass (HDU_EPILOGUE_STATS=0).  64x64, batch 2: at 32x32 the
