@@ -85,3 +85,18 @@ def test_bench_world2_guarded_shard3d_watchdog(emu_lib):
     assert rec["value"] > 0 and rec["n_gpus"] == 2
     ex = rec["config"]["extra_workloads"]
     assert len(ex) == 1 and "watchdog" in ex[0]["error"]
+
+
+def test_bench_dryrun_float32_split_contraction_extra(emu_lib):
+    """the `2d:f32x3` extra workload (float32 storage, split-bf16 contraction switched on for that workload only) through
+    bench.py's own control flow on CPU: both float32 lines are reported, labelled, and the mode is switched back afterwards"""
+    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "1", "--size", "32",
+           "--extras", "2d:f32x3,2d:f32"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    ex = rec["config"]["extra_workloads"]
+    assert [e["dtype"] for e in ex] == ["f32x3", "f32"] and all(e["value"] > 0 for e in ex)
