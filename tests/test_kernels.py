@@ -709,6 +709,48 @@ def test_conv_fused_bn_backward_from_output(hdu, cs, dtype):
     assert float((S[1] - S2_u).abs().max()) <= (1e-4 if dtype == F32 else 2e-2) * sc
 
 
+def test_conv_fused_bn_backward_from_output_dead_channel(hdu):
+    """bnb_relu bit 1 with a channel whose folded scale a is exactly 0 (a dead Scale gamma): z = relu(b) carries no information
+    about the BN input, so that channel's S2 is defined as 0 -- and nothing may turn into NaN / Inf (rstd / a is guarded)."""
+    import ctypes
+    ops = ops_mod()
+    N, D, H, W, Cdy, Cu, K, p = 1, 1, 10, 12, 48, 64, (1, 3, 3), (0, 1, 1)
+    dy = rnd((N, D, H, W, Cdy), 1, 1.0, F32)
+    w = rnd((Cu,) + K + (Cdy,), 5, 1.0 / np.sqrt(9 * Cdy), F32)
+    u = rnd((N, D, H, W, Cu), 7, 1.0, F32)
+    a = (rnd((Cu,), 9, 1.0).abs() + 0.3).float().double()
+    a[5] = 0.0
+    a[40] = 0.0
+    b = rnd((Cu,), 10, 0.4).float().double()
+    b[5] = 0.25                                          # relu(b) > 0: the mask is open on the dead channel
+    mean = rnd((Cu,), 11, 0.3).float().double()
+    rstd = (rnd((Cu,), 12, 0.5).abs() + 0.5).float().double()
+    z = q((a * u + b).clamp_min(0), F32)
+    dya, za = mkact(ops, dy, F32), mkact(ops, z, F32)
+    outa = ops.Act.alloc(N, D, H, W, Cu, F32)
+    wt = w.float().contiguous().to(ops.device())
+    slots = 3
+    keep = [dev(ops, t) for t in (a, b, mean, rstd)]
+    partial = torch.zeros(slots * 2 * Cu, dtype=torch.float32, device=ops.device())
+    d = ops.conv_desc(dya, ctypes.c_void_p(wt.data_ptr()), outa, K, (1, 1, 1), p)
+    d.bnb_u, d.bnb_ldu = za.ptr, za.ld
+    d.bnb_a, d.bnb_b, d.bnb_relu = keep[0].data_ptr(), keep[1].data_ptr(), 3
+    d.bnb_mean, d.bnb_rstd, d.bnb_partial, d.bnb_slots = keep[2].data_ptr(), keep[3].data_ptr(), partial.data_ptr(), slots
+    ops.conv_fprop(d)
+    out = outa.to_torch().cpu().double()
+    S = partial.cpu().double().reshape(slots, 2, Cu).sum(0)
+    assert torch.isfinite(out).all() and torch.isfinite(S).all()
+    assert float(out[..., 5].abs().max()) == 0.0 and float(out[..., 40].abs().max()) == 0.0
+    assert float(S[1, 5]) == 0.0 and float(S[1, 40]) == 0.0
+    dz = ref_conv(dy, w, (1, 1, 1), p, None)
+    g = torch.where(z > 0, dz, torch.zeros_like(dz))
+    assert abs(float(S[0, 5]) - float(g[..., 5].sum())) <= 2e-5 * float(g[..., 5].abs().sum())     # S1 of the dead channel is still the masked sum
+    live = [c for c in range(Cu) if c not in (5, 40)]
+    uhat = (z - (b + a * mean)) * torch.where(a != 0, rstd / torch.where(a != 0, a, torch.ones_like(a)), torch.zeros_like(a))
+    S2 = (g * uhat).reshape(-1, Cu).sum(0)
+    assert float((S[1][live] - S2[live]).abs().max()) <= 2e-5 * float(S2[live].abs().max())
+
+
 SPLITK_CASES = [
     # dense-block shapes whose output grid cannot fill the chip (include/hdu.h, hdu_conv_desc.splitk_ws)
     dict(N=2, D=1, H=16, W=15, Cin=192, Cout=48, K=(1, 3, 3), p=(0, 1, 1), bias=False, ldout=96, id="block5_3x3_192to48"),
