@@ -314,6 +314,50 @@ def test_conv_wgrad(hdu, cs, dtype):
     assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
 
 
+def _halo_geometries():
+    rng = np.random.default_rng(20260925)
+    out = []
+    while len(out) < 24:
+        three_d = bool(rng.integers(0, 3))            # two thirds 3D
+        up = tuple(int(v) for v in rng.integers(0, 2, 3)) if rng.integers(0, 3) == 0 else (0, 0, 0)
+        if not three_d:
+            up = (0, up[1], up[2])
+        N, D = int(rng.integers(1, 3)), (int(rng.integers(1, 5)) if three_d else 1)
+        H, W = int(rng.integers(2, 8)), int(rng.integers(12, 21)) if up[2] else int(rng.integers(24, 41))
+        Cin, Cout = int(rng.choice([8, 16, 40, 64, 104])), int(rng.choice([8, 24, 48, 72]))
+        pd = 1
+        if three_d:
+            pd = int(rng.choice([1, 0, -1])) if up[0] else int(rng.choice([1, 0]))
+            De = D << up[0]
+            if De + 2 * pd - 2 < 1:
+                continue
+        out.append(dict(N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, K=(3, 3, 3) if three_d else (1, 3, 3), s=(1, 1, 1),
+                        p=(pd if three_d else 0, 1, 1), up=up, skip=False, pro=False, bias=False,
+                        ldin=(Cin + 16 if rng.integers(0, 2) else None), ldout=None, id="geo%d" % len(out)))
+    return out
+
+
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in _halo_geometries()])
+def test_halo_filter_gradient_random_geometries(hdu, cs):
+    """seeded sweep over the geometry space of the halo-tile filter gradient (2D / 3D, depth same / valid / cropped behind a depth
+    up-sampling, up-sampling per axis, ragged tiles in H and W, ragged channel chunks, several volumes, slab inputs): every case
+    must take the halo kernel and match the float64 reference"""
+    import ctypes
+    ops = ops_mod()
+    b = build_conv_case(ops, cs, BF16, seed=700)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    dy = rnd((N, Do, Ho, Wo, Cout), 779, 1.0, BF16)
+    dya = mkact(ops, dy, BF16)
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, None)
+    assert ops.conv_kernel_name(d, 1).startswith("conv_wgrad_halo_kernel"), (cs, ops.conv_kernel_name(d, 1))
+    dw = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+    ops.conv_wgrad(d, dw)
+    xe = ref_xeff(b["x"], cs["up"], None, None, True, BF16).requires_grad_(True)
+    wref = b["w"].clone().requires_grad_(True)
+    (ref_conv(xe, wref, cs["s"], cs["p"], None) * dy).sum().backward()
+    assert_close(dw.cpu(), wref.grad, BF16, what="halo wgrad %s" % (cs,))
+
+
 SPLIT_CASES = [c for c in CONV_CASES if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "decoder_up_skip_2d", "dense3x3x3", "stem7x7s2",
                                                      "wide_bn128", "pw_pro_two_stage", "pw_pro_wide_table_splitk")]
 
