@@ -1,0 +1,419 @@
+// conv_halo_wide.hip -- halo-tile forward / data-gradient kernel for the WIDE 3x3 and 3x3x3 stride-1 "same" convolutions
+// (bf16): the decoder layers conv_up0..4 (denseunet.py:189-218), 3dconv_up0..4 / fianl_conv (denseunet3d.py:158-184,430) and
+// their data gradients -- the launches that the im2col implicit GEMM (conv_igemm.hip) runs at 0.19-0.31 of the MFMA roof
+// because it re-loads every input pixel once per tap.
+//
+// Work decomposition.  A workgroup owns TH x 32 output pixels of ONE output plane (image n, depth od) and BN = 32 * NT output
+// channels.  The contraction is walked in stages of (depth tap kd, 16 input channels): per stage ONE async DMA of the
+// (TH + 2) x 34 halo tile of input plane od + kd - pd (32 B per pixel) and of the filter rows' 9 in-plane taps for these 16
+// channels (288 B per output channel); the 9 taps are then formed from LDS -- the A fragment of tap (kh, kw) is the halo
+// tile read at a shifted pixel window.  Per MAC the L2 -> LDS traffic is 3-6 x below the im2col tiling's (e.g. TH = 8,
+// BN = 128: 47 KB per 4.7 M MACs against 32 KB per 1.0 M).  A depth tap whose plane lies outside the volume is skipped, not
+// loaded as zeros.  The decoder's nearest-neighbour up-sampling in front of the conv is address arithmetic of the halo-tile
+// DMA (stored pixel = effective pixel >> u per axis).
+//
+// MFMA: v_mfma_f32_32x32x16_bf16 -- its k extent IS the 16-channel stage, and a 32 x 32 fragment needs half the LDS operand
+// reads per FLOP of the 16 x 16 x 32 form.  Operands are swapped (D rows = output channels, D columns = pixels) so that a lane
+// holds 4 consecutive output channels of one pixel per accumulator quad (8-byte LDS stores in the epilogue).
+//
+// LDS: NS ring stages of [halo tile | filter tile], lane-linear 1-KiB DMA pieces; the two 16-byte chunks of a 32-byte row are
+// swapped on odd 8-row groups (chunk ^ ((row >> 3) & 1)) so that the 16 lanes of a ds_read_b128 group hit 16 distinct bank
+// slots for every tap shift.  One counted s_waitcnt + one raw barrier per stage (the ring of conv_igemm_ring_kernel).
+#include "conv_common.h"
+#include "hdu_host.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 hdu_mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef HDU_EMU
+  return hipemu_mfma_32x32x16_bf16(__builtin_bit_cast(hipemu_u16x8, a), __builtin_bit_cast(hipemu_u16x8, b), c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hdu_bf16x8, a), __builtin_bit_cast(hdu_bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+template <int N> __device__ __forceinline__ void hw_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+#ifndef HDU_EMU
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+#endif
+}
+
+template <int TH_, int NT_, int WAVES_M_, int WAVES_N_, int NS_> struct HaloWide {
+  static constexpr int TH = TH_, NT = NT_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NS = NS_;
+  static constexpr int NW = WAVES_M * WAVES_N, NTHR = NW * 64;
+  static constexpr int TW = 32, HC = TW + 2, HR = TH + 2, HP = HR * HC;   // halo tile: HR rows of HC pixels
+  static constexpr int BN = NT * 32, BM = TH * TW;
+  static constexpr int XI = (HP * 2 + 63) / 64;            // 1-KiB DMA pieces of the halo tile (2 chunks per pixel)
+  static constexpr int WI = (BN * 18 + 63) / 64;           // ... of the filter tile (9 taps x 2 chunks per row)
+  static constexpr int LPW = (XI + WI + NW - 1) / NW;      // pieces per wave and stage (the last round is padded: counted vmcnt)
+  static constexpr int STAGE = LPW * NW * 1024;
+  static constexpr int XBYTES = XI * 1024;
+  static constexpr int ROWB = BN * 2 + 16;                 // staged output row (+16 B: consecutive rows start on different banks)
+  static constexpr int SMEM = NS * STAGE > BM * ROWB ? NS * STAGE : BM * ROWB;
+  static constexpr int MT = TH / WAVES_M, NTW = NT / WAVES_N;   // 32 x 32 fragments per wave: tile rows x channel groups
+  static_assert(TH % WAVES_M == 0 && NT % WAVES_N == 0, "wave layout");
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  static_assert((NS - 2) * LPW < 64, "vmcnt");
+};
+
+// per-channel moments of the staged output tile (ConvK::stats_partial): epilogue_stats of conv_igemm.hip for NTHR threads and
+// halo-tile rows (tile pixel -> image pixel validity), rows requested 8 at a time
+template <typename C, typename RowValid>
+__device__ __forceinline__ void hw_epilogue_stats(const ConvK& p, const char* smem, int n0, int tid, unsigned slot, RowValid valid) {
+  constexpr int NCC = C::BN / 8, CPI = C::NTHR / 16;
+  float* dst = p.stats_partial + (long long)(slot % (unsigned)p.stats_slots) * 2 * p.Cout;
+  const int rl = tid & 15;
+#pragma unroll 1
+  for (int it = 0; it < (NCC + CPI - 1) / CPI; ++it) {      // every lane takes every trip (the row sum is wave-wide)
+    const int cc = (tid >> 4) + it * CPI;
+    const int nbase = n0 + cc * 8;
+    const bool col = cc < NCC && nbase < p.Cout;
+    const int ccq = col ? cc : 0, nc = col ? nbase : 0;
+    float s1[8], s2[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; j += 4) {
+      const f32x4 v4 = *(const f32x4*)(p.stats_shift + nc + j);
+      sh[j] = v4[0]; sh[j + 1] = v4[1]; sh[j + 2] = v4[2]; sh[j + 3] = v4[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll 1
+    for (int q0 = 0; q0 < C::BM / 16; q0 += 8) {
+      u32x4 rv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rv[q] = *(const u32x4*)(smem + (rl + (q0 + q) * 16) * C::ROWB + ccq * 16);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float keep = (col && valid(rl + (q0 + q) * 16)) ? 1.f : 0.f;
+        float f[8];
+        Chunk<bf16_t>::unpack(rv[q], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = (f[j] - sh[j]) * keep; s1[j] += d; s2[j] += d * d; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = hdu_row16_sum(s1[j]); s2[j] = hdu_row16_sum(s2[j]); }
+    float mine = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mine = rl == j ? s1[j] : mine;
+      mine = rl == 8 + j ? s2[j] : mine;
+    }
+    if (col) atomicAdd(dst + (rl < 8 ? 0 : p.Cout) + nbase + (rl & 7), mine);
+  }
+}
+
+template <typename C>
+__global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int tiles_x, int tiles_y, int ngroups) {
+  typedef bf16_t T;
+  constexpr int TH = C::TH, HC = C::HC, HP = C::HP, BN = C::BN, BM = C::BM, NW = C::NW, NTHR = C::NTHR, NS = C::NS;
+  constexpr int XI = C::XI, WI = C::WI, LPW = C::LPW, STAGE = C::STAGE, XBYTES = C::XBYTES, ROWB = C::ROWB;
+  constexpr int MT = C::MT, NTW = C::NTW;
+  __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+  const T* __restrict__ xp = (const T*)p.x;
+  const int He = p.He, We = p.We;
+
+  // workgroup -> (channel group, output plane, tile): channel groups fastest (they share the halo tiles), then the planes of
+  // one tile position (neighbouring planes share two of their three input planes); each XCD walks a contiguous range
+  unsigned t = (p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int ng = (int)(t % (unsigned)ngroups); t /= (unsigned)ngroups;
+  const int od = (int)(t % (unsigned)p.Do); t /= (unsigned)p.Do;
+  const int txi = (int)(t % (unsigned)tiles_x); t /= (unsigned)tiles_x;
+  const int tyi = (int)(t % (unsigned)tiles_y);
+  const int n = (int)(t / (unsigned)tiles_y);
+  const int y0 = tyi * TH, x0 = txi * C::TW;
+  const int n0 = ng * BN;
+
+  // ---- fixed DMA roles of this lane: piece jj = j * NW + wave; pieces [0, XI) are the halo tile, [XI, XI + WI) the filters
+  unsigned roff[LPW];                // byte offset inside the input plane / the filter (stage-independent part); HDU_OOB = zeros
+  int rlc[LPW];                      // first channel of the lane's 16-byte chunk inside the 16-channel stage (0 / 8)
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int jj = j * NW + wave;
+    if (jj < XI) {
+      const int q = jj * 64 + lane;
+      const int hp = q >> 1;
+      const int lc = (q & 1) ^ ((hp >> 3) & 1);
+      const int hr = hp / HC, hc = hp - hr * HC;
+      const int iy = y0 - 1 + hr, ix = x0 - 1 + hc;
+      const bool ok = hp < HP && (unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We;
+      roff[j] = ok ? (unsigned)(((iy >> p.uh) * p.Wi + (ix >> p.uw)) * (int)p.ldx + lc * 8) * 2u : HDU_OOB;
+      rlc[j] = lc * 8;
+    } else if (jj < XI + WI) {
+      const int q = (jj - XI) * 64 + lane;
+      const int row = q / 18, rem = q - row * 18;
+      const int tap = rem >> 1;
+      const int lc = (rem & 1) ^ ((row >> 3) & 1);
+      const int co = n0 + row;
+      const bool ok = row < BN && co < p.Cout;
+      roff[j] = ok ? (unsigned)((co * p.KD * 9 + tap) * p.Cin + lc * 8) * 2u : HDU_OOB;
+      rlc[j] = lc * 8;
+    } else {
+      roff[j] = HDU_OOB;
+      rlc[j] = 0;
+    }
+  }
+  const hdu_bufsrd wsrd = hdu_make_srd(p.w, p.w_bytes);
+  const long long plane_elems = (long long)p.Hi * p.Wi * p.ldx;
+  const unsigned plane_bytes = (unsigned)((((long long)p.Hi * p.Wi - 1) * p.ldx + p.Cin) * 2);
+
+  auto issue = [&](int slot, int kd, int c0) {
+    char* base = smem + slot * STAGE;
+    const int pz = od + kd - p.pd;                            // effective input plane (inside the volume: see kd_lo / kd_hi)
+    const T* plane = xp + (long long)(n * p.Di + (pz >> p.ud)) * plane_elems + c0;
+    const hdu_bufsrd xsrd = hdu_make_srd(plane, plane_bytes - (unsigned)c0 * 2u);
+    const unsigned woff = (unsigned)(kd * 9 * p.Cin + c0) * 2u;
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      const int jj = j * NW + wave;
+      const bool ok = roff[j] != HDU_OOB && c0 + rlc[j] < p.Cin;    // (a ragged last stage: channels >= Cin read as zeros on both sides)
+      if (jj < XI) hdu_bufload_lds16(xsrd, ok ? roff[j] : HDU_OOB, base + jj * 1024);
+      else hdu_bufload_lds16(wsrd, ok ? roff[j] + woff : HDU_OOB, base + jj * 1024);
+    }
+  };
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // stages: depth taps whose plane lies inside the volume x 16-channel chunks
+  const int kd_lo = p.pd - od > 0 ? p.pd - od : 0;
+  const int kd_hi = p.De + p.pd - od < p.KD ? p.De + p.pd - od : p.KD;
+  const int nch = (p.Cin + 15) >> 4;
+  const int nst = kd_hi > kd_lo ? (kd_hi - kd_lo) * nch : 0;
+  int ikd = kd_lo, ic = 0;                                    // the next stage to issue
+  auto issue_next = [&](int slot) {
+    issue(slot, ikd, ic * 16);
+    if (++ic == nch) { ic = 0; ++ikd; }
+  };
+#pragma unroll
+  for (int pre = 0; pre < NS - 1; ++pre)
+    if (pre < nst) issue_next(pre);
+
+  // per-lane fragment addressing
+  const int l31 = lane & 31, lh = lane >> 5;
+  int wrow_off[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int row = (wn * NTW + j) * 32 + l31;
+    wrow_off[j] = XBYTES + row * 288 + ((lh ^ ((row >> 3) & 1)) << 4);
+  }
+  const int hp_base = wm * MT * HC + l31;
+
+  int slot = 0;
+  for (int s = 0; s < nst; ++s) {
+    const int ahead = nst - 1 - s;                            // stages issued beyond s: min(NS - 2, ahead) may stay in flight
+    if (ahead >= NS - 2) hw_wait_vmcnt<(NS - 2) * LPW>();
+    else if (NS > 3 && ahead == 1) hw_wait_vmcnt<(NS > 3 ? LPW : 0)>();
+    else hw_wait_vmcnt<0>();
+    HDU_RAW_BARRIER();
+    if (s + NS - 1 < nst) issue_next(slot == 0 ? NS - 1 : slot - 1);
+    const char* Xs = smem + slot * STAGE;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      u32x4 af[MT], bf[NTW];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int hp = hp_base + (i + kh) * HC + kw;
+        af[i] = *(const u32x4*)(Xs + hp * 32 + ((lh ^ ((hp >> 3) & 1)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bf[j] = *(const u32x4*)(Xs + wrow_off[j] + tap * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = hdu_mfma_32x32x16_bf16(bf[j], af[i], acc[i][j]);
+    }
+    slot = slot == NS - 1 ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: bias / dropout / output affine in registers, the tile through LDS, 16-byte row stores
+  __syncthreads();                                            // every wave is done with the operand stages (all DMAs have landed)
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
+  const long long mplane = ((long long)n * p.Do + od) * p.Ho;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    f32x4 bias_v[4], epa_v[4], epb_v[4];                      // unconditional loads at a clamped channel (see igemm_epilogue)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nn = n0 + (wn * NTW + j) * 32 + 8 * g + 4 * lh;
+      const int nc = nn < p.Cout ? nn : 0;
+      bias_v[g] = has_bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      epa_v[g] = has_epi ? *(const f32x4*)(p.epi_a + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+      epb_v[g] = has_epi ? *(const f32x4*)(p.epi_b + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int trow = wm * MT + i;
+      const int row = trow * 32 + l31;
+      const long long m = (mplane + y0 + trow) * p.Wo + x0 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = (wn * NTW + j) * 32 + 8 * g + 4 * lh;
+        const int nn = n0 + col;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (has_bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bias_v[g][r];
+        }
+        if (drop) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(nn + r), dseed);
+            v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+          }
+        }
+        if (has_epi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = epa_v[g][r] * v[r] + epb_v[g][r];
+            if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+          }
+        }
+        Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
+      }
+    }
+  }
+  __syncthreads();
+  T* __restrict__ yp = (T*)p.y;
+  constexpr int NCC = BN / 8;
+  constexpr int NIT = (BM * NCC + NTHR - 1) / NTHR;
+  auto out_ptr = [&](int q, bool& ok) -> T* {
+    const int row = q / NCC, cc = q - row * NCC;
+    const int oy = y0 + (row >> 5), ox = x0 + (row & 31);
+    const int nn = n0 + cc * 8;
+    ok = q < BM * NCC && oy < p.Ho && ox < p.Wo && nn < p.Cout;
+    return ok ? yp + ((mplane + oy) * p.Wo + ox) * p.ldy + nn : yp;
+  };
+  if (p.accumulate) {
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += 4) {
+      u32x4 old[4];
+      T* dst[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dst[u] = out_ptr(tid + (it0 + u) * NTHR, ok[u]);
+        ok[u] = ok[u] && it0 + u < NIT;
+        old[u] = *(const u32x4*)dst[u];                      // unconditional (a lane without a chunk re-reads element 0)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const int q = tid + (it0 + u) * NTHR;
+        const int row = q / NCC, cc = q - row * NCC;
+        float f[8], g[8];
+        Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), f);
+        Chunk<T>::unpack(old[u], g);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) f[jj] += g[jj];
+        *(u32x4*)dst[u] = Chunk<T>::pack(f);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = tid + it * NTHR;
+      bool ok;
+      T* dst = out_ptr(q, ok);
+      if (!ok) continue;
+      const int row = q / NCC, cc = q - row * NCC;
+      *(u32x4*)dst = *(const u32x4*)(smem + row * ROWB + cc * 16);
+    }
+  }
+  if (p.stats_partial)
+    hw_epilogue_stats<C>(p, smem, n0, tid, blockIdx.x, [&](int row) { return y0 + (row >> 5) < p.Ho && x0 + (row & 31) < p.Wo; });
+}
+
+// ------------------------------------------------------------------ host side
+// configurations: (tile rows, 32-channel groups, waves along the tile rows, waves along the channel groups, ring stages)
+typedef HaloWide<8, 4, 4, 2, 3> HW_8x128;        // 512 threads, 144 KB: one workgroup per CU
+typedef HaloWide<16, 2, 8, 1, 3> HW_16x64;       // 512 threads, 120 KB
+typedef HaloWide<16, 3, 8, 1, 3> HW_16x96;       // 512 threads, 144 KB
+typedef HaloWide<8, 2, 4, 1, 2> HW_8x64;         // 256 threads, 64 KB: two workgroups per CU
+typedef HaloWide<8, 3, 4, 1, 2> HW_8x96;         // 256 threads, 80 KB: two workgroups per CU
+
+struct HwChoice { int cfg; };                    // 1..5 in the order above, 0 = not taken
+
+template <typename C>
+static void hw_launch(const ConvK& k, hipStream_t s) {
+  const int tiles_x = (k.We + C::TW - 1) / C::TW, tiles_y = (k.He + C::TH - 1) / C::TH;
+  const int ngroups = (k.Cout + C::BN - 1) / C::BN;
+  const unsigned grid = (unsigned)((long long)k.N * k.Do * tiles_x * tiles_y * ngroups);
+  HDU_LAUNCH((conv_halo_wide_kernel<C>), dim3(grid), dim3(C::NTHR), 0, s, k, tiles_x, tiles_y, ngroups);
+}
+
+// geometry the kernel covers
+static bool hw_shape_ok(const ConvK& k, int dtype) {
+  if (dtype != HDU_BF16 || k.bnb_u != nullptr || k.pro_a != nullptr || k.skip != nullptr || !k.vec_out) return false;
+  if (k.KH != 3 || k.KW != 3 || (k.KD != 1 && k.KD != 3) || k.sd != 1 || k.sh != 1 || k.sw != 1 || k.ph != 1 || k.pw != 1) return false;
+  if (k.Ho != k.He || k.Wo != k.We || k.Do != k.De + 2 * k.pd - k.KD + 1 || k.Do < 1) return false;
+  if (k.KD == 1 && k.pd != 0) return false;
+  if (k.Cin % 8 || k.Cout % 8) return false;
+  if ((long long)k.Hi * k.Wi * k.ldx * 2 >= (1ll << 32)) return false;        // one input plane within a 32-bit byte offset
+  if ((long long)k.N * k.Do * ((k.He + 7) / 8) * ((k.We + 31) / 32) * ((k.Cout + 31) / 32) >= (1ll << 31)) return false;
+  return true;
+}
+
+// which configuration (0 = leave the launch to the im2col kernels).  Decided for the WHOLE layer (hdu_conv_desc.layer_rows),
+// so that a depth shard sums every output element in the same order as the unsharded launch.
+static int hw_choose(const ConvK& k, int dtype) {
+  const int force = g_tuning[HDU_TUNE_HALO_WIDE];
+  if (force == 1 || !hw_shape_ok(k, dtype)) return 0;
+  if (force >= 2) return force - 1 <= 5 ? force - 1 : 0;
+  if (k.Cin < 48 || k.Cout < 48 || k.We < 24) return 0;
+  const double scale = (double)k.M_layer / (double)k.M;                        // planes of the whole layer per plane of this launch
+  int best = 0;
+  double best_cost = 0.;
+  const int th[5] = {8, 16, 16, 8, 8}, nt[5] = {4, 2, 3, 2, 3}, occ[5] = {1, 1, 1, 2, 2};
+  for (int c = 0; c < 5; ++c) {
+    const int bn = nt[c] * 32;
+    const long long ngroups = (k.Cout + bn - 1) / bn;
+    const long long tiles = (long long)k.N * k.Do * ((k.He + th[c] - 1) / th[c]) * ((k.We + 31) / 32);
+    const double wgs = (double)tiles * scale * (double)ngroups;
+    const double rounds = __builtin_ceil(wgs / (256.0 * occ[c]));
+    // time ~ rounds x (MFMA work of a tile + a fixed prologue / epilogue share) / (share of a CU a workgroup gets)
+    const double tile_work = (double)th[c] * nt[c];                            // in units of one 32 x 32 fragment row
+    const double fixed = 6.0 * 16.0 / (double)(((k.Cin + 15) / 16) * k.KD);    // prologue + epilogue ~ 6 stages' worth of a 16-fragment tile
+    // operand bytes per MAC favour the large tiles: halo + filter bytes per stage over MACs per stage
+    const double bytes = (double)((th[c] + 2) * 34 * 32 + bn * 288) / ((double)th[c] * 32 * bn * 144);
+    const double cost = rounds * (tile_work + fixed) * (occ[c] == 2 ? 0.5 : 1.0) * (1.0 + 40.0 * bytes);
+    if (best == 0 || cost < best_cost) { best = c + 1; best_cost = cost; }
+  }
+  return best;
+}
+
+bool hdu_halo_wide_taken(const ConvK& k, int dtype) { return hw_choose(k, dtype) != 0; }
+
+const char* hdu_halo_wide_name(const ConvK& k, int dtype) {
+  static const char* names[6] = {"", "conv_halo_wide_kernel<8x128>", "conv_halo_wide_kernel<16x64>", "conv_halo_wide_kernel<16x96>",
+                                 "conv_halo_wide_kernel<8x64>", "conv_halo_wide_kernel<8x96>"};
+  return names[hw_choose(k, dtype)];
+}
+
+bool hdu_halo_wide_launch(const ConvK& k, int dtype, hipStream_t s) {
+  switch (hw_choose(k, dtype)) {
+    case 1: hw_launch<HW_8x128>(k, s); return true;
+    case 2: hw_launch<HW_16x64>(k, s); return true;
+    case 3: hw_launch<HW_16x96>(k, s); return true;
+    case 4: hw_launch<HW_8x64>(k, s); return true;
+    case 5: hw_launch<HW_8x96>(k, s); return true;
+    default: return false;
+  }
+}

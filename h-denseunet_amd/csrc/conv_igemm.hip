@@ -3278,6 +3278,11 @@ static void dispatch_igemm(const ConvK& k, size_t skb, hipStream_t s) {
   else dispatch_igemm_bn<T, 128>(k, bn, skb, s);
 }
 
+// conv_halo_wide.hip: halo-tile kernel for the wide 3x3 / 3x3x3 layers (round 5)
+bool hdu_halo_wide_taken(const ConvK& k, int dtype);
+const char* hdu_halo_wide_name(const ConvK& k, int dtype);
+bool hdu_halo_wide_launch(const ConvK& k, int dtype, hipStream_t s);
+
 static bool fprop_halo_ok(const ConvK& k, int dtype) {
   return dtype == HDU_BF16 && k.bnb_u == nullptr && !g_tuning[HDU_TUNE_NO_HALO_FPROP] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 &&
          k.KH == 3 && k.KW == 3 && k.sd == 1 && k.sh == 1 && k.sw == 1 && k.pd == 0 && k.ph == 1 && k.pw == 1 &&
@@ -3350,6 +3355,7 @@ extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
     launch_pw_bstat(k, (hipStream_t)stream);
     return hdu_check_launch("conv_fprop(pointwise, filter-stationary)");
   }
+  if (hdu_halo_wide_launch(k, d->dtype, (hipStream_t)stream)) return hdu_check_launch("conv_fprop(halo, wide)");
   if (fprop_halo_ok(k, d->dtype)) {
     switch (choose_halo_bn(k)) {
       case 96: launch_halo_fprop<96>(k, (hipStream_t)stream); break;
@@ -3367,7 +3373,7 @@ extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
 extern "C" size_t hdu_conv_splitk_ws_bytes(const hdu_conv_desc* d) {
   ConvK k;
   if (fill_convk(d, &k, false)) return 0;
-  if (k.M == 0 || pw_bstat_ok(k, d->dtype) || fprop_halo_ok(k, d->dtype) || (k.pro_a != nullptr && !igemm_pro_dma_ok(k)) || k.skip != nullptr) return 0;
+  if (k.M == 0 || pw_bstat_ok(k, d->dtype) || hdu_halo_wide_taken(k, d->dtype) || fprop_halo_ok(k, d->dtype) || (k.pro_a != nullptr && !igemm_pro_dma_ok(k)) || k.skip != nullptr) return 0;
   int bm, bn;
   choose_igemm(k, &bm, &bn);
   if (bm == 128 && igemm_pers_ok(k, bn)) return 0;
@@ -3726,6 +3732,8 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     else snprintf(buf, buflen, "conv_wgrad_kernel<float, %d>", choose_wgrad(k));
   } else if (pw_bstat_ok(k, d->dtype)) {
     snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 128, %s>", k.Ktot / 64, k.bnb_u ? "true" : "false");
+  } else if (hdu_halo_wide_taken(k, d->dtype)) {
+    snprintf(buf, buflen, "%s", hdu_halo_wide_name(k, d->dtype));
   } else if (fprop_halo_ok(k, d->dtype)) {
     snprintf(buf, buflen, "conv_halo_fprop_kernel<%d>", choose_halo_bn(k));
   } else {

@@ -136,6 +136,30 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_u16x8 a, hipemu_u16x
   hipemu::wave_release();
   return d;
 }
+// D = A(32x16) * B(16x32) + C (v_mfma_f32_32x32x16_bf16); A: lane l holds A[l&31][(l>>5)*8+j]; B: lane l holds B[(l>>5)*8+j][l&31];
+// C/D: lane l reg r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_u16x8 a, hipemu_u16x8 b, hipemu_f32x16 c) {
+  struct Slot { unsigned short a[8], b[8]; } mine;
+  for (int j = 0; j < 8; ++j) { mine.a[j] = a[j]; mine.b[j] = b[j]; }
+  size_t stride;
+  const char* all = hipemu::wave_exchange(&mine, sizeof(mine), &stride);
+  const int lane = hipemu::g_cur->lane;
+  const int col = lane & 31;
+  hipemu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      const Slot* sa = (const Slot*)(all + (size_t)(row + 32 * (k >> 3)) * stride);
+      const Slot* sb = (const Slot*)(all + (size_t)(col + 32 * (k >> 3)) * stride);
+      acc += hipemu_bf16_to_f32(sa->a[k & 7]) * hipemu_bf16_to_f32(sb->b[k & 7]);
+    }
+    d[r] = acc;
+  }
+  hipemu::wave_release();
+  return d;
+}
 // D = A(16x4) * B(4x16) + C ; A: lane l holds A[l&15][l>>4]; B: lane l holds B[l>>4][l&15].
 static inline hipemu_f32x4 hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x4 c) {
   struct Slot { float a, b; } mine{a, b};

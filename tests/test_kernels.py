@@ -269,6 +269,91 @@ def test_conv_fprop_persistent_kernel(hdu, cs, dtype, wgs):
         lib.hdu_set_tuning(23, 0)          # (off by default: measured slower than the two-stage kernel)
 
 
+# round 5: the halo-tile forward / data-gradient kernel for the wide 3x3 / 3x3x3 layers (csrc/conv_halo_wide.hip): every tile
+# configuration forced (HDU_TUNE_HALO_WIDE = 2..6) onto geometries with ragged tile grids, ragged 16-channel stages (Cin % 16 = 8),
+# ragged 32-channel output groups, slab input / output, two volumes (the plane in front of volume 1 must read as padding), depth
+# "valid" / cropped (the depth-sharded forms) and the decoder's fused nearest-neighbour up-sampling per axis
+HALO_WIDE_CASES = [
+    dict(N=2, D=1, H=9, W=37, Cin=40, Cout=72, K=(1, 3, 3), p=(0, 1, 1), up=(0, 0, 0), bias=True, ldin=56, ldout=88, id="2d_ragged_slab"),
+    dict(N=1, D=1, H=16, W=32, Cin=32, Cout=128, K=(1, 3, 3), p=(0, 1, 1), up=(0, 0, 0), bias=False, ldin=None, ldout=None, id="2d_exact_tile"),
+    dict(N=2, D=1, H=5, W=17, Cin=24, Cout=64, K=(1, 3, 3), p=(0, 1, 1), up=(0, 1, 1), bias=True, ldin=None, ldout=None, id="2d_up"),
+    dict(N=2, D=3, H=5, W=33, Cin=24, Cout=40, K=(3, 3, 3), p=(1, 1, 1), up=(0, 0, 0), bias=False, ldin=32, ldout=None, id="3d_two_volumes"),
+    dict(N=1, D=4, H=4, W=34, Cin=16, Cout=96, K=(3, 3, 3), p=(0, 1, 1), up=(0, 0, 0), bias=True, ldin=None, ldout=None, id="3d_valid_depth"),
+    dict(N=1, D=2, H=3, W=16, Cin=32, Cout=24, K=(3, 3, 3), p=(1, 1, 1), up=(1, 1, 1), bias=True, ldin=None, ldout=40, id="3d_up222"),
+    dict(N=1, D=3, H=3, W=16, Cin=8, Cout=48, K=(3, 3, 3), p=(-1, 1, 1), up=(1, 1, 1), bias=False, ldin=None, ldout=None, id="3d_up222_cropped_depth"),
+    dict(N=1, D=3, H=4, W=18, Cin=40, Cout=32, K=(3, 3, 3), p=(1, 1, 1), up=(0, 1, 1), bias=False, ldin=None, ldout=None, id="3d_up221"),
+]
+for _c in HALO_WIDE_CASES:
+    _c.update(s=(1, 1, 1), skip=False, pro=False)
+HALO_WIDE_CFGS = [(2, "8x128"), (3, "16x64"), (4, "16x96"), (5, "8x64"), (6, "8x96")]
+
+
+@pytest.mark.parametrize("cfg", [pytest.param(c[0], id=c[1]) for c in HALO_WIDE_CFGS])
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in HALO_WIDE_CASES])
+def test_conv_halo_wide(hdu, cs, cfg):
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    dtype = BF16
+    b = build_conv_case(ops, cs, dtype)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    if cs["ldout"]:
+        big = ops.Act.alloc(N, Do, Ho, Wo, cs["ldout"], dtype, zero=True)
+        big.buf.fill_(3.0)
+        ya = big.slab(8, Cout)
+    else:
+        big, ya = None, ops.Act.alloc(N, Do, Ho, Wo, Cout, dtype)
+    bias = dev(ops, b["bias"]) if b["bias"] is not None else None
+    wp = ctypes.c_void_p(b["wt"].data_ptr())
+    d = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias)
+    xe = ref_xeff(b["x"], cs["up"], None, None, True, dtype)
+    ref = ref_conv(xe, b["w"], cs["s"], cs["p"], b["bias"])
+    M = N * Do * Ho * Wo
+    try:
+        lib.hdu_set_tuning(29, cfg)
+        assert ops.conv_kernel_name(d, 0).startswith("conv_halo_wide_kernel"), ops.conv_kernel_name(d, 0)
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), ref, dtype, what="fprop")
+        if big is not None:
+            full = big.to_torch().cpu()
+            assert float((full[..., :8] - 3.0).abs().max()) == 0.0 and float((full[..., 8 + Cout:] - 3.0).abs().max()) == 0.0
+        d.accumulate = 1
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), q(ref, dtype) * 2, dtype, scale=2 * float(ref.abs().max()), what="fprop accumulate")
+        ea, eb = rnd((Cout,), 31, 1.0).float().double() + 1.5, rnd((Cout,), 32, 0.5).float().double()
+        ea_d, eb_d = dev(ops, ea), dev(ops, eb)
+        d2 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias, epi=(ea_d, eb_d, True))
+        ops.conv_fprop(d2)
+        r2 = (ref * ea + eb).clamp_min(0)
+        assert_close(ya.to_torch().cpu(), r2, dtype, scale=float(r2.abs().max()), what="fprop + output affine")
+        # epilogue statistics of the STORED values
+        slots = 8
+        shift = rnd((Cout,), 33, 0.3).float()
+        shift_d = shift.to(ops.device())
+        part = torch.zeros(slots * 2 * Cout, dtype=torch.float32, device=ops.device())
+        d3 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias)
+        d3.stats_partial, d3.stats_shift, d3.stats_slots = part.data_ptr(), shift_d.data_ptr(), slots
+        ops.conv_fprop(d3)
+        assert_close(ya.to_torch().cpu(), ref, dtype, what="fprop with statistics")
+        y = ya.to_torch().cpu().double().reshape(M, Cout)
+        got = part.cpu().double().reshape(slots, 2, Cout).sum(0)
+        dd = y - shift.double()
+        assert float((got[0] - dd.sum(0)).abs().max()) <= 1e-4 * (float(dd.abs().sum(0).max()) + 1e-9)
+        assert float((got[1] - (dd * dd).sum(0)).abs().max()) <= 1e-4 * float((dd * dd).sum(0).max())
+        # dropout: the mask the im2col kernels draw (stateless hash of the element index)
+        seed_dev = torch.zeros(1, dtype=torch.int32, device=ops.device())
+        d4 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias, False, 0.7, 1234, seed_dev)
+        ops.conv_fprop(d4)
+        got_drop = ya.to_torch().cpu().double()
+        lib.hdu_set_tuning(29, 1)
+        assert not ops.conv_kernel_name(d4, 0).startswith("conv_halo_wide_kernel")
+        ops.conv_fprop(d4)
+        assert_close(got_drop, ya.to_torch().cpu().double(), dtype, scale=float(ref.abs().max()) / 0.7, what="dropout mask vs the im2col kernel")
+        assert 0.55 < float((got_drop != 0).double().mean()) < 0.85
+    finally:
+        lib.hdu_set_tuning(29, 0)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES
                                 if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "stem7x7s2")])
