@@ -167,19 +167,20 @@ __global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int ti
   const long long plane_elems = (long long)p.Hi * p.Wi * p.ldx;
   const unsigned plane_bytes = (unsigned)((((long long)p.Hi * p.Wi - 1) * p.ldx + p.Cin) * 2);
 
-  auto issue = [&](int slot, int kd, int c0) {
-    char* base = smem + slot * STAGE;
+  // one stage = LPW DMA pieces per wave.  The stage's wave-uniform state (plane resource, filter offset) is set up once; the
+  // pieces themselves are issued BETWEEN the taps of the stage that is being multiplied (issue_piece), not in a burst after the
+  // barrier: both waves of a SIMD leave the barrier together, and a burst of LPW x ~100-180 issue cycles at that point leaves
+  // the MFMA pipe idle (first build, rocprof + ISA: 52 % of the MFMA roof with the burst)
+  // wave-uniform part of a stage's sources: input-plane pointer (+ first channel), bytes addressable behind it, filter offset
+  auto stage_plane = [&](int kd, int c0) -> const T* {
     const int pz = od + kd - p.pd;                            // effective input plane (inside the volume: see kd_lo / kd_hi)
-    const T* plane = xp + (long long)(n * p.Di + (pz >> p.ud)) * plane_elems + c0;
-    const hdu_bufsrd xsrd = hdu_make_srd(plane, plane_bytes - (unsigned)c0 * 2u);
-    const unsigned woff = (unsigned)(kd * 9 * p.Cin + c0) * 2u;
-#pragma unroll
-    for (int j = 0; j < LPW; ++j) {
-      const int jj = j * NW + wave;
-      const bool ok = roff[j] != HDU_OOB && c0 + rlc[j] < p.Cin;    // (a ragged last stage: channels >= Cin read as zeros on both sides)
-      if (jj < XI) hdu_bufload_lds16(xsrd, ok ? roff[j] : HDU_OOB, base + jj * 1024);
-      else hdu_bufload_lds16(wsrd, ok ? roff[j] + woff : HDU_OOB, base + jj * 1024);
-    }
+    return xp + (long long)(n * p.Di + (pz >> p.ud)) * plane_elems + c0;
+  };
+  auto issue_piece = [&](const hdu_bufsrd& xsrd, unsigned woff, int c0, char* base, int j, bool live) {
+    const int jj = j * NW + wave;
+    const bool ok = live && roff[j] != HDU_OOB && c0 + rlc[j] < p.Cin;   // (a ragged last stage: channels >= Cin read as zeros on both sides)
+    if (jj < XI) hdu_bufload_lds16(xsrd, ok ? roff[j] : HDU_OOB, base + jj * 1024);
+    else hdu_bufload_lds16(wsrd, ok ? roff[j] + woff : HDU_OOB, base + jj * 1024);
   };
 
   f32x16 acc[MT][NTW];
@@ -196,13 +197,16 @@ __global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int ti
   const int nch = (p.Cin + 15) >> 4;
   const int nst = kd_hi > kd_lo ? (kd_hi - kd_lo) * nch : 0;
   int ikd = kd_lo, ic = 0;                                    // the next stage to issue
-  auto issue_next = [&](int slot) {
-    issue(slot, ikd, ic * 16);
-    if (++ic == nch) { ic = 0; ++ikd; }
-  };
 #pragma unroll
-  for (int pre = 0; pre < NS - 1; ++pre)
-    if (pre < nst) issue_next(pre);
+  for (int pre = 0; pre < NS - 1; ++pre) {
+    const bool live = pre < nst;
+    const int c0 = live ? ic * 16 : 0;
+    const hdu_bufsrd xsrd = hdu_make_srd(stage_plane(live ? ikd : kd_lo, c0), plane_bytes - (unsigned)c0 * 2u);
+    const unsigned woff = (unsigned)(ikd * 9 * p.Cin + c0) * 2u;
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) issue_piece(xsrd, woff, c0, smem + pre * STAGE, j, live);
+    if (live && ++ic == nch) { ic = 0; ++ikd; }
+  }
 
   // per-lane fragment addressing
   const int l31 = lane & 31, lh = lane >> 5;
@@ -216,13 +220,21 @@ __global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int ti
 
   int slot = 0;
   for (int s = 0; s < nst; ++s) {
-    const int ahead = nst - 1 - s;                            // stages issued beyond s: min(NS - 2, ahead) may stay in flight
-    if (ahead >= NS - 2) hw_wait_vmcnt<(NS - 2) * LPW>();
-    else if (NS > 3 && ahead == 1) hw_wait_vmcnt<(NS > 3 ? LPW : 0)>();
-    else hw_wait_vmcnt<0>();
+    // every iteration issues LPW pieces per wave (the last NS - 1 iterations issue dead ones: out-of-range lanes, zeros into the
+    // slot nobody reads again), so ONE counted wait serves every iteration and the taps below carry no branch
+    hw_wait_vmcnt<(NS - 2) * LPW>();
     HDU_RAW_BARRIER();
-    if (s + NS - 1 < nst) issue_next(slot == 0 ? NS - 1 : slot - 1);
+    // the stage issued during this iteration (into the slot the previous iteration multiplied from): its DMA pieces go out
+    // BETWEEN the taps below, not in a burst after the barrier -- both waves of a SIMD leave the barrier together, and a burst
+    // of LPW x ~100-180 issue cycles there leaves the MFMA pipe idle (first build: 0.52 of the MFMA roof with the burst)
+    const bool more = s + NS - 1 < nst;
+    const int nc0 = more ? ic * 16 : 0;
+    const hdu_bufsrd nxsrd = hdu_make_srd(stage_plane(more ? ikd : kd_lo, nc0), plane_bytes - (unsigned)nc0 * 2u);
+    const unsigned nwoff = (unsigned)(ikd * 9 * p.Cin + nc0) * 2u;
+    char* nbase = smem + (slot == 0 ? NS - 1 : slot - 1) * STAGE;
+    if (more && ++ic == nch) { ic = 0; ++ikd; }
     const char* Xs = smem + slot * STAGE;
+    constexpr int PER_TAP = (LPW + 8) / 9;                    // pieces issued behind each tap's MFMAs
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap - kh * 3;
@@ -238,12 +250,16 @@ __global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int ti
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = hdu_mfma_32x32x16_bf16(bf[j], af[i], acc[i][j]);
+#pragma unroll
+      for (int u = 0; u < PER_TAP; ++u)
+        if (tap * PER_TAP + u < LPW) issue_piece(nxsrd, nwoff, nc0, nbase, tap * PER_TAP + u, more);
     }
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
   // ---- epilogue: bias / dropout / output affine in registers, the tile through LDS, 16-byte row stores
-  __syncthreads();                                            // every wave is done with the operand stages (all DMAs have landed)
+  hw_wait_vmcnt<0>();                                         // (the dead pieces of the last iterations too)
+  __syncthreads();                                            // every wave is done with the operand stages, all DMAs have landed
   const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
   const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
   const long long mplane = ((long long)n * p.Do + od) * p.Ho;
@@ -348,6 +364,7 @@ typedef HaloWide<16, 2, 8, 1, 3> HW_16x64;       // 512 threads, 120 KB
 typedef HaloWide<16, 3, 8, 1, 3> HW_16x96;       // 512 threads, 144 KB
 typedef HaloWide<8, 2, 4, 1, 2> HW_8x64;         // 256 threads, 64 KB: two workgroups per CU
 typedef HaloWide<8, 3, 4, 1, 2> HW_8x96;         // 256 threads, 80 KB: two workgroups per CU
+typedef HaloWide<16, 4, 8, 1, 2> HW_16x128;      // 512 threads, 112 KB, two stages
 
 struct HwChoice { int cfg; };                    // 1..5 in the order above, 0 = not taken
 
@@ -373,37 +390,43 @@ static bool hw_shape_ok(const ConvK& k, int dtype) {
 
 // which configuration (0 = leave the launch to the im2col kernels).  Decided for the WHOLE layer (hdu_conv_desc.layer_rows),
 // so that a depth shard sums every output element in the same order as the unsharded launch.
+// Cost model, calibrated on the per-layer A/B of profiles/r05_experiment_halo_wide_*.txt (unit: one 32 x 32 x 16 MFMA per SIMD):
+// a compute unit is handed load = ceil(workgroups / 256) workgroups; each needs stages x TH x NT x 9 / 4 MFMA slots of the pipe
+// the co-resident workgroups share (measured 0.58-0.74 busy in the K loop), and a fixed prologue + epilogue per workgroup that a
+// co-resident partner mostly hides (two-workgroup configurations).  Padded output channels and tile rows are paid in full.
 static int hw_choose(const ConvK& k, int dtype) {
   const int force = g_tuning[HDU_TUNE_HALO_WIDE];
   if (force == 1 || !hw_shape_ok(k, dtype)) return 0;
-  if (force >= 2) return force - 1 <= 5 ? force - 1 : 0;
-  if (k.Cin < 48 || k.Cout < 48 || k.We < 24) return 0;
+  if (force >= 2) return force - 1 <= 6 ? force - 1 : 0;
+  if (k.Cin < 32 || k.Cout < 48 || k.We < 24) return 0;
   const double scale = (double)k.M_layer / (double)k.M;                        // planes of the whole layer per plane of this launch
+  const int th[6] = {8, 16, 16, 8, 8, 16}, nt[6] = {4, 2, 3, 2, 3, 4}, occ[6] = {1, 1, 1, 2, 2, 1};
+  const double busy[6] = {0.60, 0.68, 0.68, 0.58, 0.58, 0.74};
+  const double nst = (double)((k.Cin + 15) / 16) * k.KD;
   int best = 0;
-  double best_cost = 0.;
-  const int th[5] = {8, 16, 16, 8, 8}, nt[5] = {4, 2, 3, 2, 3}, occ[5] = {1, 1, 1, 2, 2};
-  for (int c = 0; c < 5; ++c) {
+  double best_cost = 0., best_wgs = 0.;
+  for (int c = 0; c < 6; ++c) {
     const int bn = nt[c] * 32;
-    const long long ngroups = (k.Cout + bn - 1) / bn;
-    const long long tiles = (long long)k.N * k.Do * ((k.He + th[c] - 1) / th[c]) * ((k.We + 31) / 32);
-    const double wgs = (double)tiles * scale * (double)ngroups;
-    const double rounds = __builtin_ceil(wgs / (256.0 * occ[c]));
-    // time ~ rounds x (MFMA work of a tile + a fixed prologue / epilogue share) / (share of a CU a workgroup gets)
-    const double tile_work = (double)th[c] * nt[c];                            // in units of one 32 x 32 fragment row
-    const double fixed = 6.0 * 16.0 / (double)(((k.Cin + 15) / 16) * k.KD);    // prologue + epilogue ~ 6 stages' worth of a 16-fragment tile
-    // operand bytes per MAC favour the large tiles: halo + filter bytes per stage over MACs per stage
-    const double bytes = (double)((th[c] + 2) * 34 * 32 + bn * 288) / ((double)th[c] * 32 * bn * 144);
-    const double cost = rounds * (tile_work + fixed) * (occ[c] == 2 ? 0.5 : 1.0) * (1.0 + 40.0 * bytes);
-    if (best == 0 || cost < best_cost) { best = c + 1; best_cost = cost; }
+    const double wgs = (double)k.N * k.Do * ((k.He + th[c] - 1) / th[c]) * ((k.We + 31) / 32) * scale * (double)((k.Cout + bn - 1) / bn);
+    const double load = __builtin_ceil(wgs / 256.0);
+    const double work = (double)th[c] * nt[c];
+    const double main_ = nst * work / busy[c];
+    const double fixed = 40.0 + work;
+    const double cost = load * main_ + __builtin_ceil(load / occ[c]) * fixed * ((occ[c] == 2 && load >= 2.) ? 0.3 : 1.0);
+    if (best == 0 || cost < best_cost) { best = c + 1; best_cost = cost; best_wgs = wgs; }
   }
+  // too small to fill the chip with halo tiles: the im2col ring kernels with split-K spread such layers over more compute units
+  if (best_wgs < 128.) return 0;
+  // narrow outputs (the 48-channel dense-block layers) pay 25 % padding here: only where the layer is large
+  if (k.Cout < 64 && best_wgs < 1024.) return 0;
   return best;
 }
 
 bool hdu_halo_wide_taken(const ConvK& k, int dtype) { return hw_choose(k, dtype) != 0; }
 
 const char* hdu_halo_wide_name(const ConvK& k, int dtype) {
-  static const char* names[6] = {"", "conv_halo_wide_kernel<8x128>", "conv_halo_wide_kernel<16x64>", "conv_halo_wide_kernel<16x96>",
-                                 "conv_halo_wide_kernel<8x64>", "conv_halo_wide_kernel<8x96>"};
+  static const char* names[7] = {"", "conv_halo_wide_kernel<8x128>", "conv_halo_wide_kernel<16x64>", "conv_halo_wide_kernel<16x96>",
+                                 "conv_halo_wide_kernel<8x64>", "conv_halo_wide_kernel<8x96>", "conv_halo_wide_kernel<16x128>"};
   return names[hw_choose(k, dtype)];
 }
 
@@ -414,6 +437,7 @@ bool hdu_halo_wide_launch(const ConvK& k, int dtype, hipStream_t s) {
     case 3: hw_launch<HW_16x96>(k, s); return true;
     case 4: hw_launch<HW_8x64>(k, s); return true;
     case 5: hw_launch<HW_8x96>(k, s); return true;
+    case 6: hw_launch<HW_16x128>(k, s); return true;
     default: return false;
   }
 }

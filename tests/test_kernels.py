@@ -285,7 +285,7 @@ HALO_WIDE_CASES = [
 ]
 for _c in HALO_WIDE_CASES:
     _c.update(s=(1, 1, 1), skip=False, pro=False)
-HALO_WIDE_CFGS = [(2, "8x128"), (3, "16x64"), (4, "16x96"), (5, "8x64"), (6, "8x96")]
+HALO_WIDE_CFGS = [(2, "8x128"), (3, "16x64"), (4, "16x96"), (5, "8x64"), (6, "8x96"), (7, "16x128")]
 
 
 @pytest.mark.parametrize("cfg", [pytest.param(c[0], id=c[1]) for c in HALO_WIDE_CFGS])

@@ -16,8 +16,9 @@ ops = importlib.import_module("h-denseunet_amd.ops")
 lib = pkg.lib.get()
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-cfgs = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 0, 2, 3, 4, 5, 6]
-NAMES = {1: "im2col", 0: "auto", 2: "8x128", 3: "16x64", 4: "16x96", 5: "8x64", 6: "8x96"}
+ONLY = os.environ.get("HW_ONLY")          # "layer:form" -- one layer / form only (PMC probes)
+cfgs = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 0, 2, 3, 4, 5, 6, 7]
+NAMES = {1: "im2col", 0: "auto", 2: "8x128", 3: "16x64", 4: "16x96", 5: "8x64", 6: "8x96", 7: "16x128"}
 
 # (name, N, D, H, W (stored input), Cin, Cout, K, up)
 L2D = [
@@ -62,6 +63,8 @@ def timeit(fn, n=6):
 
 def run(layers, tag):
     for (name, N, D, H, W, Cin, Cout, K, up) in layers:
+        if ONLY and ONLY.split(":")[0] != name:
+            continue
         pad = (K[0] // 2, 1, 1)
         x = ops.Act.alloc(N, D, H, W, Cin, 0); x.buf.normal_()
         De, He, We = D << up[0], H << up[1], W << up[2]
@@ -73,6 +76,8 @@ def run(layers, tag):
         d_d = ops.conv_desc(y, ctypes.c_void_p(w.data_ptr()), dxe, K, (1, 1, 1), pad)
         flops = 2.0 * N * De * He * We * Cout * T * Cin
         for form, d in (("fprop", d_f), ("dgrad", d_d)):
+            if ONLY and ONLY != name + ":" + form:
+                continue
             line = "%-6s %-13s %-5s %6.1f GF |" % (tag, name, form, flops / 1e9)
             for c in cfgs:
                 lib.hdu_set_tuning(29, c)
@@ -81,8 +86,8 @@ def run(layers, tag):
                     line += " %s: n/a |" % NAMES[c]
                     continue
                 t = timeit(lambda: ops.conv_fprop(d))
-                lab = NAMES[c] if c != 0 else "auto[" + kn.replace("conv_halo_wide_kernel", "hw").replace("conv_igemm_", "")[:22] + "]"
-                line += " %s %7.1f us %6.0f TF |" % (lab, t * 1e3, flops / t / 1e9)
+                lab = NAMES[c] if c != 0 else "auto[" + kn.replace("conv_halo_wide_kernel", "hw").replace("conv_igemm_", "")[:10] + "]"
+                line += " %s %6.0f us %4.0f |" % (lab, t * 1e3, flops / t / 1e9) if c < 2 else " %s %4.0f |" % (lab, flops / t / 1e9)
             lib.hdu_set_tuning(29, 0)
             print(line, flush=True)
         del x, y, dxe, w
