@@ -37,10 +37,12 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,   # MI355X_MICROARCH.md: dense MFMA
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 PROFILE_ROUND = "r04"
 
-# HDU_BENCH_DRYRUN=1 (tests/test_bench_flow_gloo.py only): the same control flow on CPU -- x86 emulator build of the
-# kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
-# checked without a multi-GPU node.  Never a measurement; the JSON line says so.
-DRYRUN = os.environ.get("HDU_BENCH_DRYRUN") == "1"
+# tests/bench_dryrun.py (tests/test_bench_flow_gloo.py only) sets these two: the same control flow on CPU -- x86 emulator build
+# of the kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
+# checked without a multi-GPU node.  Never a measurement; the JSON line says so.  No environment variable or flag of bench.py
+# itself reaches this path.
+DRYRUN = False
+_dryrun_bind = None
 
 
 def _sync():
@@ -536,7 +538,7 @@ def main():
 
     pkg = importlib.import_module("h-denseunet_amd")
     if DRYRUN:
-        pkg.lib.use_emulator_for_tests()
+        _dryrun_bind()
         a.no_graph, a.no_cpu_baseline = True, True
     else:
         pkg.lib.load()   # gfx950 library or a loud failure: there is no CPU fallback

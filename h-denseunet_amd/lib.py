@@ -2,9 +2,9 @@
 
 The product library is `libhdu.so` next to this file, built for gfx950 by `build.sh hip` /
 `__graft_entry__.build()`.  If it is missing, loading fails loudly -- there is no CPU fallback on the
-product path.  `use_emulator_for_tests()` is test infrastructure: it binds the x86 emulator build of the
-*same kernel sources* (tests/hipemu) so the CPU-only test tier can execute kernel logic; it must be
-called explicitly and is never reached from bench.py or __graft_entry__.smoke().
+product path, and `load()` refuses a library that does not identify itself as the gfx950 build.  (The x86
+emulator build of the same kernel sources, which lets the CPU-only test tier execute kernel logic, is bound
+by tests/emu_bind.py -- test infrastructure; nothing in this package knows it exists.)
 """
 import ctypes
 import os
@@ -194,10 +194,6 @@ def product_library_path():
     return os.path.join(_HERE, "libhdu.so")
 
 
-def emulator_library_path():
-    return os.path.join(_ROOT, "tests", "hipemu", "libhdu_emu.so")
-
-
 def _bind(path):
     # torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be resident BEFORE libhdu.so is loaded so
     # that both share ONE runtime instance (otherwise our launches hit a second, device-less runtime).
@@ -240,6 +236,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(9, int(os.environ["HDU_NO_HALO_FPROP"]))
     if "HDU_NO_HALO" in os.environ:
         lib.hdu_set_tuning(8, int(os.environ["HDU_NO_HALO"]))
+    if "HDU_HALO_WIDE" in os.environ:       # 1 = the im2col kernels of rounds 1-4 for the wide 3x3 / 3x3x3 layers (A/B)
+        lib.hdu_set_tuning(29, int(os.environ["HDU_HALO_WIDE"]))
     if "HDU_HALO_MIN_W" in os.environ:
         lib.hdu_set_tuning(28, int(os.environ["HDU_HALO_MIN_W"]))
     if "HDU_HALO_TARGET" in os.environ:
@@ -266,8 +264,7 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(23, int(os.environ["HDU_PERS"]))
     if "HDU_NO_PW_BSTAT_BNB" in os.environ:
         lib.hdu_set_tuning(26, int(os.environ["HDU_NO_PW_BSTAT_BNB"]))
-    if os.environ.get("HDU_F32_CONTRACTION", "exact") != "exact":
-        lib.hdu_set_tuning(TUNE_F32_SPLIT, {"bf16x3": 1}[os.environ["HDU_F32_CONTRACTION"]])
+    lib.hdu_set_tuning(TUNE_F32_SPLIT, _F32_MODES[_f32_contraction])
     if "HDU_PERS_MIN_ITEMS" in os.environ:
         lib.hdu_set_tuning(24, int(os.environ["HDU_PERS_MIN_ITEMS"]))
     if "HDU_WGRAD_MIN_STEPS" in os.environ:
@@ -282,21 +279,11 @@ def load(path=None):
         raise HduError(
             "libhdu.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
-    _lib = _bind(path)
-    _backend = _lib.hdu_backend().decode()
-    _apply_env_tuning(_lib)
-    return _lib
-
-
-def use_emulator_for_tests():
-    """TEST INFRASTRUCTURE ONLY: bind the x86 emulator build of the kernel sources."""
-    global _lib, _backend
-    path = emulator_library_path()
-    if not os.path.exists(path):
-        raise HduError("emulator library not built: run ./build.sh emu")
-    _lib = _bind(path)
-    _backend = _lib.hdu_backend().decode()
-    assert _backend == "emu-x86"
+    bound = _bind(path)
+    backend = bound.hdu_backend().decode()
+    if backend != "hip-gfx950":
+        raise HduError("%s is not the gfx950 product library (hdu_backend() = %r).  There is no CPU fallback." % (path, backend))
+    _lib, _backend = bound, backend
     _apply_env_tuning(_lib)
     return _lib
 
@@ -336,15 +323,24 @@ def set_f32_contraction(mode):
     into bf16 hi + lo, a.b ~ ah.bh + ah.bl + al.bh on the bf16 MFMA with the float32 accumulator (<= 3 * 2^-18 relative per
     product).  Environment: HDU_F32_CONTRACTION=bf16x3.  Returns the previous mode."""
     global _f32_contraction
-    if mode not in ("exact", "bf16x3"):
-        raise ValueError("f32 contraction mode: 'exact' or 'bf16x3'")
     prev = _f32_contraction
-    check(get().hdu_set_tuning(TUNE_F32_SPLIT, 1 if mode == "bf16x3" else 0), "hdu_set_tuning")
+    check(get().hdu_set_tuning(TUNE_F32_SPLIT, _F32_MODES[_check_f32_mode(mode)]), "hdu_set_tuning")
     _f32_contraction = mode
     return prev
 
 
-_f32_contraction = os.environ.get("HDU_F32_CONTRACTION", "exact")
+_F32_MODES = {"exact": 0, "bf16x3": 1}
+
+
+def _check_f32_mode(mode, what="f32 contraction mode"):
+    if mode not in _F32_MODES:
+        raise ValueError("%s: 'exact' or 'bf16x3', not %r" % (what, mode))
+    return mode
+
+
+# validated ONCE, at import (ADVICE r4: an unknown value used to surface as a bare KeyError while the library loaded, and
+# set_f32_contraction could hand it back as the 'previous' mode)
+_f32_contraction = _check_f32_mode(os.environ.get("HDU_F32_CONTRACTION", "exact"), "HDU_F32_CONTRACTION")
 
 
 def profile_begin(max_records=1 << 16):

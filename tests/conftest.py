@@ -20,8 +20,8 @@ def hdu_pkg():
 
 
 def _ensure_emulator():
-    lib = hdu_pkg().lib
-    path = lib.emulator_library_path()
+    import emu_bind
+    path = emu_bind.emulator_library_path()
     srcs = [os.path.join(ROOT, "h-denseunet_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "h-denseunet_amd", "csrc"))]
     srcs += [os.path.join(ROOT, "tests", "hipemu", f) for f in ("hipemu.h", "hipemu.cpp")]
     if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
@@ -33,8 +33,9 @@ def _ensure_emulator():
 def emu_lib():
     """Bind the x86 emulator build of the kernel sources (test infrastructure)."""
     _ensure_emulator()
+    import emu_bind
     pkg = hdu_pkg()
-    pkg.lib.use_emulator_for_tests()
+    emu_bind.use_emulator()
     return pkg
 
 

@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     pkg = importlib.import_module("h-denseunet_amd")
-    pkg.lib.use_emulator_for_tests()
+    import emu_bind
+    emu_bind.use_emulator()
     import parity_utils as U
     par = U.pkg("parallel")
     ka = U.pkg("keras_api")

@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 import parity_utils as U
 kind, variant, b, size, cols = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]) or None
 if len(sys.argv) > 6:
-    U.pkg("lib").use_emulator_for_tests()
+    import emu_bind
+    emu_bind.use_emulator()
 nb2, nb3 = ((6, 12, 36, 24), (3, 4, 12, 8)) if size >= 128 else ((2, 2, 2, 2), (1, 1, 2, 1))
 m, P, fwd = U.build_pair(kind, variant, b, size, cols, "f32", nb2, nb3, odtype=torch.float32)
 m.ctx.dropout_enabled = False

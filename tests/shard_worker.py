@@ -44,7 +44,8 @@ class GlooComm:
 
 def main():
     pkg = importlib.import_module("h-denseunet_amd")
-    pkg.lib.use_emulator_for_tests()
+    import emu_bind
+    emu_bind.use_emulator()
     import parity_utils as U
     par, ka = U.pkg("parallel"), U.pkg("keras_api")
     sh = par.depth_shard_info("gloo")

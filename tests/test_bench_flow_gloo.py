@@ -1,4 +1,4 @@
-"""bench.py's multi-rank control flow on 2 CPU ranks (HDU_BENCH_DRYRUN=1: emulator kernels, gloo, reduced-depth net): the
+"""bench.py's multi-rank control flow on 2 CPU ranks (tests/bench_dryrun.py: emulator kernels, gloo, reduced-depth net): the
 sequence of collectives -- broadcast, per-step gradient all-reduce, barriers, MAX-reduce of the time, the loss reduce, and
 the rank-0-ONLY instrumented roofline step that must not enter a collective -- completes, and rank 0 prints ONE JSON line
 with the contract's keys.  (What the driver launches at round end with --gpus 2/4/8 over RCCL.)"""
@@ -11,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_world2_control_flow(emu_lib):
-    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--batch", "1", "--size", "32", "--dtype", "bf16", "--extras", "3dpart"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -38,9 +38,9 @@ def test_bench_world2_shard3d_control_flow(emu_lib):
     """--config shard3d with 2 ranks: the depth-sharded step always contains collectives (halo exchange, sync-BN), so
     the rank-0-only instrumented roofline step must be skipped -- otherwise rank 0 blocks on sends that the other
     rank, already in the final barrier, never matches."""
-    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "1", "--config", "shard3d", "--size", "32", "--cols", "16", "--dtype", "f32"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
@@ -52,10 +52,10 @@ def test_bench_world2_shard3d_control_flow(emu_lib):
 
 
 def _run_guarded(port, timeout_s):
-    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2", HDU_BENCH_SHARD3D="force",
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2", HDU_BENCH_SHARD3D="force",
                HDU_BENCH_SHARD3D_TIMEOUT=timeout_s)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+           "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "1", "--batch", "1", "--size", "32", "--dtype", "f32", "--extras", "none", "--no-roofline"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -90,8 +90,8 @@ def test_bench_world2_guarded_shard3d_watchdog(emu_lib):
 def test_bench_dryrun_float32_split_contraction_extra(emu_lib):
     """the `2d:f32x3` extra workload (float32 storage, split-bf16 contraction switched on for that workload only) through
     bench.py's own control flow on CPU: both float32 lines are reported, labelled, and the mode is switched back afterwards"""
-    env = dict(os.environ, HDU_BENCH_DRYRUN="1", HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "1", "--size", "32",
+    env = dict(os.environ, HIPEMU_THREADS="4", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_dryrun.py"), "--steps", "1", "--warmup", "1", "--batch", "1", "--size", "32",
            "--extras", "2d:f32x3,2d:f32"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]

@@ -124,6 +124,42 @@ def test_shard_shape_forward_loss_f32(hip_lib):
     assert min(U.dice_vs_oracle(got, ref)) >= 1 - 1e-3
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_depth_halo_form_world1_equals_unsharded_gpu(hip_lib, monkeypatch, dtype):
+    """the depth-sharded launch list in ONE process (HDU_FORCE_DEPTH_HALO=1, world-1 ShardInfo: every 3D layer
+    over an input that stores its halo planes, which stay zero without neighbours = the unsharded network) on the GPU, full depth,
+    224 x 224 x 12 -- what bench.py times as the per-rank compute of the sharded step was compared on the emulator only
+    (tests/test_model_parity.py).  A shard decides like the whole layer (tile form, split-K, kernel family), so the two launch
+    lists sum every output element in the same order: float32 logits / loss / gradients equal to float-atomics noise; bf16 (the
+    depth-valid / cropped forms of the halo-tile kernels) equal to a few bf16 ulps of the logits."""
+    shard_mod = U.pkg("shard")
+    ctor = U.pkg("densenet3d_sharded").dense_net3d
+    x, y = U.synthetic_batch("3d", 1, 224, 12, seed=5)
+
+    def step(halo):
+        monkeypatch.setenv("HDU_FORCE_DEPTH_HALO", "1" if halo else "0")
+        m = ctor(U.make_args(1, 224, 12), dtype=dtype, nb_layers3d=FULL3D, seed=9, shard=shard_mod.ShardInfo(0, 1) if halo else None)
+        assert any(cv.halo for cv in m.ctx.convs) == halo
+        m.ctx.dropout_enabled = False
+        m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[U.pkg("loss").weighted_crossentropy])
+        loss = m.train_on_batch(x, y)
+        names = [U.pkg("ops").conv_kernel_name(cv.d_f, 0) for cv in m.ctx.convs]
+        return loss, m._download_logits().cpu().numpy(), m.ctx.G[:m.ctx.n_trainable].clone(), names
+
+    l_h, z_h, g_h, n_h = step(True)
+    l_u, z_u, g_u, n_u = step(False)
+    if dtype == "bf16":
+        assert any(nm.startswith("conv_halo_wide_kernel") for nm in n_h) and any(nm.startswith("conv_halo_wide_kernel") for nm in n_u)
+    scale = max(1.0, float(np.abs(z_u).max()))
+    ez, eg = float(np.abs(z_h - z_u).max()), float((g_h - g_u).norm() / g_u.norm())
+    print("depth-halo form vs unsharded, %s, 224x224x12: logits max abs diff %.3e (scale %.3g), loss %.6f vs %.6f, gradient rel-L2 %.3e"
+          % (dtype, ez, scale, l_h, l_u, eg))
+    if dtype == "f32":
+        assert ez <= 1e-4 * scale and abs(l_h - l_u) <= 1e-5 * abs(l_u) and eg <= 1e-3, (ez, l_h, l_u, eg)
+    else:
+        assert ez <= 2e-2 * scale and abs(l_h - l_u) <= 2e-3 * abs(l_u) and eg <= 5e-2, (ez, l_h, l_u, eg)
+
+
 @pytest.mark.parametrize("dtype,kind,variant,b,size,cols", [
     ("f32", "2d", "denseunet", 2, 256, None),
     ("bf16", "2d", "denseunet", 8, 512, None),          # the benchmarked configuration itself
@@ -276,7 +312,8 @@ def test_f32_absolute_logit_error_from_trained_weights(hip_lib, kind, variant, b
         # measured on MI355X (profiles/r04_f32_split_contraction.txt): predict 1.3e-4 (2D) / 2.6e-5 (3D) against the exact mode's
         # 1.2e-5 / 3.7e-6, training-phase forward 2.6e-4 / 2.8e-4 at max|logit| 5 / 16 -- about 10x the float32 product's own error,
         # 1000x inside the bf16 product's 0.1 ... 0.3; NOT a mode that meets the 1e-4 bound on every net
-        assert e3 <= 1e-3 and e3_t <= 1e-3, (e3, e3_t)
+        # round 5: gated at what it measures (1.5 x the figures above), not at a loose 1e-3
+        assert e3 <= 2e-4 and e3_t <= 4e-4, (e3, e3_t)
         assert min(dice3) >= 1 - 1e-3
     assert mx <= 40.0, "the recipe is meant to give O(10) logits"
     assert e_got <= 1e-4, "predict logits: max abs err %.3e at max|logit| %.3f" % (e_got, mx)
