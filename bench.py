@@ -35,7 +35,7 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,   # MI355X_MICROARCH.md: dense MFMA
                # the K=16 form moves half the K of the K=32 form per issue, so a product-equivalent peak of 2500 / 2 / 3
                "f32x3": 2500.0 / 6.0}
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 # tests/bench_dryrun.py (tests/test_bench_flow_gloo.py only) sets these two: the same control flow on CPU -- x86 emulator build
 # of the kernels, gloo instead of RCCL, reduced-depth nets -- so that the multi-rank sequence of collectives of this script is
@@ -184,6 +184,60 @@ def _row_work(name, a, ctx):
     return None
 
 
+def _is_3d_dense_block_conv(layer):
+    """conv_block3d's two convolutions (denseunet3d.py:18-53, hybridnet.py:11-46): 3dconv<stage>_<i>_x1 (1x1x1) / _x2 (3x3x3)"""
+    return layer.startswith("3dconv") and (layer.endswith("_x1") or layer.endswith("_x2"))
+
+
+def step_roofline(agg, dtype):
+    """time-weighted roofline fraction of the WHOLE step (a one-kernel roofline says little for a step whose top
+    kernel is 11 %): every kernel with an algorithmic-work model is priced against the roof its arithmetic intensity puts it
+    under (HBM 8 TB/s or the dense MFMA peak), weighted by its share of the step's kernel time; kernels without a model (small
+    per-channel folds / finalizes) count as 0 and their share is reported as `unmodelled_time_share`."""
+    ridge = PEAK_TFLOPS[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
+    tot = sum(v[1] for v in agg.values())
+    acc = mf = hb = un = 0.0
+    for n, tms, fl, nb in agg.values():
+        sec = tms * 1e-3
+        hbm = fl == 0.0 or (nb and fl / nb < ridge)
+        if hbm and nb:
+            acc += tms * min(1.0, nb / sec / 1e9 / PEAK_HBM_GBS); hb += tms
+        elif not hbm:
+            acc += tms * min(1.0, fl / sec / 1e12 / PEAK_TFLOPS[dtype]); mf += tms
+        else:
+            un += tms
+    return {"time_weighted_frac": round(acc / tot, 4), "mfma_bound_time_share": round(mf / tot, 3),
+            "hbm_bound_time_share": round(hb / tot, 3), "unmodelled_time_share": round(un / tot, 3)}
+
+
+def parity_of_timed_mode(config, dtype):
+    """fidelity of the mode this workload is timed in, from the committed figures of the GPU parity tests (a
+    bf16 slices/s is never quoted without it): Dice deficit per class and max abs logit error of the product against the FLOAT32
+    oracle (tests/test_gpu_parity_bf16.py, tests/test_gpu_parity.py -> profiles/<round>_bf16_parity_figures.txt)."""
+    import re
+    path = os.path.join(ROOT, "profiles", "%s_bf16_parity_figures.txt" % PROFILE_ROUND)
+    tag = {"2d": "2d/denseunet", "3dpart": "hybrid/3dpart", "end2end": "hybrid/end2end", "shard3d": "3d/3dpart"}[config]
+    if not os.path.exists(path):
+        return None
+    rec = None
+    for ln in open(path):
+        if dtype == "bf16" and ln.startswith("[" + tag + "/") and "north_star tolerances" in ln:
+            mm = re.search(r"Dice deficit per class \[([^\]]*)\].*max abs err ([0-9.e+-]+)", ln)
+            if mm:      # (the LAST matching case of the file: the benchmarked batch / shape comes last in the test's case list)
+                rec = {"dtype": "bf16", "vs": "float32 oracle", "case": ln[1:ln.index("]")],
+                       "dice_deficit_per_class": [float(v.strip(" '")) for v in mm.group(1).split(",")],
+                       "logit_max_abs_err": float(mm.group(2)), "north_star_bounds": {"dice": 1e-3, "logits": 1e-4}}
+        elif dtype.startswith("f32") and ln.startswith("[f32 absolute " + tag.split("/", 1)[0]) and tag.split("/", 1)[1] in ln:
+            mm = re.search(r"product vs float32 oracle ([0-9.e+-]+).*Dice vs oracle \[([^\]]*)\]", ln)
+            if mm:
+                rec = {"dtype": "f32", "vs": "float32 oracle", "case": ln[1:ln.index("]")],
+                       "dice_deficit_per_class": [round(1.0 - float(v.strip(" '")), 7) for v in mm.group(2).split(",")],
+                       "logit_max_abs_err": float(mm.group(1)), "north_star_bounds": {"dice": 1e-3, "logits": 1e-4}}
+    if rec is not None:
+        rec["source"] = "profiles/%s_bf16_parity_figures.txt" % PROFILE_ROUND
+    return rec
+
+
 def instrumented_step(m):
     """ONE eager step with the library's launch profiler armed (include/hdu.h: hdu_profile_*): EVERY kernel the step
     launches is recorded with its own begin-to-end time (start / stop events attached to the dispatch itself -- the figure
@@ -192,13 +246,17 @@ def instrumented_step(m):
     Returns {kernel_name: [n_launches, total_ms, algorithmic_flops, algorithmic_bytes (or None)]}."""
     lib = importlib.import_module("h-denseunet_amd.lib")
     ctx = m.ctx
-    scale = {}
+    scale, owner = {}, {}
     for cv in ctx.convs:
         ks = cv.kernel.keras_shape
         sc = (ks[-2] / cv.cin_p) * (ks[-1] / cv.cout_p)
         scale[cv.wf_ptr.value] = sc
+        owner[cv.wf_ptr.value] = cv.name
         if cv.wd_ptr is not None:
             scale[cv.wd_ptr.value] = sc
+            owner[cv.wd_ptr.value] = cv.name
+    dense3d = lambda d: _is_3d_dense_block_conv(owner.get(d.w, ""))
+    db = [0.0, 0.0, 0]           # north_star's quantity: FLOPs, ms, launches of the 3D dense-block convs (forward + data + filter gradient)
     g = m._graph
     m._graph = None
     # this extra step runs on rank 0 ONLY: it must not enter the gradient all-reduce (the other ranks are already
@@ -220,10 +278,15 @@ def instrumented_step(m):
         if name in ("hdu_conv_fprop", "hdu_conv_wgrad", "hdu_conv_dgrad_strided"):
             d = args[0]._obj
             work[n0] = _conv_work(d, 1 if name == "hdu_conv_wgrad" else 0, scale)
+            if dense3d(d):
+                db[0] += work[n0][0]; db[1] += sum(r[1] for r in recs[n0:n1]); db[2] += n1 - n0
         elif name == "hdu_wgrad_plan_run" and plan is not None:
             ds = plan.descs[getattr(args[0], "value", args[0])]
             ws = [_conv_work(d, 1, scale) for d in ds]
             work[n0] = (sum(w[0] for w in ws), sum(w[1] for w in ws))
+            fd = sum(w[0] for d, w in zip(ds, ws) if dense3d(d))
+            if fd > 0:             # a batched launch covers many layers: its time is shared out by FLOPs
+                db[0] += fd; db[1] += recs[n0][1] * fd / max(work[n0][0], 1.0); db[2] += 1
         else:
             rw = _row_work(name, args, ctx)
             if rw is not None:
@@ -267,6 +330,7 @@ def instrumented_step(m):
     out = {}
     for k, a in agg.items():
         out[k] = [a[0], a[1], a[2], a[3] if a[4] else None]
+    instrumented_step.dense_blocks_3d = tuple(db)
     if os.environ.get("HDU_BENCH_VERBOSE"):
         tot = sum(v[1] for v in out.values())
         for k, v in sorted(out.items(), key=lambda kv: -kv[1][1]):
@@ -478,6 +542,16 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
         "step_frac_of_mfma_peak": round(gflop / ms / PEAK_TFLOPS[dtype], 4),
     }
     rec["parallelism"] = ("depth-shard%d" if config == "shard3d" else "dp%d") % world
+    par_rec = parity_of_timed_mode(config, "f32" if dtype.startswith("f32") else dtype)
+    if par_rec is not None:
+        rec["parity"] = par_rec
+    if config == "shard3d" and world > 1 and gcols == 512 and size == 512:
+        # strong scaling of BASELINE configs[4] against the SAME volume on ONE GPU (profiles/: measured this round, world 1)
+        ref = os.path.join(ROOT, "profiles", "%s_full_512cubed_world1.json" % PROFILE_ROUND)
+        if os.path.exists(ref):
+            n1 = json.load(open(ref))
+            rec["strong_scaling"] = {"n1_ms_per_step": n1["ms_per_step"], "speedup_vs_n1": round(n1["ms_per_step"] / ms, 3),
+                                     "efficiency": round(n1["ms_per_step"] / ms / world, 3), "n1_source": "profiles/%s_full_512cubed_world1.json" % PROFILE_ROUND}
     if torch.cuda.is_available():
         rec["peak_hbm_gib"] = round(torch.cuda.max_memory_allocated() / 2.0 ** 30, 2)
     # the instrumented step is rank-0-only and must not enter a collective: the depth-sharded step always does
@@ -487,6 +561,12 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
         name = max(agg.items(), key=lambda kv: kv[1][1])[0]       # largest total time over ALL kernels of the step
         rec["roofline"] = roofline_record(agg, name, config, dtype)
         rec["top_kernels"] = top_kernels(agg, dtype)
+        rec["step_roofline"] = step_roofline(agg, dtype)
+        fl3, ms3, n3 = instrumented_step.dense_blocks_3d
+        if n3:       # north_star: "MFMA roofline on the 3D dense-block fwd+bwd" -- the convs of conv_block3d, all three passes
+            rec["dense_blocks_3d"] = {"conv_launches": n3, "ms": round(ms3, 3), "gflop": round(fl3 / 1e9, 1),
+                                      "mfma_frac": round(fl3 / (ms3 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4),
+                                      "note": "convolutions of conv_block3d (1x1x1 + 3x3x3; forward, data gradient, filter gradient) only"}
         kms = sum(v[1] for v in agg.values())
         rec["step_kernel_ms_eager_profiled"] = round(kms, 3)
         rec["launches_per_step"] = sum(v[0] for v in agg.values())
@@ -505,7 +585,13 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
 def compact(rec):
     """what the ONE JSON line carries per extra workload (the driver keeps 8 KB of stdout: the whole metric must fit)"""
     out = {k: rec[k] for k in ("workload", "value", "unit", "ms_per_step", "steps", "dtype", "hipgraph", "global_batch_slices",
-                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism") if k in rec}
+                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism", "strong_scaling") if k in rec}
+    if "step_roofline" in rec:
+        out["step_roofline_frac"] = rec["step_roofline"]["time_weighted_frac"]
+    if "dense_blocks_3d" in rec:
+        out["dense_blocks_3d_mfma_frac"] = rec["dense_blocks_3d"]["mfma_frac"]
+    if "parity" in rec:
+        out["parity"] = {k: rec["parity"][k] for k in ("dtype", "dice_deficit_per_class", "logit_max_abs_err")}
     out["workload"] = rec["workload"][:120]
     if "roofline" in rec:
         r = rec["roofline"]
@@ -613,11 +699,18 @@ def main():
                 out["roofline"] = main_rec["roofline"]
                 out["config"]["top_kernels"] = main_rec.get("top_kernels")
                 out["config"]["launches_per_step"] = main_rec.get("launches_per_step")
+                out["config"]["step_roofline"] = main_rec.get("step_roofline")
+                if "dense_blocks_3d" in main_rec:
+                    out["config"]["dense_blocks_3d"] = main_rec["dense_blocks_3d"]
+            if "parity" in main_rec:
+                out["parity"] = main_rec["parity"]
             if not a.no_cpu_baseline and world == 1 and a.config != "shard3d":
                 out["cpu_baseline"] = cpu_baseline(a.config, size, cols)
                 for r in extra_recs:
                     if r["workload"].startswith("denseunet_3d"):      # the 3D half beside its own CPU baseline
                         r["cpu_baseline"] = cpu_baseline("3dpart", 224, 12, samples=1)
+                    elif r["workload"].startswith("dense_rnn_net"):
+                        r["cpu_baseline"] = cpu_baseline("end2end", 224, 12, samples=1)
             if extra_recs:
                 out["config"]["extra_workloads"] = [compact(r) for r in extra_recs]
             line = json.dumps(out)

@@ -2336,8 +2336,15 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
   // tile).  Everything that depends on the lane only is now computed ONCE: operands arrive through buffer resources (a lane
   // adds its fixed element offset to the tile's base, out-of-range = zeros: hdu_platform.h), the tile position advances
   // incrementally, and the lane's 64 LDS read addresses are kept as 16-bit offsets, two per register.
+  // Tensors of 4 GiB and more (round 5: the whole 512^3 volume on one GPU -- dy of 3dconv_up4 is 17 GB): `big` = the resources
+  // are made PER TILE from the 64-bit address of the tile's input plane / output plane, and the lane offsets stay inside that
+  // plane (host: a plane is < 2 GiB).  Tensors below 4 GiB keep ONE resource over the whole tensor (no per-tile SALU).
+  const long long dy_bytes = (((long long)p.M - 1) * p.ldy + p.Cout) * 2;
+  const bool big = p.x_bytes == 0u || p.x_bytes > 0xF0000000u || dy_bytes >= 0xF0000000ll;     // (256 MB of slack for the halo offsets of a tile)
   const hdu_bufsrd xsrd = hdu_make_srd(p.x, p.x_bytes);
-  const hdu_bufsrd dsrd = hdu_make_srd(p.y, (unsigned)((((long long)p.M - 1) * p.ldy + p.Cout) * 2));     // (host: < 4 GiB)
+  const hdu_bufsrd dsrd = hdu_make_srd(p.y, (unsigned)dy_bytes);
+  const long long xplane_elems = (long long)p.Hi * p.Wi * p.ldx, dplane_elems = (long long)p.He * p.We * p.ldy;
+  const unsigned xplane_bytes = (unsigned)((xplane_elems - p.ldx + p.Cin) * 2), dplane_bytes = (unsigned)((dplane_elems - p.ldy + p.Cout) * 2);
   // x halo tile: instruction jj = j * 4 + wave covers halo pixels jj * 16 .. + 15, 4 lanes (16-byte chunks) per pixel
   int xhr[4], xhc[4], xoff[4];
 #pragma unroll
@@ -2377,22 +2384,26 @@ __device__ __forceinline__ void wgrad_halo_body(const ConvK& p, float* __restric
     char* Dt = Xh + XBYTES;
     const int y0 = l_ty * TH, x0 = l_tx * TW;
     const bool plane_ok = (unsigned)(l_d + xshift) < (unsigned)Dx;
-    const int xplane = l_v * p.Di + ((l_d + xshift) >> p.ud);                           // stored input plane
-    const int xbase = ((xplane * p.Hi + (y0 >> p.uh)) * p.Wi + (x0 >> p.uw)) * (int)p.ldx;       // valid pixels give >= 0 sums
+    const int xplane = l_v * p.Di + (plane_ok ? ((l_d + xshift) >> p.ud) : 0);          // stored input plane
+    const int xin = ((y0 >> p.uh) * p.Wi + (x0 >> p.uw)) * (int)p.ldx;                 // tile origin inside the plane
+    const int din = (y0 * W + x0) * (int)p.ldy;
+    const hdu_bufsrd xs = big ? hdu_make_srd((const bf16_t*)p.x + (long long)xplane * xplane_elems, xplane_bytes) : xsrd;
+    const hdu_bufsrd ds = big ? hdu_make_srd((const bf16_t*)p.y + (long long)l_n * dplane_elems, dplane_bytes) : dsrd;
+    const int xbase = big ? xin : xplane * (int)xplane_elems + xin;                     // valid pixels give >= 0 sums
+    const int dbase = big ? din : l_n * (int)dplane_elems + din;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int jj = j * 4 + wave;
       if (jj < HPP / 16) {                                  // wave-uniform
         const bool ok = plane_ok && (unsigned)(y0 - 1 + xhr[j]) < (unsigned)H && (unsigned)(x0 - 1 + xhc[j]) < (unsigned)W;
-        hdu_bufload_lds16(xsrd, ok ? (unsigned)(xbase + xoff[j]) * 2u : HDU_OOB, Xh + jj * 1024);
+        hdu_bufload_lds16(xs, ok ? (unsigned)(xbase + xoff[j]) * 2u : HDU_OOB, Xh + jj * 1024);
       }
     }
-    const int dbase = ((l_n * H + y0) * W + x0) * (int)p.ldy;
     const bool colok = dvalid && x0 + dpx0 < W;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool ok = colok && y0 + j < H;
-      hdu_bufload_lds16(dsrd, ok ? (unsigned)(dbase + j * W * (int)p.ldy + doff0) * 2u : HDU_OOB, Dt + (j * 32 + wave * 8) * DROWB);
+      hdu_bufload_lds16(ds, ok ? (unsigned)(dbase + j * W * (int)p.ldy + doff0) * 2u : HDU_OOB, Dt + (j * 32 + wave * 8) * DROWB);
     }
     if (++l_tx == tiles_x) {
       l_tx = 0;
@@ -3235,6 +3246,7 @@ static int pers_table_cap(int bn, int cin) {                 // LDS table capaci
 static bool igemm_pers_ok(const ConvK& k, int bn) {
   if (g_tuning[HDU_TUNE_PERS] == 0) return false;
   if (k.skip != nullptr || !k.vec_out || k.bnb_u != nullptr || !igemm_fast_ok(k)) return false;
+  if (k.f32_split) return false;      // (the persistent body contracts in the exact form only: a split-bf16 net must not mix the two by grid size -- ADVICE r4)
   if (k.pro_a != nullptr && (!igemm_pro_dma_ok(k) || pers_table_cap(bn, k.Cin) < 0)) return false;
   const long long items = ((k.M_layer + 255) / 256) * ((k.Cout + bn - 1) / bn);
   const int min_items = g_tuning[HDU_TUNE_PERS_MIN_ITEMS] > 0 ? g_tuning[HDU_TUNE_PERS_MIN_ITEMS] : 512;
@@ -3487,9 +3499,9 @@ static bool wgrad_halo_ok(const ConvK& k) {
          // (a nearest-neighbour up-sampling in front of the conv is resolved in the tile's addressing: bit 2 of the knob = off)
          ((k.ud | k.uh | k.uw) == 0 || !(g_tuning[HDU_TUNE_NO_HALO] & 4)) &&
          k.Cin % 8 == 0 && k.We >= (g_tuning[HDU_TUNE_HALO_MIN_W] > 0 ? g_tuning[HDU_TUNE_HALO_MIN_W] : 24) &&      // (swept 32 / 24 / 14: r04_experiment_halo_wgrad_3d.txt)
-         // operands through buffer resources with 32-bit byte offsets (tensors of 4 GiB and more take the im2col form)
-         k.x_bytes != 0 && (((long long)k.M - 1) * k.ldy + k.Cout) * 2 < (1ll << 32) &&
-         (long long)k.N * k.De * k.He * k.We * k.ldx < (1ll << 31) - (long long)(k.He * k.We + k.We + 2) * k.ldx;
+         // operands through buffer resources with 32-bit byte offsets: over the whole tensor below 4 GiB, per input / output
+         // plane above (round 5) -- a plane (+ one tile row of slack for the halo offsets) must stay inside 2^31 bytes
+         ((long long)k.Hi * k.Wi + k.Wi + 2) * k.ldx * 2 < (1ll << 31) && ((long long)k.He * k.We + k.We + 2) * k.ldy * 2 < (1ll << 31);
 }
 
 // work grid of the halo-tile filter gradient: 32-channel chunks x filter-row tiles x splits of the spatial tiles

@@ -41,6 +41,7 @@ extern "C" size_t hdu_sizeof_conv_desc(void) { return sizeof(hdu_conv_desc); }
 #include <dlfcn.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,7 @@ struct ProfRec {
 };
 std::vector<ProfRec> g_prof;
 size_t g_prof_cap = 0;
+std::mutex g_prof_mutex;
 #ifndef HDU_EMU
 std::vector<hipEvent_t> g_prof_pool;      // events are created once and reused by later profiling windows
 #endif
@@ -84,7 +86,13 @@ std::string kernel_of(const void* addr) {
 }  // namespace
 
 #ifndef HDU_EMU
-int hdu_prof_next(const void* kernel_addr, hipEvent_t* e0, hipEvent_t* e1) {
+int hdu_prof_next(const void* kernel_addr, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return 0;                                  // a captured launch takes the plain path
+  }
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (g_prof.size() >= g_prof_cap) return 0;
   const size_t i = g_prof.size();
   while (g_prof_pool.size() < 2 * (i + 1)) {
@@ -103,6 +111,7 @@ int hdu_prof_next(const void* kernel_addr, hipEvent_t* e0, hipEvent_t* e1) {
 }
 #else
 int hdu_prof_note(const void* kernel_addr) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (g_prof.size() >= g_prof_cap) return 0;
   ProfRec r;
   r.addr = kernel_addr;
@@ -113,6 +122,8 @@ int hdu_prof_note(const void* kernel_addr) {
 
 extern "C" int hdu_profile_begin(int max_records) {
   if (max_records <= 0) return hdu_set_error(HDU_ERR_ARG, "profile_begin: max_records must be positive");
+  if (g_hdu_prof_on) return hdu_set_error(HDU_ERR_ARG, "profile_begin: a profiling window is already armed (end it first)");
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   g_prof.clear();
   g_prof.reserve((size_t)max_records);
   g_prof_cap = (size_t)max_records;

@@ -27,14 +27,14 @@ int hdu_prof_note(const void* kernel_addr);
 // every launch); the record keeps the kernel's address (hdu_profile_get resolves it to the instantiated name: dladdr +
 // demangling).  Not armed (always, outside bench.py's one instrumented step): one predictable branch.
 extern int g_hdu_prof_on;
-int hdu_prof_next(const void* kernel_addr, hipEvent_t* e0, hipEvent_t* e1);
+int hdu_prof_next(const void* kernel_addr, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1);
 // hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind so that
 // hdu_check_launch() reports THIS launch only
 #define HDU_LAUNCH(kern, grid, block, smem, stream, ...)                                                         \
   do {                                                                                                           \
     (void)hipGetLastError();                                                                                     \
     hipEvent_t pe0_, pe1_;                                                                                       \
-    if (g_hdu_prof_on && hdu_prof_next((const void*)(kern), &pe0_, &pe1_))                                       \
+    if (g_hdu_prof_on && hdu_prof_next((const void*)(kern), (stream), &pe0_, &pe1_))                                       \
       hipExtLaunchKernelGGL(kern, (grid), (block), (smem), (stream), pe0_, pe1_, 0, __VA_ARGS__);                \
     else                                                                                                         \
       hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);                                  \

@@ -84,8 +84,14 @@ class Var:
         ctx = self.ctx
         if r.corr_off is not None and ctx.corr_acc is not None and ctx.fuse_bn_bwd_now:
             pend = ctx._pending_fin
+            # (hdu_bn_bwd_finalize_correct addresses 16-byte chunks: channel offsets, widths and pixel strides must be chunk
+            # multiples and the slabs 16-byte aligned -- anything else takes the two-launch path below instead of raising in the
+            # middle of a backward pass)
+            ch = ops.CHUNK[self.act.dtype]
+            aligned = (self.c0 - (pend["c0"] if pend else 0)) % ch == 0 and self.C % ch == 0 and self.act.ld % ch == 0 \
+                and self.grad.ld % ch == 0 and self.act.ptr.value % 16 == 0 and self.grad.ptr.value % 16 == 0
             if pend is not None and pend["root"] is r and pend["c0"] <= self.c0 and self.c0 + self.C <= pend["c0"] + pend["C"] \
-                    and self.act.M == pend["M"]:
+                    and self.act.M == pend["M"] and aligned:
                 # the finalize of the consumer BN that ran last and this correction: one launch (hdu_bn_bwd_finalize_correct)
                 ctx._pending_fin = None
                 ops.bn_bwd_finalize_correct(*pend["args"], self.c0 - pend["c0"], self.act, self.grad)

@@ -399,6 +399,32 @@ def test_conv_wgrad(hdu, cs, dtype):
     assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
 
 
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES if c["id"].startswith("halo_tile")])
+def test_conv_wgrad_halo_large_tensor_path(hdu, cs):
+    """round 5: tensors of 4 GiB and more (the whole 512^3 volume on one GPU) stay on the halo-tile filter gradient -- the buffer
+    resources are made per input / output plane from 64-bit addresses.  HDU_TUNE_DEBUG bit 4 forces that path on the small cases."""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    dtype = BF16
+    b = build_conv_case(ops, cs, dtype, seed=100)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    dy = rnd((N, Do, Ho, Wo, Cout), 777, 1.0, dtype)
+    dya = mkact(ops, dy, dtype, cs["ldout"], 8 if cs["ldout"] else 0)
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, None)
+    dw = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+    try:
+        lib.hdu_set_tuning(4, 16)
+        assert ops.conv_kernel_name(d, 1).startswith("conv_wgrad_halo"), ops.conv_kernel_name(d, 1)
+        ops.conv_wgrad(d, dw)
+    finally:
+        lib.hdu_set_tuning(4, 0)
+    xe = ref_xeff(b["x"], cs["up"], None, None, True, dtype).requires_grad_(True)
+    wref = b["w"].clone().requires_grad_(True)
+    (ref_conv(xe, wref, cs["s"], cs["p"], None) * dy).sum().backward()
+    assert_close(dw.cpu(), wref.grad, BF16, what="wgrad, per-plane resources")
+
+
 def _halo_geometries():
     rng = np.random.default_rng(20260925)
     out = []
