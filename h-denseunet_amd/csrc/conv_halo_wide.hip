@@ -104,6 +104,114 @@ __device__ __forceinline__ void hw_epilogue_stats(const ConvK& p, const char* sm
   }
 }
 
+// ---- epilogue shared by the kernels of this file: bias / dropout / output affine in registers, the tile through LDS, 16-byte
+// row stores (accumulate mode: read-modify-write), conv-epilogue statistics.  Tile pixel `row` = (y0 + row / 32, x0 + row % 32) of
+// output plane `mplane` (= (n * Do + od) * Ho); acc[i][j] = 32 x 32 fragment (tile row wm * MT + i, channel group wn * NTW + j).
+template <typename C>
+__device__ __forceinline__ void hw_epilogue(const ConvK& p, f32x16 (&acc)[C::MT][C::NTW], char* smem, long long mplane, int y0, int x0,
+                                            int n0, int wm, int wn, int lane, int tid, unsigned slot) {
+  typedef bf16_t T;
+  constexpr int BN = C::BN, BM = C::BM, NTHR = C::NTHR, ROWB = C::ROWB, MT = C::MT, NTW = C::NTW;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // ---- epilogue: bias / dropout / output affine in registers, the tile through LDS, 16-byte row stores
+  hw_wait_vmcnt<0>();                                         // (the dead pieces of the last iterations too)
+  __syncthreads();                                            // every wave is done with the operand stages, all DMAs have landed
+  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
+  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    f32x4 bias_v[4], epa_v[4], epb_v[4];                      // unconditional loads at a clamped channel (see igemm_epilogue)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nn = n0 + (wn * NTW + j) * 32 + 8 * g + 4 * lh;
+      const int nc = nn < p.Cout ? nn : 0;
+      bias_v[g] = has_bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      epa_v[g] = has_epi ? *(const f32x4*)(p.epi_a + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+      epb_v[g] = has_epi ? *(const f32x4*)(p.epi_b + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int trow = wm * MT + i;
+      const int row = trow * 32 + l31;
+      const long long m = (mplane + y0 + trow) * p.Wo + x0 + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = (wn * NTW + j) * 32 + 8 * g + 4 * lh;
+        const int nn = n0 + col;
+        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (has_bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bias_v[g][r];
+        }
+        if (drop) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(nn + r), dseed);
+            v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
+          }
+        }
+        if (has_epi) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = epa_v[g][r] * v[r] + epb_v[g][r];
+            if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
+          }
+        }
+        Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
+      }
+    }
+  }
+  __syncthreads();
+  T* __restrict__ yp = (T*)p.y;
+  constexpr int NCC = BN / 8;
+  constexpr int NIT = (BM * NCC + NTHR - 1) / NTHR;
+  auto out_ptr = [&](int q, bool& ok) -> T* {
+    const int row = q / NCC, cc = q - row * NCC;
+    const int oy = y0 + (row >> 5), ox = x0 + (row & 31);
+    const int nn = n0 + cc * 8;
+    ok = q < BM * NCC && oy < p.Ho && ox < p.Wo && nn < p.Cout;
+    return ok ? yp + ((mplane + oy) * p.Wo + ox) * p.ldy + nn : yp;
+  };
+  if (p.accumulate) {
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += 4) {
+      u32x4 old[4];
+      T* dst[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dst[u] = out_ptr(tid + (it0 + u) * NTHR, ok[u]);
+        ok[u] = ok[u] && it0 + u < NIT;
+        old[u] = *(const u32x4*)dst[u];                      // unconditional (a lane without a chunk re-reads element 0)
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const int q = tid + (it0 + u) * NTHR;
+        const int row = q / NCC, cc = q - row * NCC;
+        float f[8], g[8];
+        Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), f);
+        Chunk<T>::unpack(old[u], g);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) f[jj] += g[jj];
+        *(u32x4*)dst[u] = Chunk<T>::pack(f);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int q = tid + it * NTHR;
+      bool ok;
+      T* dst = out_ptr(q, ok);
+      if (!ok) continue;
+      const int row = q / NCC, cc = q - row * NCC;
+      *(u32x4*)dst = *(const u32x4*)(smem + row * ROWB + cc * 16);
+    }
+  }
+  if (p.stats_partial)
+    hw_epilogue_stats<C>(p, smem, n0, tid, slot, [&](int row) { return y0 + (row >> 5) < p.Ho && x0 + (row & 31) < p.Wo; });
+}
+
 template <typename C>
 __global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int tiles_x, int tiles_y, int ngroups) {
   typedef bf16_t T;
@@ -257,104 +365,168 @@ __global__ __launch_bounds__(C::NTHR) void conv_halo_wide_kernel(ConvK p, int ti
     slot = slot == NS - 1 ? 0 : slot + 1;
   }
 
-  // ---- epilogue: bias / dropout / output affine in registers, the tile through LDS, 16-byte row stores
-  hw_wait_vmcnt<0>();                                         // (the dead pieces of the last iterations too)
-  __syncthreads();                                            // every wave is done with the operand stages, all DMAs have landed
-  const unsigned dseed = p.drop_seed + (p.drop_seed_dev ? *p.drop_seed_dev : 0u);
-  const bool has_bias = p.bias != nullptr, drop = p.drop_scale != 0.f, has_epi = p.epi_a != nullptr;
   const long long mplane = ((long long)n * p.Do + od) * p.Ho;
+  hw_epilogue<C>(p, acc, smem, mplane, y0, x0, n0, wm, wn, lane, tid, blockIdx.x);
+}
+
+// =====================================================================================
+// Stem: 7 x 7 (x 7) stride-2 convolution over an 8-channel (16 B per pixel) input, Cout <= 96 per group -- `conv1` / `3dconv1`
+// (denseunet.py:163-164, denseunet3d.py:129-130).  The im2col GEMM gathers ONE 16-byte chunk per (row, tap): 343 taps x 8 padded
+// channels, 0.26 of the MFMA roof at the shard shape (2.2 of 41.8 ms).  Here the contraction is ordered (kd, kh | kw, c): for one
+// (kd, kh) the seven kw taps of an output pixel are 7 ADJACENT input pixels = 112 contiguous bytes, so a 16-element MFMA k-step is
+// two neighbouring input pixels and the A fragment of output pixel ow is a 16-byte read at input pixel 2 * ow - 3 + kw (lane
+// stride 32 B) of a row segment staged once per stage.  kw is padded to 8 (the 8th tap's filter chunk is read out of range =
+// zeros).  Workgroup = 16 x 32 output pixels of one output plane x 96 channels, 8 waves (2 tile rows x 3 channel groups each);
+// stage = (kd, kh): 16 row segments of 70 input pixels + the filter rows' 8 chunks; ring of 4 stages, counted waits as above.
+// LDS: input pixel slot q = r * 70 + j stored at q ^ ((q >> 4) & 1) (the lanes of a ds_read_b128 group are 2 slots apart: pairs
+// 16 / 48 slots apart would share a bank slot); filter rows at a 9-chunk (144 B) stride (9 * co mod 16 is a permutation).
+struct StemCfg {
+  static constexpr int TH = 16, NT = 3, WAVES_M = 8, WAVES_N = 1, NS = 4;
+  static constexpr int NW = 8, NTHR = 512, TW = 32;
+  static constexpr int BN = 96, BM = TH * TW;
+  static constexpr int SEG = 70;                            // input pixels per row segment: 2 * 31 + 8 taps
+  static constexpr int XSLOTS = TH * SEG;                   // 1120
+  static constexpr int XI = (XSLOTS + 63) / 64;             // 18 pieces
+  static constexpr int WSLOTS = BN * 9;                     // 864
+  static constexpr int WI = (WSLOTS + 63) / 64;             // 14 pieces
+  static constexpr int LPW = (XI + WI + NW - 1) / NW;       // 4
+  static constexpr int STAGE = LPW * NW * 1024;
+  static constexpr int XBYTES = XI * 1024;
+  static constexpr int ROWB = BN * 2 + 16;
+  static constexpr int SMEM = NS * STAGE > BM * ROWB ? NS * STAGE : BM * ROWB;
+  static constexpr int MT = 2, NTW = 3;
+  static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(StemCfg::NTHR) void conv_stem_s2_kernel(ConvK p, int tiles_x, int tiles_y, int ngroups) {
+  typedef StemCfg C;
+  typedef bf16_t T;
+  constexpr int NW = C::NW, NS = C::NS, XI = C::XI, WI = C::WI, LPW = C::LPW, STAGE = C::STAGE, XBYTES = C::XBYTES, SEG = C::SEG;
+  constexpr int MT = C::MT, NTW = C::NTW, BN = C::BN;
+  __shared__ __attribute__((aligned(16))) char smem[C::SMEM];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  const T* __restrict__ xp = (const T*)p.x;
+  unsigned t = (p.xcd_swizzle & 1) ? xcd_tile_index(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int ng = (int)(t % (unsigned)ngroups); t /= (unsigned)ngroups;
+  const int od = (int)(t % (unsigned)p.Do); t /= (unsigned)p.Do;
+  const int txi = (int)(t % (unsigned)tiles_x); t /= (unsigned)tiles_x;
+  const int tyi = (int)(t % (unsigned)tiles_y);
+  const int n = (int)(t / (unsigned)tiles_y);
+  const int y0 = tyi * C::TH, x0 = txi * C::TW;
+  const int n0 = ng * BN;
+
+  // ---- fixed DMA roles: pieces [0, XI) = input row segments (stage part: + kh rows), [XI, XI + WI) = filter chunks
+  unsigned roff[LPW];
+  int riy[LPW];                      // input row of the lane's pixel at kh = 0 (x pieces); rows outside the image read as zeros
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    f32x4 bias_v[4], epa_v[4], epb_v[4];                      // unconditional loads at a clamped channel (see igemm_epilogue)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nn = n0 + (wn * NTW + j) * 32 + 8 * g + 4 * lh;
-      const int nc = nn < p.Cout ? nn : 0;
-      bias_v[g] = has_bias ? *(const f32x4*)(p.bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-      epa_v[g] = has_epi ? *(const f32x4*)(p.epi_a + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
-      epb_v[g] = has_epi ? *(const f32x4*)(p.epi_b + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int trow = wm * MT + i;
-      const int row = trow * 32 + l31;
-      const long long m = (mplane + y0 + trow) * p.Wo + x0 + l31;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = (wn * NTW + j) * 32 + 8 * g + 4 * lh;
-        const int nn = n0 + col;
-        float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        if (has_bias) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bias_v[g][r];
-        }
-        if (drop) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned h = hdu_hash32((unsigned long long)m * (unsigned)p.Cout + (unsigned)(nn + r), dseed);
-            v[r] = h < p.drop_thresh ? v[r] * p.drop_scale : 0.f;
-          }
-        }
-        if (has_epi) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = epa_v[g][r] * v[r] + epb_v[g][r];
-            if (p.epi_relu) v[r] = v[r] > 0.f ? v[r] : 0.f;
-          }
-        }
-        Chunk<T>::store4((T*)(smem + row * ROWB) + col, v);
-      }
+  for (int j = 0; j < LPW; ++j) {
+    const int jj = j * NW + wave;
+    riy[j] = -(1 << 28);
+    if (jj < XI) {
+      const int ps = jj * 64 + lane;
+      const int q = ps ^ ((ps >> 4) & 1);
+      const int r = q / SEG, c = q - r * SEG;
+      const int iy = 2 * (y0 + r) - p.ph, ix = 2 * x0 - p.pw + c;
+      const bool ok = q < C::XSLOTS && (unsigned)ix < (unsigned)p.Wi;
+      roff[j] = ok ? (unsigned)((iy * p.Wi + ix) * (int)p.ldx) * 2u : HDU_OOB;      // (iy may be negative: checked per stage with kh)
+      riy[j] = ok ? iy : -(1 << 28);
+    } else if (jj < XI + WI) {
+      const int ps = (jj - XI) * 64 + lane;
+      const int row = ps / 9, kw = ps - row * 9;
+      const int co = n0 + row;
+      const bool ok = row < BN && co < p.Cout && kw < 7;
+      roff[j] = ok ? (unsigned)((co * p.KD * 49 + kw) * 8) * 2u : HDU_OOB;
+    } else {
+      roff[j] = HDU_OOB;
     }
   }
-  __syncthreads();
-  T* __restrict__ yp = (T*)p.y;
-  constexpr int NCC = BN / 8;
-  constexpr int NIT = (BM * NCC + NTHR - 1) / NTHR;
-  auto out_ptr = [&](int q, bool& ok) -> T* {
-    const int row = q / NCC, cc = q - row * NCC;
-    const int oy = y0 + (row >> 5), ox = x0 + (row & 31);
-    const int nn = n0 + cc * 8;
-    ok = q < BM * NCC && oy < p.Ho && ox < p.Wo && nn < p.Cout;
-    return ok ? yp + ((mplane + oy) * p.Wo + ox) * p.ldy + nn : yp;
+  const hdu_bufsrd wsrd = hdu_make_srd(p.w, p.w_bytes);
+  const long long plane_elems = (long long)p.Hi * p.Wi * p.ldx;
+  const unsigned plane_bytes = (unsigned)((((long long)p.Hi * p.Wi - 1) * p.ldx + 8) * 2);
+  const int row_bytes = p.Wi * (int)p.ldx * 2;
+
+  auto stage_plane = [&](int kd) -> const T* {
+    const int pz = od * p.sd + kd - p.pd;
+    return xp + (long long)(n * p.Di + pz) * plane_elems;
   };
-  if (p.accumulate) {
-#pragma unroll 1
-    for (int it0 = 0; it0 < NIT; it0 += 4) {
-      u32x4 old[4];
-      T* dst[4];
-      bool ok[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        dst[u] = out_ptr(tid + (it0 + u) * NTHR, ok[u]);
-        ok[u] = ok[u] && it0 + u < NIT;
-        old[u] = *(const u32x4*)dst[u];                      // unconditional (a lane without a chunk re-reads element 0)
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (!ok[u]) continue;
-        const int q = tid + (it0 + u) * NTHR;
-        const int row = q / NCC, cc = q - row * NCC;
-        float f[8], g[8];
-        Chunk<T>::unpack(*(const u32x4*)(smem + row * ROWB + cc * 16), f);
-        Chunk<T>::unpack(old[u], g);
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) f[jj] += g[jj];
-        *(u32x4*)dst[u] = Chunk<T>::pack(f);
-      }
+  auto issue_piece = [&](const hdu_bufsrd& xsrd, int kd, int kh, char* base, int j, bool live) {
+    const int jj = j * NW + wave;
+    if (jj < XI) {
+      const bool ok = live && (unsigned)(riy[j] + kh) < (unsigned)p.Hi;
+      hdu_bufload_lds16(xsrd, ok ? roff[j] + (unsigned)(kh * row_bytes) : HDU_OOB, base + jj * 1024);
+    } else {
+      const bool ok = live && roff[j] != HDU_OOB;
+      hdu_bufload_lds16(wsrd, ok ? roff[j] + (unsigned)((kd * 7 + kh) * 7 * 8 * 2) : HDU_OOB, base + jj * 1024);
     }
-  } else {
+  };
+
+  f32x16 acc[MT][NTW];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int q = tid + it * NTHR;
-      bool ok;
-      T* dst = out_ptr(q, ok);
-      if (!ok) continue;
-      const int row = q / NCC, cc = q - row * NCC;
-      *(u32x4*)dst = *(const u32x4*)(smem + row * ROWB + cc * 16);
-    }
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // stages: (kd with its plane inside the volume) x kh
+  const int pz0 = od * p.sd - p.pd;
+  const int kd_lo = pz0 < 0 ? -pz0 : 0;
+  const int kd_hi = p.Di - pz0 < p.KD ? p.Di - pz0 : p.KD;
+  const int nst = kd_hi > kd_lo ? (kd_hi - kd_lo) * 7 : 0;
+  int ikd = kd_lo, ikh = 0;
+#pragma unroll
+  for (int pre = 0; pre < NS - 1; ++pre) {
+    const bool live = pre < nst;
+    const hdu_bufsrd xsrd = hdu_make_srd(stage_plane(live ? ikd : kd_lo), plane_bytes);
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) issue_piece(xsrd, ikd, ikh, smem + pre * STAGE, j, live);
+    if (live && ++ikh == 7) { ikh = 0; ++ikd; }
   }
-  if (p.stats_partial)
-    hw_epilogue_stats<C>(p, smem, n0, tid, blockIdx.x, [&](int row) { return y0 + (row >> 5) < p.Ho && x0 + (row & 31) < p.Wo; });
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  int wrow_off[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) wrow_off[j] = XBYTES + ((j * 32 + l31) * 9 + lh) * 16;
+  int xq[MT];                        // slot of (tile row, input pixel 2 * l31 + lh) at k-step 0
+#pragma unroll
+  for (int i = 0; i < MT; ++i) xq[i] = (wave * MT + i) * SEG + 2 * l31 + lh;
+
+  int slot = 0;
+  for (int s = 0; s < nst; ++s) {
+    hw_wait_vmcnt<(NS - 2) * LPW>();
+    HDU_RAW_BARRIER();
+    const bool more = s + NS - 1 < nst;
+    const hdu_bufsrd nxsrd = hdu_make_srd(stage_plane(more ? ikd : kd_lo), plane_bytes);
+    const int nkd = ikd, nkh = ikh;
+    char* nbase = smem + (slot == 0 ? NS - 1 : slot - 1) * STAGE;
+    if (more && ++ikh == 7) { ikh = 0; ++ikd; }
+    const char* Xs = smem + slot * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                          // k-step = input pixels 2 ks, 2 ks + 1 of the 8-pixel window
+      u32x4 af[MT], bf[NTW];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int q = xq[i] + 2 * ks;
+        af[i] = *(const u32x4*)(Xs + ((q ^ ((q >> 4) & 1)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) bf[j] = *(const u32x4*)(Xs + wrow_off[j] + ks * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = hdu_mfma_32x32x16_bf16(bf[j], af[i], acc[i][j]);
+      if (ks < LPW) issue_piece(nxsrd, nkd, nkh, nbase, ks, more);
+    }
+    slot = slot == NS - 1 ? 0 : slot + 1;
+  }
+  const long long mplane = ((long long)n * p.Do + od) * p.Ho;
+  hw_epilogue<C>(p, acc, smem, mplane, y0, x0, n0, wave, 0, lane, tid, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ host side
@@ -422,15 +594,38 @@ static int hw_choose(const ConvK& k, int dtype) {
   return best;
 }
 
-bool hdu_halo_wide_taken(const ConvK& k, int dtype) { return hw_choose(k, dtype) != 0; }
+// the stem kernel's geometry: 7 x 7 (x 7), stride 2 in the plane (and in depth for 7 x 7 x 7), 8 stored channels, plain launch
+static bool stem_ok(const ConvK& k, int dtype) {
+  if (g_tuning[HDU_TUNE_HALO_WIDE] == 1 || dtype != HDU_BF16) return false;
+  if (k.bnb_u != nullptr || k.pro_a != nullptr || k.skip != nullptr || !k.vec_out || (k.ud | k.uh | k.uw) != 0) return false;
+  if (k.KH != 7 || k.KW != 7 || k.sh != 2 || k.sw != 2 || k.ph != 3 || k.pw != 3 || k.Cin != 8) return false;
+  if (!((k.KD == 1 && k.sd == 1 && k.pd == 0) || (k.KD == 7 && k.sd == 2 && k.pd >= 0 && k.pd <= 3))) return false;
+  if (k.Ho != (k.Hi + 6 - 7) / 2 + 1 || k.Wo != (k.Wi + 6 - 7) / 2 + 1 || k.Do != (k.Di + 2 * k.pd - k.KD) / k.sd + 1) return false;
+  if (k.Cout % 8) return false;
+  if ((long long)k.Hi * k.Wi * k.ldx * 2 >= (1ll << 31)) return false;
+  const long long wgs = (long long)k.N * k.Do * ((k.Ho + 15) / 16) * ((k.Wo + 31) / 32) * ((k.Cout + 95) / 96);
+  if (wgs >= (1ll << 31)) return false;
+  if (g_tuning[HDU_TUNE_HALO_WIDE] >= 2) return true;                          // tests: every geometry the kernel covers
+  return k.Wo >= 24 && wgs * k.M_layer / k.M >= 128;
+}
+
+static void stem_launch(const ConvK& k, hipStream_t s) {
+  const int tiles_x = (k.Wo + 31) / 32, tiles_y = (k.Ho + 15) / 16, ngroups = (k.Cout + 95) / 96;
+  const unsigned grid = (unsigned)((long long)k.N * k.Do * tiles_x * tiles_y * ngroups);
+  HDU_LAUNCH(conv_stem_s2_kernel, dim3(grid), dim3(StemCfg::NTHR), 0, s, k, tiles_x, tiles_y, ngroups);
+}
+
+bool hdu_halo_wide_taken(const ConvK& k, int dtype) { return stem_ok(k, dtype) || hw_choose(k, dtype) != 0; }
 
 const char* hdu_halo_wide_name(const ConvK& k, int dtype) {
+  if (stem_ok(k, dtype)) return "conv_stem_s2_kernel";
   static const char* names[7] = {"", "conv_halo_wide_kernel<8x128>", "conv_halo_wide_kernel<16x64>", "conv_halo_wide_kernel<16x96>",
                                  "conv_halo_wide_kernel<8x64>", "conv_halo_wide_kernel<8x96>", "conv_halo_wide_kernel<16x128>"};
   return names[hw_choose(k, dtype)];
 }
 
 bool hdu_halo_wide_launch(const ConvK& k, int dtype, hipStream_t s) {
+  if (stem_ok(k, dtype)) { stem_launch(k, s); return true; }
   switch (hw_choose(k, dtype)) {
     case 1: hw_launch<HW_8x128>(k, s); return true;
     case 2: hw_launch<HW_16x64>(k, s); return true;

@@ -399,6 +399,69 @@ def test_conv_wgrad(hdu, cs, dtype):
     assert_close(dw.cpu(), 2 * wref.grad, F32 if dtype == F32 else BF16, what="wgrad accumulate")
 
 
+STEM_CASES = [
+    dict(N=2, D=1, H=40, W=70, Cin=8, Cout=96, K=(1, 7, 7), s=(1, 2, 2), p=(0, 3, 3), bias=False, ldout=None, id="2d_ragged"),
+    dict(N=1, D=1, H=64, W=64, Cin=8, Cout=96, K=(1, 7, 7), s=(1, 2, 2), p=(0, 3, 3), bias=True, ldout=112, id="2d_exact_slab"),
+    dict(N=1, D=8, H=34, W=50, Cin=8, Cout=96, K=(7, 7, 7), s=(2, 2, 2), p=(3, 3, 3), bias=False, ldout=None, id="3d_ragged"),
+    dict(N=2, D=4, H=12, W=20, Cin=8, Cout=40, K=(7, 7, 7), s=(2, 2, 2), p=(3, 3, 3), bias=True, ldout=None, id="3d_two_volumes_cout40"),
+    dict(N=1, D=10, H=16, W=36, Cin=8, Cout=104, K=(7, 7, 7), s=(2, 2, 2), p=(0, 3, 3), bias=False, ldout=None, id="3d_valid_depth_two_groups"),
+]
+for _c in STEM_CASES:
+    _c.update(up=(0, 0, 0), skip=False, pro=False, ldin=None)
+
+
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in STEM_CASES])
+def test_conv_stem_kernel(hdu, cs):
+    """round 5: the 7 x 7 (x 7) stride-2 stem over 8 stored channels on its own kernel (conv_stem_s2_kernel: contraction ordered
+    (kd, kh | kw, c), row segments staged once per (kd, kh)) against the float64 reference: plain, bias, slab output, two volumes,
+    depth "valid" (the depth-sharded stem), two output-channel groups, epilogue statistics."""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    dtype = BF16
+    b = build_conv_case(ops, cs, dtype)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    if cs["ldout"]:
+        big = ops.Act.alloc(N, Do, Ho, Wo, cs["ldout"], dtype, zero=True)
+        big.buf.fill_(3.0)
+        ya = big.slab(8, Cout)
+    else:
+        big, ya = None, ops.Act.alloc(N, Do, Ho, Wo, Cout, dtype)
+    bias = dev(ops, b["bias"]) if b["bias"] is not None else None
+    wp = ctypes.c_void_p(b["wt"].data_ptr())
+    d = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias)
+    ref = ref_conv(ref_xeff(b["x"], cs["up"], None, None, True, dtype), b["w"], cs["s"], cs["p"], b["bias"])
+    M = N * Do * Ho * Wo
+    try:
+        lib.hdu_set_tuning(29, 2)
+        assert ops.conv_kernel_name(d, 0) == "conv_stem_s2_kernel", ops.conv_kernel_name(d, 0)
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), ref, dtype, what="stem fprop")
+        if big is not None:
+            full = big.to_torch().cpu()
+            assert float((full[..., :8] - 3.0).abs().max()) == 0.0 and float((full[..., 8 + Cout:] - 3.0).abs().max()) == 0.0
+        slots = 8
+        shift = rnd((Cout,), 33, 0.3).float()
+        shift_d = shift.to(ops.device())
+        part = torch.zeros(slots * 2 * Cout, dtype=torch.float32, device=ops.device())
+        d3 = ops.conv_desc(b["xa"], wp, ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias)
+        d3.stats_partial, d3.stats_shift, d3.stats_slots = part.data_ptr(), shift_d.data_ptr(), slots
+        ops.conv_fprop(d3)
+        y = ya.to_torch().cpu().double().reshape(M, Cout)
+        got = part.cpu().double().reshape(slots, 2, Cout).sum(0)
+        dd = y - shift.double()
+        assert float((got[0] - dd.sum(0)).abs().max()) <= 1e-4 * (float(dd.abs().sum(0).max()) + 1e-9)
+        assert float((got[1] - (dd * dd).sum(0)).abs().max()) <= 1e-4 * float((dd * dd).sum(0).max())
+        # the im2col kernels on the same descriptor: equal to rounding
+        lib.hdu_set_tuning(29, 1)
+        assert ops.conv_kernel_name(d, 0) != "conv_stem_s2_kernel"
+        got_stem = ya.to_torch().cpu().double()
+        ops.conv_fprop(d)
+        assert_close(got_stem, ya.to_torch().cpu().double(), dtype, scale=float(ref.abs().max()), what="stem kernel vs im2col")
+    finally:
+        lib.hdu_set_tuning(29, 0)
+
+
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES if c["id"].startswith("halo_tile")])
 def test_conv_wgrad_halo_large_tensor_path(hdu, cs):
     """round 5: tensors of 4 GiB and more (the whole 512^3 volume on one GPU) stay on the halo-tile filter gradient -- the buffer

@@ -93,6 +93,28 @@ def run(layers, tag):
         del x, y, dxe, w
 
 
+def run_stem():
+    for (name, N, D, H, W, K, st, pad) in (("2d stem 8x512^2", 8, 1, 512, 512, (1, 7, 7), (1, 2, 2), (0, 3, 3)),
+                                           ("3d stem 224^2x12", 1, 12, 224, 224, (7, 7, 7), (2, 2, 2), (3, 3, 3)),
+                                           ("3d stem 512^2x64", 1, 64, 512, 512, (7, 7, 7), (2, 2, 2), (3, 3, 3))):
+        x = ops.Act.alloc(N, D, H, W, 8, 0); x.buf.normal_()
+        Do, Ho, Wo = [(n + 2 * p - k) // s_ + 1 for n, p, k, s_ in zip((D, H, W), pad, K, st)]
+        y = ops.Act.alloc(N, Do, Ho, Wo, 96, 0)
+        T = K[0] * 49
+        w = (torch.randn(96 * T * 8, device="cuda") * 0.05).to(torch.bfloat16)
+        d = ops.conv_desc(x, ctypes.c_void_p(w.data_ptr()), y, K, st, pad)
+        flops = 2.0 * N * Do * Ho * Wo * 96 * T * 8
+        line = "stem   %-18s fprop %7.1f GF (8 stored channels) |" % (name, flops / 1e9)
+        for c in (1, 0):
+            lib.hdu_set_tuning(29, c)
+            t = timeit(lambda: ops.conv_fprop(d))
+            line += " %s %7.0f us %5.0f TF |" % (ops.conv_kernel_name(d, 0)[:24], t * 1e3, flops / t / 1e9)
+        lib.hdu_set_tuning(29, 0)
+        print(line, flush=True)
+
+
+if which in ("stem", "all"):
+    run_stem()
 if which in ("2d", "all"):
     run(L2D, "2d")
 if which in ("shard", "all"):
