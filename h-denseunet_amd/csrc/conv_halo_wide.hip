@@ -529,6 +529,195 @@ __global__ __launch_bounds__(StemCfg::NTHR) void conv_stem_s2_kernel(ConvK p, in
   hw_epilogue<C>(p, acc, smem, mplane, y0, x0, n0, wave, 0, lane, tid, blockIdx.x);
 }
 
+// =====================================================================================
+// Stem filter gradient: dW[co][kd][kh][kw][c] of the 7 x 7 (x 7) stride-2 stem over 8 stored channels (the im2col
+// filter-gradient kernel runs it at 0.08 of the MFMA roof -- 2.9 of 41.8 ms at the shard shape -- because a k-chunk of its GEMM is ONE
+// 16-byte pixel).  Here a workgroup owns one depth tap kd and a range of 4 x 32-pixel output tiles; per tile ONE DMA of the dy tile
+// ([128 px][96 co]) and of the 13 input row segments (70 pixels of 16 B) that the 7 kh taps of its 4 output rows touch.  Wave w < 7
+// owns kh = w: D[co][n = kw * 8 + c] += dy^T[co][px] . X[px][n] with px as the MFMA k axis -- for a fixed (kd, kh) the (kw, c)
+// columns of output pixel ow are the 112 contiguous bytes at input pixel 2 * ow - 3 (kw padded to 8: columns 56..63 are discarded).
+// Both operands are read with the transposing LDS load (8 consecutive pixels of one column per lane).  The 7 x 6 accumulator
+// fragments live in registers for the whole range; one float atomic per element at the end.
+struct StemW {
+  static constexpr int TH = 4, TW = 32, PX = TH * TW, SEG = 70, NR = 2 * TH + 5, NW = 8, NTHR = 512, NS = 3;
+  static constexpr int DSLOTS = PX * 12, DI = DSLOTS / 64;            // dy tile: 12 chunks (96 channels) per pixel, 24 pieces
+  static constexpr int XSLOTS = NR * SEG, XI = (XSLOTS + 63) / 64;    // 910 slots, 15 pieces
+  static constexpr int LPW = (DI + XI + NW - 1) / NW;                 // 5
+  static constexpr int STAGE = LPW * NW * 1024, DBYTES = DI * 1024;
+  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+};
+
+__global__ __launch_bounds__(StemW::NTHR) void conv_stem_wgrad_kernel(ConvK p, float* __restrict__ dw, int tiles_x, int tiles_y,
+                                                                      int nsplit, int ngroups) {
+  typedef StemW C;
+  typedef bf16_t T;
+  constexpr int NW = C::NW, NS = C::NS, DI = C::DI, XI = C::XI, LPW = C::LPW, STAGE = C::STAGE, DBYTES = C::DBYTES, SEG = C::SEG;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+#ifdef HDU_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+  // workgroup -> (depth tap kd, split of the tile list, channel group); the KD workgroups of a split are neighbours in the launch
+  // order (they read the same dy tiles) and the XCD-major order keeps them on one L2
+  unsigned t = xcd_tile_index(blockIdx.x, gridDim.x);
+  const int kd = (int)(t % (unsigned)p.KD); t /= (unsigned)p.KD;
+  const int split = (int)(t % (unsigned)nsplit);
+  const int ng = (int)(t / (unsigned)nsplit);
+  const int n0 = ng * 96;
+  // output planes whose input plane od * sd + kd - pd lies inside the volume
+  const int num = p.pd - kd;
+  int od_lo = num > 0 ? (num + p.sd - 1) / p.sd : 0;
+  int od_hi = (p.Di - 1 + p.pd - kd) >= 0 ? (p.Di - 1 + p.pd - kd) / p.sd + 1 : 0;
+  if (od_hi > p.Do) od_hi = p.Do;
+  const int nod = od_hi > od_lo ? od_hi - od_lo : 0;
+  const int ntiles = p.N * nod * tiles_y * tiles_x;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int t0 = split * per;
+  const int t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  const int nt = t1 > t0 ? t1 - t0 : 0;
+
+  // ---- fixed DMA roles: pieces [0, DI) = dy tile, [DI, DI + XI) = input row segments
+  unsigned loff[LPW];
+  int la[LPW], lb[LPW];              // dy: tile row / column of the lane's pixel (la < 0: no chunk); x: segment row / pixel
+#pragma unroll
+  for (int j = 0; j < LPW; ++j) {
+    const int jj = j * NW + wave;
+    la[j] = -1; lb[j] = 0; loff[j] = 0u;
+    if (jj < DI) {
+      const int ps = jj * 64 + lane;
+      const int px = ps / 12, ch = ps - px * 12;
+      const int r = px >> 5, c = px & 31;
+      if (n0 + ch * 8 < p.Cout) {
+        la[j] = r; lb[j] = c;
+        loff[j] = (unsigned)((r * p.Wo + c) * (int)p.ldy + n0 + ch * 8) * 2u;
+      }
+    } else if (jj < DI + XI) {
+      const int ps = (jj - DI) * 64 + lane;
+      const int rr = ps / SEG, cc = ps - rr * SEG;
+      if (ps < C::XSLOTS) {
+        la[j] = rr; lb[j] = cc;
+        loff[j] = (unsigned)((rr * p.Wi + cc) * (int)p.ldx) * 2u;
+      }
+    }
+  }
+  const long long dplane_elems = (long long)p.Ho * p.Wo * p.ldy, xplane_elems = (long long)p.Hi * p.Wi * p.ldx;
+  const unsigned dplane_bytes = (unsigned)((dplane_elems - p.ldy + p.Cout) * 2), xplane_bytes = (unsigned)((xplane_elems - p.ldx + 8) * 2);
+
+  // tile cursor (issue side), advanced incrementally: (tx, ty, odr, n)
+  int i_tx, i_ty, i_od, i_n;
+  {
+    int q = t0;
+    i_tx = q % tiles_x; q /= tiles_x;
+    i_ty = q % tiles_y; q /= tiles_y;
+    i_od = nod > 0 ? q % nod : 0;
+    i_n = nod > 0 ? q / nod : 0;
+  }
+  auto issue_tile = [&](int slot, bool live) {
+    char* base = smem + slot * STAGE;
+    const int y0 = i_ty * C::TH, x0 = i_tx * C::TW;
+    const int od = od_lo + i_od;
+    const int n = live ? i_n : 0;
+    const hdu_bufsrd dsrd = hdu_make_srd((const T*)p.y + (long long)(n * p.Do + (live ? od : 0)) * dplane_elems, dplane_bytes);
+    const hdu_bufsrd xsrd = hdu_make_srd((const T*)p.x + (long long)(n * p.Di + (live ? od * p.sd + kd - p.pd : 0)) * xplane_elems, xplane_bytes);
+    const unsigned dbase = (unsigned)((y0 * p.Wo + x0) * (int)p.ldy) * 2u;
+    const int iy0 = 2 * y0 - p.ph, ix0 = 2 * x0 - p.pw;
+    const unsigned xbase = (unsigned)((iy0 * p.Wi + ix0) * (int)p.ldx) * 2u;      // (modular: the sum with a valid lane offset is in range)
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+      const int jj = j * NW + wave;
+      if (jj < DI) {
+        const bool ok = live && la[j] >= 0 && y0 + la[j] < p.Ho && x0 + lb[j] < p.Wo;
+        hdu_bufload_lds16(dsrd, ok ? dbase + loff[j] : HDU_OOB, base + jj * 1024);
+      } else {
+        const bool ok = live && la[j] >= 0 && (unsigned)(iy0 + la[j]) < (unsigned)p.Hi && (unsigned)(ix0 + lb[j]) < (unsigned)p.Wi;
+        hdu_bufload_lds16(xsrd, ok ? xbase + loff[j] : HDU_OOB, base + jj * 1024);
+      }
+    }
+    if (live) {
+      if (++i_tx == tiles_x) {
+        i_tx = 0;
+        if (++i_ty == tiles_y) {
+          i_ty = 0;
+          if (++i_od == nod) { i_od = 0; ++i_n; }
+        }
+      }
+    }
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int pre = 0; pre < NS - 1; ++pre) issue_tile(pre, pre < nt);
+
+  // per-lane fragment addressing (tile-invariant): transposing reads, 16-lane groups = 4 pixel rows x 16 columns
+  const int li = lane & 15, g16 = (lane >> 4) & 1, lh = lane >> 5;
+  const int kh = wave;                                   // wave 7 only moves data
+  const int kpix = 8 * lh + (li >> 2);                   // pixel (k index) of the first half; + 4 for the second
+  int doff[3], xoff[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) doff[i] = kpix * 192 + (i * 32 + g16 * 16 + (li & 3) * 4) * 2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) xoff[j] = DBYTES + (kh * SEG + 2 * kpix) * 16 + (j * 32 + g16 * 16 + (li & 3) * 4) * 2;
+
+  int slot = 0;
+  for (int s = 0; s < nt; ++s) {
+    hw_wait_vmcnt<(NS - 2) * LPW>();
+    HDU_RAW_BARRIER();
+    issue_tile(slot == 0 ? NS - 1 : slot - 1, s + NS - 1 < nt);
+    if (kh < 7) {
+      const char* St = smem + slot * STAGE;
+#pragma unroll
+      for (int r = 0; r < C::TH; ++r)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 af[3], bf[2];
+          const int dbase = (r * 32 + ks * 16) * 192;                   // dy rows of these 16 pixels
+          const int xb = (2 * r * SEG + 32 * ks) * 16;                  // input row 2 r (+ kh), input pixel 2 * (16 ks)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const u32x2 lo = hdu_lds_tr16_b64(St + dbase + doff[i]);
+            const u32x2 hi = hdu_lds_tr16_b64(St + dbase + doff[i] + 4 * 192);
+            af[i] = u32x4{lo.x, lo.y, hi.x, hi.y};
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const u32x2 lo = hdu_lds_tr16_b64(St + xb + xoff[j]);
+            const u32x2 hi = hdu_lds_tr16_b64(St + xb + xoff[j] + 8 * 16);
+            bf[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = hdu_mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+        }
+    }
+    slot = slot == NS - 1 ? 0 : slot + 1;
+  }
+  hw_wait_vmcnt<0>();
+  if (kh >= 7 || nt == 0) return;
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nn = j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nn < 56 && co < p.Cout) atomicAdd(dw + ((long long)(co * p.KD + kd) * 7 + kh) * 56 + nn, acc[i][j][r]);
+      }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // configurations: (tile rows, 32-channel groups, waves along the tile rows, waves along the channel groups, ring stages)
 typedef HaloWide<8, 4, 4, 2, 3> HW_8x128;        // 512 threads, 144 KB: one workgroup per CU
@@ -594,15 +783,19 @@ static int hw_choose(const ConvK& k, int dtype) {
   return best;
 }
 
-// the stem kernel's geometry: 7 x 7 (x 7), stride 2 in the plane (and in depth for 7 x 7 x 7), 8 stored channels, plain launch
-static bool stem_ok(const ConvK& k, int dtype) {
+// the stem kernels' geometry: 7 x 7 (x 7), stride 2 in the plane (and in depth for 7 x 7 x 7), 8 stored channels, plain launch
+static bool stem_geom_ok(const ConvK& k, int dtype) {
   if (g_tuning[HDU_TUNE_HALO_WIDE] == 1 || dtype != HDU_BF16) return false;
   if (k.bnb_u != nullptr || k.pro_a != nullptr || k.skip != nullptr || !k.vec_out || (k.ud | k.uh | k.uw) != 0) return false;
   if (k.KH != 7 || k.KW != 7 || k.sh != 2 || k.sw != 2 || k.ph != 3 || k.pw != 3 || k.Cin != 8) return false;
   if (!((k.KD == 1 && k.sd == 1 && k.pd == 0) || (k.KD == 7 && k.sd == 2 && k.pd >= 0 && k.pd <= 3))) return false;
   if (k.Ho != (k.Hi + 6 - 7) / 2 + 1 || k.Wo != (k.Wi + 6 - 7) / 2 + 1 || k.Do != (k.Di + 2 * k.pd - k.KD) / k.sd + 1) return false;
   if (k.Cout % 8) return false;
-  if ((long long)k.Hi * k.Wi * k.ldx * 2 >= (1ll << 31)) return false;
+  return (long long)k.Hi * k.Wi * k.ldx * 2 < (1ll << 31);
+}
+
+static bool stem_ok(const ConvK& k, int dtype) {
+  if (!stem_geom_ok(k, dtype)) return false;
   const long long wgs = (long long)k.N * k.Do * ((k.Ho + 15) / 16) * ((k.Wo + 31) / 32) * ((k.Cout + 95) / 96);
   if (wgs >= (1ll << 31)) return false;
   if (g_tuning[HDU_TUNE_HALO_WIDE] >= 2) return true;                          // tests: every geometry the kernel covers
@@ -613,6 +806,26 @@ static void stem_launch(const ConvK& k, hipStream_t s) {
   const int tiles_x = (k.Wo + 31) / 32, tiles_y = (k.Ho + 15) / 16, ngroups = (k.Cout + 95) / 96;
   const unsigned grid = (unsigned)((long long)k.N * k.Do * tiles_x * tiles_y * ngroups);
   HDU_LAUNCH(conv_stem_s2_kernel, dim3(grid), dim3(StemCfg::NTHR), 0, s, k, tiles_x, tiles_y, ngroups);
+}
+
+// filter gradient of the same layers (dy is `y` of the descriptor): same geometry test, any size (its im2col form is the slowest
+// kernel family of the library), planes within 32-bit byte offsets
+bool hdu_stem_wgrad_taken(const ConvK& k, int dtype) {
+  return stem_geom_ok(k, dtype) && k.ldy % 8 == 0 && (long long)k.Ho * k.Wo * k.ldy * 2 < (1ll << 31) &&
+         (long long)k.Cout * k.KD * 49 * 8 < (1ll << 31);
+}
+
+bool hdu_stem_wgrad_launch(const ConvK& k, int dtype, float* dw, hipStream_t s) {
+  if (!hdu_stem_wgrad_taken(k, dtype)) return false;
+  const int tiles_x = (k.Wo + 31) / 32, tiles_y = (k.Ho + 3) / 4, ngroups = (k.Cout + 95) / 96;
+  const long long tiles = (long long)k.N * k.Do * tiles_x * tiles_y;
+  // ~2 workgroups per CU over the launch, at least 8 tiles each (a workgroup ends with 96 x 56 x 7 float atomics)
+  long long nsplit = 512 / ((long long)k.KD * ngroups);
+  if (nsplit > tiles / 8) nsplit = tiles / 8;
+  if (nsplit < 1) nsplit = 1;
+  const unsigned grid = (unsigned)(nsplit * k.KD * ngroups);
+  HDU_LAUNCH(conv_stem_wgrad_kernel, dim3(grid), dim3(StemW::NTHR), 0, s, k, dw, tiles_x, tiles_y, (int)nsplit, ngroups);
+  return true;
 }
 
 bool hdu_halo_wide_taken(const ConvK& k, int dtype) { return stem_ok(k, dtype) || hw_choose(k, dtype) != 0; }

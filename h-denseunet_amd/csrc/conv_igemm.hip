@@ -3294,6 +3294,8 @@ static void dispatch_igemm(const ConvK& k, size_t skb, hipStream_t s) {
 bool hdu_halo_wide_taken(const ConvK& k, int dtype);
 const char* hdu_halo_wide_name(const ConvK& k, int dtype);
 bool hdu_halo_wide_launch(const ConvK& k, int dtype, hipStream_t s);
+bool hdu_stem_wgrad_taken(const ConvK& k, int dtype);
+bool hdu_stem_wgrad_launch(const ConvK& k, int dtype, float* dw, hipStream_t s);
 
 static bool fprop_halo_ok(const ConvK& k, int dtype) {
   return dtype == HDU_BF16 && k.bnb_u == nullptr && !g_tuning[HDU_TUNE_NO_HALO_FPROP] && k.pro_a == nullptr && k.skip == nullptr && k.KD == 1 &&
@@ -3555,6 +3557,7 @@ extern "C" int hdu_conv_wgrad(const hdu_conv_desc* d, float* dw, void* stream) {
   if (!dw || !d->y) return hdu_set_error(HDU_ERR_ARG, "conv_wgrad: null dw / dy");
   if ((uintptr_t)d->y % 16) return hdu_set_error(HDU_ERR_ARG, "conv_wgrad: dy must be 16-byte aligned");
   if (k.M == 0) return 0;
+  if (hdu_stem_wgrad_launch(k, d->dtype, dw, (hipStream_t)stream)) return hdu_check_launch("conv_wgrad(stem)");
   if (d->dtype == HDU_BF16) dispatch_wgrad<bf16_t>(k, dw, (hipStream_t)stream);
   else dispatch_wgrad<float>(k, dw, (hipStream_t)stream);
   return hdu_check_launch("conv_wgrad");
@@ -3738,7 +3741,8 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     const bool dma = wgrad_dma_ok(k);
     const bool pw = k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 && (k.pd | k.ph | k.pw) == 0 &&
                     (k.ud | k.uh | k.uw) == 0;
-    if (d->dtype == HDU_BF16 && wgrad_halo_ok(k)) snprintf(buf, buflen, "conv_wgrad_halo_kernel<%d>", choose_wgrad(k));
+    if (hdu_stem_wgrad_taken(k, d->dtype)) snprintf(buf, buflen, "conv_stem_wgrad_kernel");
+    else if (d->dtype == HDU_BF16 && wgrad_halo_ok(k)) snprintf(buf, buflen, "conv_wgrad_halo_kernel<%d>", choose_wgrad(k));
     else if (d->dtype == HDU_BF16 && dma) snprintf(buf, buflen, "conv_wgrad_dma_kernel<%d, %s>", choose_wgrad(k), pw ? "true" : "false");
     else if (d->dtype == HDU_BF16) snprintf(buf, buflen, "conv_wgrad_tr_kernel<%d>", choose_wgrad(k));
     else snprintf(buf, buflen, "conv_wgrad_kernel<float, %d>", choose_wgrad(k));

@@ -356,6 +356,8 @@ class Ctx:
                                   (cv.bn.a, cv.bn.b), cv.bn.relu)
             else:
                 continue                    # fused prologue: per-layer launch
+            if ops.conv_kernel_name(d, 1) == "conv_stem_wgrad_kernel":
+                continue                    # the 7 x 7 (x 7) stem has its own filter-gradient kernel (round 5): per-layer launch
             plan.add(d, cv.kernel.grad)
             cv.in_plan = True
         if len(plan):

@@ -462,6 +462,30 @@ def test_conv_stem_kernel(hdu, cs):
         lib.hdu_set_tuning(29, 0)
 
 
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in STEM_CASES])
+def test_conv_stem_wgrad_kernel(hdu, cs):
+    """round 5: the stem's filter gradient on its own kernel (conv_stem_wgrad_kernel: one depth tap and a range of output tiles per
+    workgroup, wave = kh, pixels as the MFMA k axis, both operands through transposing LDS reads) against autograd of the float64
+    reference; a second call accumulates."""
+    import ctypes
+    ops = ops_mod()
+    dtype = BF16
+    b = build_conv_case(ops, cs, dtype, seed=100)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    dy = rnd((N, Do, Ho, Wo, Cout), 777, 1.0, dtype)
+    dya = mkact(ops, dy, dtype, cs["ldout"], 8 if cs["ldout"] else 0)
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), dya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, None)
+    assert ops.conv_kernel_name(d, 1) == "conv_stem_wgrad_kernel", ops.conv_kernel_name(d, 1)
+    dw = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+    ops.conv_wgrad(d, dw)
+    xe = ref_xeff(b["x"], cs["up"], None, None, True, dtype).requires_grad_(True)
+    wref = b["w"].clone().requires_grad_(True)
+    (ref_conv(xe, wref, cs["s"], cs["p"], None) * dy).sum().backward()
+    assert_close(dw.cpu(), wref.grad, BF16, what="stem wgrad")
+    ops.conv_wgrad(d, dw)
+    assert_close(dw.cpu(), 2 * wref.grad, BF16, what="stem wgrad accumulate")
+
+
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES if c["id"].startswith("halo_tile")])
 def test_conv_wgrad_halo_large_tensor_path(hdu, cs):
     """round 5: tensors of 4 GiB and more (the whole 512^3 volume on one GPU) stay on the halo-tile filter gradient -- the buffer

@@ -111,6 +111,15 @@ def run_stem():
             line += " %s %7.0f us %5.0f TF |" % (ops.conv_kernel_name(d, 0)[:24], t * 1e3, flops / t / 1e9)
         lib.hdu_set_tuning(29, 0)
         print(line, flush=True)
+        y.buf.normal_()
+        dw = torch.zeros(96 * T * 8, device="cuda")
+        line = "stem   %-18s wgrad %7.1f GF (8 stored channels) |" % (name, flops / 1e9)
+        for c in (1, 0):
+            lib.hdu_set_tuning(29, c)
+            t = timeit(lambda: ops.conv_wgrad(d, dw))
+            line += " %s %7.0f us %5.0f TF |" % (ops.conv_kernel_name(d, 1)[:24], t * 1e3, flops / t / 1e9)
+        lib.hdu_set_tuning(29, 0)
+        print(line, flush=True)
 
 
 if which in ("stem", "all"):
