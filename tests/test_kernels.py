@@ -556,6 +556,63 @@ def test_halo_filter_gradient_random_geometries(hdu, cs):
     assert_close(dw.cpu(), wref.grad, BF16, what="halo wgrad %s" % (cs,))
 
 
+def _halo_wide_geometries():
+    rng = np.random.default_rng(20260926)
+    out = []
+    while len(out) < 24:
+        three_d = bool(rng.integers(0, 3))            # two thirds 3D
+        up = tuple(int(v) for v in rng.integers(0, 2, 3)) if rng.integers(0, 3) == 0 else (0, 0, 0)
+        if not three_d:
+            up = (0, up[1], up[2])
+        N, D = int(rng.integers(1, 3)), (int(rng.integers(1, 5)) if three_d else 1)
+        H, W = int(rng.integers(2, 20)), int(rng.integers(5, 21)) if up[2] else int(rng.integers(9, 41))
+        Cin, Cout = int(rng.choice([8, 16, 24, 40, 56])), int(rng.choice([8, 32, 40, 72, 104, 136]))
+        pd = 1
+        if three_d:
+            pd = int(rng.choice([1, 0, -1])) if up[0] else int(rng.choice([1, 0]))
+            if (D << up[0]) + 2 * pd - 2 < 1:
+                continue
+        out.append(dict(N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, K=(3, 3, 3) if three_d else (1, 3, 3), s=(1, 1, 1),
+                        p=(pd if three_d else 0, 1, 1), up=up, skip=False, pro=False, bias=bool(rng.integers(0, 2)),
+                        ldin=(Cin + 16 if rng.integers(0, 2) else None), ldout=(Cout + 24 if rng.integers(0, 2) else None),
+                        cfg=int(rng.integers(2, 8)), id="geo%d" % len(out)))
+    return out
+
+
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in _halo_wide_geometries()])
+def test_halo_wide_random_geometries(hdu, cs):
+    """seeded sweep over the geometry space of the halo-tile forward / data-gradient kernel (2D / 3D, depth same / valid / cropped behind
+    a depth up-sampling, up-sampling per axis, ragged tiles in H and W, ragged 16-channel stages and 32-channel output groups, several
+    volumes, slab input / output, a random tile configuration each): plain + accumulate against the float64 reference"""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib.get()
+    b = build_conv_case(ops, cs, BF16, seed=900)
+    N, Do, Ho, Wo, Cout = b["out_dims"]
+    if cs["ldout"]:
+        big = ops.Act.alloc(N, Do, Ho, Wo, cs["ldout"], BF16, zero=True)
+        big.buf.fill_(3.0)
+        ya = big.slab(8, Cout)
+    else:
+        big, ya = None, ops.Act.alloc(N, Do, Ho, Wo, Cout, BF16)
+    bias = dev(ops, b["bias"]) if b["bias"] is not None else None
+    d = ops.conv_desc(b["xa"], ctypes.c_void_p(b["wt"].data_ptr()), ya, cs["K"], cs["s"], cs["p"], cs["up"], None, None, True, bias)
+    ref = ref_conv(ref_xeff(b["x"], cs["up"], None, None, True, BF16), b["w"], cs["s"], cs["p"], b["bias"])
+    try:
+        lib.hdu_set_tuning(29, cs["cfg"])
+        assert ops.conv_kernel_name(d, 0).startswith("conv_halo_wide_kernel"), (cs, ops.conv_kernel_name(d, 0))
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), ref, BF16, what="halo-wide fprop %s" % (cs,))
+        if big is not None:
+            full = big.to_torch().cpu()
+            assert float((full[..., :8] - 3.0).abs().max()) == 0.0 and float((full[..., 8 + Cout:] - 3.0).abs().max()) == 0.0
+        d.accumulate = 1
+        ops.conv_fprop(d)
+        assert_close(ya.to_torch().cpu(), q(ref, BF16) * 2, BF16, scale=2 * float(ref.abs().max()), what="halo-wide accumulate %s" % (cs,))
+    finally:
+        lib.hdu_set_tuning(29, 0)
+
+
 SPLIT_CASES = [c for c in CONV_CASES if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "decoder_up_skip_2d", "dense3x3x3", "stem7x7s2",
                                                      "wide_bn128", "pw_pro_two_stage", "pw_pro_wide_table_splitk")]
 
