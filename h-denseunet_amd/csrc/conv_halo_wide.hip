@@ -726,6 +726,7 @@ typedef HaloWide<16, 3, 8, 1, 3> HW_16x96;       // 512 threads, 144 KB
 typedef HaloWide<8, 2, 4, 1, 2> HW_8x64;         // 256 threads, 64 KB: two workgroups per CU
 typedef HaloWide<8, 3, 4, 1, 2> HW_8x96;         // 256 threads, 80 KB: two workgroups per CU
 typedef HaloWide<16, 4, 8, 1, 2> HW_16x128;      // 512 threads, 112 KB, two stages
+typedef HaloWide<16, 2, 4, 1, 2> HW_16x64p;      // 256 threads, 80 KB, two stages: two workgroups per CU, 4 x 2 fragments per wave (large grids)
 
 struct HwChoice { int cfg; };                    // 1..5 in the order above, 0 = not taken
 
@@ -755,23 +756,26 @@ static bool hw_shape_ok(const ConvK& k, int dtype) {
 // a compute unit is handed load = ceil(workgroups / 256) workgroups; each needs stages x TH x NT x 9 / 4 MFMA slots of the pipe
 // the co-resident workgroups share (measured 0.58-0.74 busy in the K loop), and a fixed prologue + epilogue per workgroup that a
 // co-resident partner mostly hides (two-workgroup configurations).  Padded output channels and tile rows are paid in full.
+static constexpr int NCFG = 7;
 static int hw_choose(const ConvK& k, int dtype) {
   const int force = g_tuning[HDU_TUNE_HALO_WIDE];
   if (force == 1 || !hw_shape_ok(k, dtype)) return 0;
-  if (force >= 2) return force - 1 <= 6 ? force - 1 : 0;
+  if (force >= 2) return force - 1 <= NCFG ? force - 1 : 0;
   if (k.Cin < 32 || k.Cout < 48 || k.We < 24) return 0;
   const double scale = (double)k.M_layer / (double)k.M;                        // planes of the whole layer per plane of this launch
-  const int th[6] = {8, 16, 16, 8, 8, 16}, nt[6] = {4, 2, 3, 2, 3, 4}, occ[6] = {1, 1, 1, 2, 2, 1};
-  const double busy[6] = {0.60, 0.68, 0.68, 0.58, 0.58, 0.74};
+  constexpr int NC = 7;
+  const int th[NC] = {8, 16, 16, 8, 8, 16, 16}, nt[NC] = {4, 2, 3, 2, 3, 4, 2}, occ[NC] = {1, 1, 1, 2, 2, 1, 2};
+  const double busy[NC] = {0.60, 0.68, 0.68, 0.58, 0.58, 0.74, 0.76};
   const double nst = (double)((k.Cin + 15) / 16) * k.KD;
   int best = 0;
   double best_cost = 0., best_wgs = 0.;
-  for (int c = 0; c < 6; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int bn = nt[c] * 32;
     const double wgs = (double)k.N * k.Do * ((k.He + th[c] - 1) / th[c]) * ((k.We + 31) / 32) * scale * (double)((k.Cout + bn - 1) / bn);
     const double load = __builtin_ceil(wgs / 256.0);
     const double work = (double)th[c] * nt[c];
-    const double main_ = nst * work / busy[c];
+    // (16x64p: 4 x 2 fragments per wave, ONE wave per SIMD and workgroup -- it needs a co-resident partner: measured 0.50 alone)
+    const double main_ = nst * work / ((c == 6 && load < 4.) ? 0.50 : busy[c]);
     const double fixed = 40.0 + work;
     const double cost = load * main_ + __builtin_ceil(load / occ[c]) * fixed * ((occ[c] == 2 && load >= 2.) ? 0.3 : 1.0);
     if (best == 0 || cost < best_cost) { best = c + 1; best_cost = cost; best_wgs = wgs; }
@@ -832,8 +836,9 @@ bool hdu_halo_wide_taken(const ConvK& k, int dtype) { return stem_ok(k, dtype) |
 
 const char* hdu_halo_wide_name(const ConvK& k, int dtype) {
   if (stem_ok(k, dtype)) return "conv_stem_s2_kernel";
-  static const char* names[7] = {"", "conv_halo_wide_kernel<8x128>", "conv_halo_wide_kernel<16x64>", "conv_halo_wide_kernel<16x96>",
-                                 "conv_halo_wide_kernel<8x64>", "conv_halo_wide_kernel<8x96>", "conv_halo_wide_kernel<16x128>"};
+  static const char* names[8] = {"", "conv_halo_wide_kernel<8x128>", "conv_halo_wide_kernel<16x64>", "conv_halo_wide_kernel<16x96>",
+                                 "conv_halo_wide_kernel<8x64>", "conv_halo_wide_kernel<8x96>", "conv_halo_wide_kernel<16x128>",
+                                 "conv_halo_wide_kernel<16x64p>"};
   return names[hw_choose(k, dtype)];
 }
 
@@ -846,6 +851,7 @@ bool hdu_halo_wide_launch(const ConvK& k, int dtype, hipStream_t s) {
     case 4: hw_launch<HW_8x64>(k, s); return true;
     case 5: hw_launch<HW_8x96>(k, s); return true;
     case 6: hw_launch<HW_16x128>(k, s); return true;
+    case 7: hw_launch<HW_16x64p>(k, s); return true;
     default: return false;
   }
 }

@@ -93,8 +93,9 @@ int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
                                         hi + lo and contracted as ah.bh + ah.bl + al.bh on the bf16 MFMA with the float32 accumulator
                                         ("bf16 x 3": <= 3 * 2^-18 relative per product; storage, statistics and every row kernel stay float32) */
 #define HDU_TUNE_HALO_WIDE 29        /* halo-tile forward / data-gradient kernel for the wide 3x3 / 3x3x3 layers (conv_halo_wide.hip, round 5):
-                                        0 = library heuristic (default), 1 = off (A/B: the im2col kernels of rounds 1-4), 2..6 = force
-                                        configuration 8x128 / 16x64 / 16x96 / 8x64 / 8x96 (tile rows x output channels) where the shape allows */
+                                        0 = library heuristic (default), 1 = off (A/B: the im2col kernels of rounds 1-4), 2..8 = force
+                                        configuration 8x128 / 16x64 / 16x96 / 8x64 / 8x96 / 16x128 / 16x64p (tile rows x output channels) where the shape allows;
+                                        any value >= 2 also lets the stem kernels take geometries below their size thresholds (tests) */
 #define HDU_TUNE_WGRAD_NCT 21        /* 1 = one filter-row tile per pointwise filter-gradient workgroup (round 2's form; A/B) */
 int hdu_set_tuning(int key, int value);
 

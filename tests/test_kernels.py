@@ -285,7 +285,7 @@ HALO_WIDE_CASES = [
 ]
 for _c in HALO_WIDE_CASES:
     _c.update(s=(1, 1, 1), skip=False, pro=False)
-HALO_WIDE_CFGS = [(2, "8x128"), (3, "16x64"), (4, "16x96"), (5, "8x64"), (6, "8x96"), (7, "16x128")]
+HALO_WIDE_CFGS = [(2, "8x128"), (3, "16x64"), (4, "16x96"), (5, "8x64"), (6, "8x96"), (7, "16x128"), (8, "16x64p")]
 
 
 @pytest.mark.parametrize("cfg", [pytest.param(c[0], id=c[1]) for c in HALO_WIDE_CFGS])
@@ -575,7 +575,7 @@ def _halo_wide_geometries():
         out.append(dict(N=N, D=D, H=H, W=W, Cin=Cin, Cout=Cout, K=(3, 3, 3) if three_d else (1, 3, 3), s=(1, 1, 1),
                         p=(pd if three_d else 0, 1, 1), up=up, skip=False, pro=False, bias=bool(rng.integers(0, 2)),
                         ldin=(Cin + 16 if rng.integers(0, 2) else None), ldout=(Cout + 24 if rng.integers(0, 2) else None),
-                        cfg=int(rng.integers(2, 8)), id="geo%d" % len(out)))
+                        cfg=int(rng.integers(2, 9)), id="geo%d" % len(out)))
     return out
 
 

@@ -18,7 +18,7 @@ lib = pkg.lib.get()
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 ONLY = os.environ.get("HW_ONLY")          # "layer:form" -- one layer / form only (PMC probes)
 cfgs = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 0, 2, 3, 4, 5, 6, 7]
-NAMES = {1: "im2col", 0: "auto", 2: "8x128", 3: "16x64", 4: "16x96", 5: "8x64", 6: "8x96", 7: "16x128"}
+NAMES = {1: "im2col", 0: "auto", 2: "8x128", 3: "16x64", 4: "16x96", 5: "8x64", 6: "8x96", 7: "16x128", 8: "16x64p"}
 
 # (name, N, D, H, W (stored input), Cin, Cout, K, up)
 L2D = [
@@ -76,7 +76,7 @@ def run(layers, tag):
         d_d = ops.conv_desc(y, ctypes.c_void_p(w.data_ptr()), dxe, K, (1, 1, 1), pad)
         flops = 2.0 * N * De * He * We * Cout * T * Cin
         for form, d in (("fprop", d_f), ("dgrad", d_d)):
-            if ONLY and ONLY != name + ":" + form:
+            if ONLY and ":" in ONLY and ONLY != name + ":" + form:
                 continue
             line = "%-6s %-13s %-5s %6.1f GF |" % (tag, name, form, flops / 1e9)
             for c in cfgs:
