@@ -770,6 +770,7 @@ static int hw_choose(const ConvK& k, int dtype) {
   int best = 0;
   double best_cost = 0., best_wgs = 0.;
   for (int c = 0; c < NC; ++c) {
+    if (c == 6 && (g_tuning[HDU_TUNE_DEBUG] & 512)) continue;                  // A/B: without the two-per-CU 16 x 64 form
     const int bn = nt[c] * 32;
     const double wgs = (double)k.N * k.Do * ((k.He + th[c] - 1) / th[c]) * ((k.We + 31) / 32) * scale * (double)((k.Cout + bn - 1) / bn);
     const double load = __builtin_ceil(wgs / 256.0);
