@@ -563,7 +563,7 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
         rec["top_kernels"] = top_kernels(agg, dtype)
         rec["step_roofline"] = step_roofline(agg, dtype)
         fl3, ms3, n3 = instrumented_step.dense_blocks_3d
-        if n3:       # north_star: "MFMA roofline on the 3D dense-block fwd+bwd" -- the convs of conv_block3d, all three passes
+        if n3 and ms3 > 0:       # north_star: "MFMA roofline on the 3D dense-block fwd+bwd" -- the convs of conv_block3d, all three passes
             rec["dense_blocks_3d"] = {"conv_launches": n3, "ms": round(ms3, 3), "gflop": round(fl3 / 1e9, 1),
                                       "mfma_frac": round(fl3 / (ms3 * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4),
                                       "note": "convolutions of conv_block3d (1x1x1 + 3x3x3; forward, data gradient, filter gradient) only"}
