@@ -349,32 +349,44 @@ def cpu_baseline(config, size, cols, samples=2):
     kind = "2d" if config == "2d" else "hybrid"
     variant = {"2d": "denseunet", "3dpart": "3dpart", "end2end": "end2end"}[config]
     b = 1
-    cores = physical_cores()
+    phys = physical_cores()
     prev = torch.get_num_threads()
-    torch.set_num_threads(cores)
+    # Round 5: the thread count is PROBED -- this graph is thousands of small ops, and on the 128-core GPU host a team of all physical
+    # cores spends its time in fork / join (tools/oracle_pair_timing.py: 59.5 s with 128 threads, 23.6 s with 64, 15.0 s with 32).  Rounds
+    # 1-4 reported the 128-thread figure, i.e. a CPU baseline ~4x slower than the host can do.  One step per candidate count, then the
+    # remaining samples at the best one; `cores` = the threads of the reported figure.
+    cands = [c for c in (16, 32, 64) if c <= phys] or [phys]
+    times = {}
     try:
         x, y = U.synthetic_batch(kind, b, size, cols)
         P = R.ParamStore(seed=4321, dtype=torch.float32, perturb=False)
         fwd = U.oracle_forward_fn(kind, variant, (6, 12, 36, 24), (3, 4, 12, 8))
+        torch.set_num_threads(cands[len(cands) // 2])
         with torch.no_grad():
             fwd(P, torch.tensor(x))      # creates the parameters (not timed)
         P.bn_batch_means = {}
         vel = {}
-        times = []
-        for _ in range(samples):
+
+        def one(c):
+            torch.set_num_threads(c)
             t1 = time.time()
             R.train_step(P, fwd, U.loss_fn_for(kind), torch.tensor(x), torch.tensor(y), vel)
-            times.append(time.time() - t1)
+            times.setdefault(c, []).append(time.time() - t1)
+        for c in cands:
+            one(c)
+        best_c = min(times, key=lambda c: min(times[c]))
+        for _ in range(max(0, samples - 1)):
+            one(best_c)
     finally:
         torch.set_num_threads(prev)
     slices = b if kind == "2d" else cols
-    best = min(times)
-    return {"value": round(slices / best, 4), "unit": "slices/s", "cores": cores, "logical_cpus": os.cpu_count(),
+    best = min(times[best_c])
+    return {"value": round(slices / best, 4), "unit": "slices/s", "cores": best_c, "physical_cores": phys, "logical_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": "%d training steps (fwd+bwd+SGD) of the float32 torch-CPU restatement of the reference graph "
-                      "(not TensorFlow) on %s, torch threads = physical cores; per-step seconds %s, best used" %
-                      (samples, "1x%dx%d" % (size, size) if kind == "2d" else "one %dx%dx%d volume" % (size, size, cols),
-                       [round(t, 1) for t in times])}
+            "sample": "training steps (fwd+bwd+SGD) of the float32 torch-CPU restatement of the reference graph (not TensorFlow) on %s; "
+                      "torch thread count probed, seconds per step by thread count %s, best used" %
+                      ("1x%dx%d" % (size, size) if kind == "2d" else "one %dx%dx%d volume" % (size, size, cols),
+                       {c: [round(t, 1) for t in ts] for c, ts in times.items()})}
 
 
 def pmc_traffic(kernel, config, dtype):

@@ -109,6 +109,39 @@ def oracle_with(weights, kind, variant, b, size, cols, nb2d=FULL2D, nb3d=FULL3D)
     return P, fwd
 
 
+def oracle_pair(weights, kind, variant, b, size, cols, nb2d, nb3d, xt, yt):
+    """predict + one training step of the float32 oracle and of the bf16-storage oracle (the calibration run), SIDE BY SIDE on two
+    host threads: the 161-layer nets are thousands of small CPU ops that do not scale to the box's 128 cores, so the two
+    independent runs overlap almost for free (the GPU tier's time is mostly this oracle).
+    HDU_PARITY_SERIAL_ORACLE=1 runs them one after the other (the results are identical: separate ParamStores, no shared state).
+    Returns (P, fwd, (pred, loss, grads, logits) of the float32 oracle, the same of the bf16-storage oracle)."""
+    import threading
+    P, fwd = oracle_with(weights, kind, variant, b, size, cols, nb2d, nb3d)
+    Pb, _ = oracle_with(weights, kind, variant, b, size, cols, nb2d, nb3d)
+    Pb.store_bf16 = True
+    out, err = {}, []
+
+    def run(tag, ps):
+        try:
+            pred = U.R.predict(ps, fwd, xt).numpy()
+            out[tag] = (pred,) + tuple(U.R.train_step(ps, fwd, U.loss_fn_for(kind), xt, yt, {}))
+        except BaseException as e:      # noqa: BLE001 -- re-raised on the test's thread
+            err.append(e)
+
+    if os.environ.get("HDU_PARITY_SERIAL_ORACLE") == "1":
+        run("ref", P)
+        run("cal", Pb)
+    else:
+        # (every host thread drives its OWN OpenMP team of torch.get_num_threads() threads: parity_utils caps that at 32, see there)
+        th = threading.Thread(target=run, args=("cal", Pb))
+        th.start()
+        run("ref", P)
+        th.join()
+    if err:
+        raise err[0]
+    return P, fwd, out["ref"], out["cal"]
+
+
 def product_with(weights, kind, variant, b, size, cols, dtype, nb2d=FULL2D, nb3d=FULL3D):
     if kind == "2d":
         mod = U.pkg("denseunet" if variant == "denseunet" else "densenet")
@@ -197,13 +230,8 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols,
     kind_tag = "%s/%s/%s" % (kind, variant, recipe)
 
     # ---- oracle: predict, float32 step, bf16-storage step (calibration)
-    P, fwd = oracle_with(W, kind, variant, b, size, cols, nb2d, nb3d)
-    ref_pred = U.R.predict(P, fwd, xt).numpy()
-    ref_loss, ref_grads, ref_logits = U.R.train_step(P, fwd, U.loss_fn_for(kind), xt, yt, {})
-    Pb, _ = oracle_with(W, kind, variant, b, size, cols, nb2d, nb3d)
-    Pb.store_bf16 = True
-    cal_pred = U.R.predict(Pb, fwd, xt).numpy()
-    cal_loss, cal_grads, cal_logits = U.R.train_step(Pb, fwd, U.loss_fn_for(kind), xt, yt, {})
+    P, fwd, (ref_pred, ref_loss, ref_grads, ref_logits), (cal_pred, cal_loss, cal_grads, cal_logits) = \
+        oracle_pair(W, kind, variant, b, size, cols, nb2d, nb3d, xt, yt)
     ref_g = {k: g.numpy() for k, g in ref_grads.items()}
     cal_g = {k: g.numpy() for k, g in cal_grads.items()}
     noise = {k: r[1] for k, r in zip(ref_g, grad_table(cal_g, ref_g))}
