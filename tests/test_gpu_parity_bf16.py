@@ -188,12 +188,13 @@ CASES = [
     ("hybrid", "3dpart", 1, 224, 12, "trained"),             # configs[2]
     ("hybrid", "end2end", 1, 224, 12, "trained"),            # configs[3]
     ("3d", "3dpart", 1, 224, 12, "trained"),                 # the per-shard network of configs[4]
+    ("2d", "denseunet", 2, 512, None, "mid"),
     ("hybrid", "end2end", 1, 224, 12, "mid"),
     ("2d", "denseunet", 8, 512, None, "mid"),                # BASELINE configs[1] itself: the batch bench.py times
     # round 5: the configs[4] per-shard shape -- 512 x 512 planes of the stand-alone 3D net (16 depth planes
     # here, bench.py's `shard3d` runs 64: the same large-grid kernel forms) -- as a bf16 TRAINING step with every gradient held to
     # the oracle: the halo-tile forward / data-gradient kernel (conv_halo_wide.hip) and the 3 x 3 x 3 / up-sampled halo-tile filter
-    # gradients at the M they are timed at.  (The 2 x 512^2 mid-training case of rounds 3-4 went: the 8 x 512^2 one subsumes it.)
+    # gradients at the M they are timed at.
     ("3d", "3dpart", 1, 512, 16, "mid"),
 ]
 # The gate constants of this file (BF16_SLACK, REL_FLOOR, COS_MIN, the 1 % / 10 x per-tensor rule, the Dice floors, the 1.5 x
@@ -213,7 +214,7 @@ def _log(msg):
 
 
 @pytest.mark.parametrize("kind,variant,b,size,cols,recipe", CASES,
-                         ids=["2d-2x512", "3dpart", "end2end", "3d", "end2end-mid", "2d-8x512-mid", "3d-shard-512x512x16-mid"])
+                         ids=["2d-2x512", "3dpart", "end2end", "3d", "2d-2x512-mid", "end2end-mid", "2d-8x512-mid", "3d-shard-512x512x16-mid"])
 def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols, recipe):
     small = os.environ.get("HDU_PARITY_SMALL") == "1"       # developer switch: same flow at reduced depth / size
     nb2d, nb3d = ((2, 2, 2, 2), (1, 1, 2, 1)) if small else (FULL2D, FULL3D)
