@@ -366,7 +366,7 @@ def cpu_baseline(config, size, cols, samples=2):
     # cores spends its time in fork / join (tools/oracle_pair_timing.py: 59.5 s with 128 threads, 23.6 s with 64, 15.0 s with 32).  Rounds
     # 1-4 reported the 128-thread figure, i.e. a CPU baseline ~4x slower than the host can do.  One step per candidate count, then the
     # remaining samples at the best one; `cores` = the threads of the reported figure.
-    cands = [c for c in (16, 32, 64) if c <= phys] or [phys]
+    cands = [c for c in (8, 16, 32, 64) if c <= phys] or [phys]
     times = {}
     try:
         x, y = U.synthetic_batch(kind, b, size, cols)
@@ -394,8 +394,8 @@ def cpu_baseline(config, size, cols, samples=2):
     best = min(times[best_c])
     return {"value": round(slices / best, 4), "unit": "slices/s", "cores": best_c, "physical_cores": phys, "logical_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": "training steps (fwd+bwd+SGD) of the float32 torch-CPU restatement of the reference graph (not TensorFlow) on %s; "
-                      "torch thread count probed, seconds per step by thread count %s, best used" %
+            "sample": "fwd+bwd+SGD steps of the float32 torch-CPU restatement of the reference graph (not TensorFlow) on %s; "
+                      "thread count probed, s/step by threads %s, best used" %
                       ("1x%dx%d" % (size, size) if kind == "2d" else "one %dx%dx%d volume" % (size, size, cols),
                        {c: [round(t, 1) for t in ts] for c, ts in times.items()})}
 
@@ -454,7 +454,7 @@ def roofline_record(agg, name, config, dtype):
     r = {"bound": "hbm" if hbm_bound else "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": frac,
          "traffic": traffic, "kernel": name, "launches_per_step": n, "avg_launch_us": round(tms / n * 1e3, 2),
          "share_of_step_kernel_time": round(tms / step_ms, 4),
-         "timing": "begin-to-end time of each dispatch (hipExtLaunchKernel start/stop events), no overhead subtracted",
+         "timing": "per-dispatch start/stop events, nothing subtracted",
          "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak_tf, 4),
          "hbm_gbs_algorithmic": round(gbs, 1) if gbs is not None else None,
          "hbm_frac": round(gbs / PEAK_HBM_GBS, 4) if gbs is not None else None,
@@ -615,11 +615,12 @@ def compact(rec):
         out["dense_blocks_3d_mfma_frac"] = rec["dense_blocks_3d"]["mfma_frac"]
     if "parity" in rec:
         out["parity"] = {k: rec["parity"][k] for k in ("dtype", "dice_deficit_per_class", "logit_max_abs_err")}
-    out["workload"] = rec["workload"][:120]
+    out["workload"] = rec["workload"][:96]
     if "roofline" in rec:
         r = rec["roofline"]
-        out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step",
-                                             "avg_launch_us", "share_of_step_kernel_time", "mfma_frac", "hbm_frac")}
+        out["roofline"] = {k: r[k] for k in ("bound", "achieved", "unit", "frac", "traffic", "kernel", "launches_per_step",
+                                             "avg_launch_us", "share_of_step_kernel_time")}
+        out["roofline"]["kernel"] = out["roofline"]["kernel"][:64]
     if "cpu_baseline" in rec:
         c = rec["cpu_baseline"]
         out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind")}
@@ -740,6 +741,12 @@ def main():
             if len(line) > 6000:            # the driver keeps 8 KB of stdout: never let the line outgrow it
                 for e in out["config"].get("extra_workloads", []):
                     e.pop("cpu_baseline", None)
+                    e.pop("hipgraph", None)
+                    e.pop("steps", None)
+                out.get("parity", {}).pop("north_star_bounds", None)
+                line = json.dumps(out)
+            if len(line) > 7000:
+                out["config"].pop("top_kernels", None)
                 line = json.dumps(out)
             # full per-kernel tables and uncompacted records: scratch file (copied to profiles/ for the judged runs) + stderr
             detail = {"main": main_rec, "extras": extra_recs, "conv_kernels": DETAILS}
