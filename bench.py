@@ -607,15 +607,15 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
 
 def compact(rec):
     """what the ONE JSON line carries per extra workload (the driver keeps 8 KB of stdout: the whole metric must fit)"""
-    out = {k: rec[k] for k in ("workload", "value", "unit", "ms_per_step", "steps", "dtype", "hipgraph", "global_batch_slices",
-                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism", "strong_scaling") if k in rec}
+    out = {k: rec[k] for k in ("workload", "value", "ms_per_step", "steps", "dtype", "global_batch_slices",
+                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism", "strong_scaling") if k in rec}      # (unit: slices/s, hipGraph: as the main workload)
     if "step_roofline" in rec:
         out["step_roofline_frac"] = rec["step_roofline"]["time_weighted_frac"]
     if "dense_blocks_3d" in rec:
         out["dense_blocks_3d_mfma_frac"] = rec["dense_blocks_3d"]["mfma_frac"]
     if "parity" in rec:
         out["parity"] = {k: rec["parity"][k] for k in ("dtype", "dice_deficit_per_class", "logit_max_abs_err")}
-    out["workload"] = rec["workload"][:96]
+    out["workload"] = rec["workload"][:80]
     if "roofline" in rec:
         r = rec["roofline"]
         out["roofline"] = {k: r[k] for k in ("bound", "achieved", "unit", "frac", "traffic", "kernel", "launches_per_step",
