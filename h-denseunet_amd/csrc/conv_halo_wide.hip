@@ -767,9 +767,17 @@ static int hw_choose(const ConvK& k, int dtype) {
   const int th[NC] = {8, 16, 16, 8, 8, 16, 16}, nt[NC] = {4, 2, 3, 2, 3, 4, 2}, occ[NC] = {1, 1, 1, 2, 2, 1, 2};
   const double busy[NC] = {0.60, 0.68, 0.68, 0.58, 0.58, 0.74, 0.76};
   const double nst = (double)((k.Cin + 15) / 16) * k.KD;
+  // deep contractions (>= 24 stages) on grids that a 16-row configuration can spread over half the chip: the 8-row two-per-CU forms
+  // re-stream the filter tile twice as often per MAC and lose (per-layer A/B: conv_up0 data gradient 741 vs 1014 TF) whatever the model says
+  bool deep16 = false;
+  if (nst >= 24. && !(g_tuning[HDU_TUNE_DEBUG] & 1024))                          // (bit 10: A/B without this rule)
+    for (int c = 0; c < NC; ++c)
+      if (th[c] == 16 && (double)k.N * k.Do * ((k.He + 15) / 16) * ((k.We + 31) / 32) * scale * (double)((k.Cout + nt[c] * 32 - 1) / (nt[c] * 32)) >= 128.)
+        deep16 = true;
   int best = 0;
   double best_cost = 0., best_wgs = 0.;
   for (int c = 0; c < NC; ++c) {
+    if (deep16 && th[c] == 8) continue;
     if (c == 6 && (g_tuning[HDU_TUNE_DEBUG] & 512)) continue;                  // A/B: without the two-per-CU 16 x 64 form
     const int bn = nt[c] * 32;
     const double wgs = (double)k.N * k.Do * ((k.He + th[c] - 1) / th[c]) * ((k.We + 31) / 32) * scale * (double)((k.Cout + bn - 1) / bn);
