@@ -14,6 +14,8 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
+_CAPTURE_MODE = "thread_local"
+
 from . import ops
 from .engine import Ctx, LossLayer
 from .lib import HDU_BF16, HDU_F32
@@ -262,6 +264,11 @@ class Model:
         self._step_update()
         self._eager_steps += 1
 
+    # Capture mode: "thread_local".  In the default "global" mode ANY thread's capture-unsafe runtime call fails while this thread
+    # captures -- and under data parallelism torch's ProcessGroupNCCL watchdog thread polls hipEventQuery on the works of the
+    # parameter broadcast / the warm-up all-reduces: when a poll lands inside the capture the process aborts with
+    # hipErrorStreamCaptureUnsupported (round 5: seen on 2 of 3 runs of the world-1 RCCL bench path once the step had become
+    # shorter; it would have cost the driver's multi-GPU line).  The capturing thread's own calls are still checked.
     def capture_graph(self, warmup=2):
         """capture the step into hipGraphs.  Single GPU: ONE graph (fwd + bwd + SGD).  Data parallel: the gradient
         all-reduce stays an eager RCCL call between two graphs (fwd+bwd | SGD update) -- no collective is captured."""
@@ -285,7 +292,7 @@ class Model:
         g_fb = torch.cuda.CUDAGraph()
         g_upd = None
         if self._allreduce is None:
-            with torch.cuda.graph(g_fb):
+            with torch.cuda.graph(g_fb, capture_error_mode=_CAPTURE_MODE):
                 self._step_device()
                 self._step_update()
         else:
@@ -293,16 +300,16 @@ class Model:
                 g_fb = []
                 for i, bk in enumerate(self._buckets):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                         if i == 0:
                             self._step_head()
                         self.ctx.run_backward((bk[0], bk[1]))
                     g_fb.append(g)
             else:
-                with torch.cuda.graph(g_fb):
+                with torch.cuda.graph(g_fb, capture_error_mode=_CAPTURE_MODE):
                     self._step_device()
             g_upd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_upd):
+            with torch.cuda.graph(g_upd, capture_error_mode=_CAPTURE_MODE):
                 self._step_update()
         self.optimizer.iterations = it0
         self._graph = (g_fb, g_upd)
