@@ -454,11 +454,10 @@ def roofline_record(agg, name, config, dtype):
     r = {"bound": "hbm" if hbm_bound else "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": frac,
          "traffic": traffic, "kernel": name, "launches_per_step": n, "avg_launch_us": round(tms / n * 1e3, 2),
          "share_of_step_kernel_time": round(tms / step_ms, 4),
-         "timing": "per-dispatch start/stop events, nothing subtracted",
          "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / peak_tf, 4),
          "hbm_gbs_algorithmic": round(gbs, 1) if gbs is not None else None,
          "hbm_frac": round(gbs / PEAK_HBM_GBS, 4) if gbs is not None else None,
-         "flop_per_byte": round(ai, 1) if ai is not None else None, "ridge_flop_per_byte": round(ridge, 1),
+         "flop_per_byte": round(ai, 1) if ai is not None else None,
          "algorithmic_bytes_per_launch": int(nbytes / n) if nbytes else None,
          "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
     if traffic is not None:
@@ -467,7 +466,7 @@ def roofline_record(agg, name, config, dtype):
     return r
 
 
-def top_kernels(agg, dtype, k=4):
+def top_kernels(agg, dtype, k=3):
     """the k kernels with the largest total time, compact: (name, launches, us per step, share, fraction of its roof)"""
     tot = sum(v[1] for v in agg.values())
     ridge = PEAK_TFLOPS[dtype] * 1e12 / (PEAK_HBM_GBS * 1e9)
@@ -623,7 +622,7 @@ def compact(rec):
         out["roofline"]["kernel"] = out["roofline"]["kernel"][:64]
     if "cpu_baseline" in rec:
         c = rec["cpu_baseline"]
-        out["cpu_baseline"] = {k: c[k] for k in ("value", "unit", "cores", "kind")}
+        out["cpu_baseline"] = {k: c[k] for k in ("value", "cores", "kind")}
     return out
 
 
