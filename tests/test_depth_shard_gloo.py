@@ -9,11 +9,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_depth_shard_world4_gloo(emu_lib):
+@pytest.mark.parametrize("halo_wide", ["", "4", "8"], ids=["default-kernels", "halo-wide-16x96", "halo-wide-16x64p"])
+def test_depth_shard_world4_gloo(emu_lib, halo_wide):
     """4 ranks x 4 depth planes of the stand-alone 3D net: ranks 0 and 3 are edge shards (zero padding on one side),
     ranks 1 and 2 INTERIOR shards -- two depth neighbours each, halos received from and halo gradients returned to both
-    sides.  (Replaces the world-2 run of round 1, which only had edge shards.)"""
+    sides.  (Replaces the world-2 run of round 1, which only had edge shards.)
+    Round 5: run again with the halo-tile forward / data-gradient kernel and the stem kernels FORCED onto every layer they cover
+    (HDU_HALO_WIDE: at 32 x 32 the size thresholds would keep them out) -- their depth-valid / cropped forms over stored halo planes,
+    in interior and edge shards, against the unsharded net built with the same kernels."""
     env = dict(os.environ, HIPEMU_THREADS="2", OMP_NUM_THREADS="1", SHARD_TEST_DL="4", SHARD_TEST_H="32")
+    if halo_wide:
+        env["HDU_HALO_WIDE"] = halo_wide
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
            "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=2400)
