@@ -4,4 +4,4 @@
 cd "$(dirname "$0")/.."
 SRC=h-denseunet_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DHDU_TIMELINE -Wno-c++20-extensions \
-  -x hip $SRC/conv_igemm.hip $SRC/rowops.hip $SRC/augment.hip -x hip $SRC/hdu_core.cpp $SRC/hdu_comm.cpp -ldl -mllvm -amdgpu-mfma-vgpr-form=1 -o tools/libhdu_tl.so && echo "built tools/libhdu_tl.so"
+  -x hip $SRC/conv_igemm.hip $SRC/conv_halo_wide.hip $SRC/rowops.hip $SRC/augment.hip -x hip $SRC/hdu_core.cpp $SRC/hdu_comm.cpp -ldl -mllvm -amdgpu-mfma-vgpr-form=1 -o tools/libhdu_tl.so && echo "built tools/libhdu_tl.so"
