@@ -538,8 +538,8 @@ __global__ __launch_bounds__(StemCfg::NTHR) void conv_stem_s2_kernel(ConvK p, in
 // columns of output pixel ow are the 112 contiguous bytes at input pixel 2 * ow - 3 (kw padded to 8: columns 56..63 are discarded).
 // Both operands are read with the transposing LDS load (8 consecutive pixels of one column per lane).  The 7 x 6 accumulator
 // fragments live in registers for the whole range; one float atomic per element at the end.
-struct StemW {
-  static constexpr int TH = 4, TW = 32, PX = TH * TW, SEG = 70, NR = 2 * TH + 5, NW = 8, NTHR = 512, NS = 3;
+template <int NS_> struct StemWT {
+  static constexpr int TH = 4, TW = 32, PX = TH * TW, SEG = 70, NR = 2 * TH + 5, NW = 8, NTHR = 512, NS = NS_;
   static constexpr int DSLOTS = PX * 12, DI = DSLOTS / 64;            // dy tile: 12 chunks (96 channels) per pixel, 24 pieces
   static constexpr int XSLOTS = NR * SEG, XI = (XSLOTS + 63) / 64;    // 910 slots, 15 pieces
   static constexpr int LPW = (DI + XI + NW - 1) / NW;                 // 5
@@ -547,9 +547,11 @@ struct StemW {
   static_assert(NS * STAGE <= 160 * 1024, "LDS");
 };
 
+typedef StemWT<2> StemW;
+template <int NS_>
 __global__ __launch_bounds__(StemW::NTHR) void conv_stem_wgrad_kernel(ConvK p, float* __restrict__ dw, int tiles_x, int tiles_y,
                                                                       int nsplit, int ngroups) {
-  typedef StemW C;
+  typedef StemWT<NS_> C;
   typedef bf16_t T;
   constexpr int NW = C::NW, NS = C::NS, DI = C::DI, XI = C::XI, LPW = C::LPW, STAGE = C::STAGE, DBYTES = C::DBYTES, SEG = C::SEG;
   __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
@@ -832,12 +834,14 @@ bool hdu_stem_wgrad_launch(const ConvK& k, int dtype, float* dw, hipStream_t s) 
   if (!hdu_stem_wgrad_taken(k, dtype)) return false;
   const int tiles_x = (k.Wo + 31) / 32, tiles_y = (k.Ho + 3) / 4, ngroups = (k.Cout + 95) / 96;
   const long long tiles = (long long)k.N * k.Do * tiles_x * tiles_y;
-  // ~2 workgroups per CU over the launch, at least 8 tiles each (a workgroup ends with 96 x 56 x 7 float atomics)
+  // two stages (80 KB): two workgroups per CU, ~512 over the launch, at least 32 tiles each -- a workgroup ends with 96 x 56 x 7 float
+  // atomics, which dominate the small stems (measured: 8 -> 32 tiles per workgroup and 3 -> 2 stages: 2D 134 -> 104 us, 224 x 224 x 12
+  // 123 -> 99 us, shard shape 1274 -> 1270 us; profiles/r05_experiment_stem_kernels_ab.txt)
   long long nsplit = 512 / ((long long)k.KD * ngroups);
-  if (nsplit > tiles / 8) nsplit = tiles / 8;
+  if (nsplit > tiles / 32) nsplit = tiles / 32;
   if (nsplit < 1) nsplit = 1;
   const unsigned grid = (unsigned)(nsplit * k.KD * ngroups);
-  HDU_LAUNCH(conv_stem_wgrad_kernel, dim3(grid), dim3(StemW::NTHR), 0, s, k, dw, tiles_x, tiles_y, (int)nsplit, ngroups);
+  HDU_LAUNCH((conv_stem_wgrad_kernel<2>), dim3(grid), dim3(StemW::NTHR), 0, s, k, dw, tiles_x, tiles_y, (int)nsplit, ngroups);
   return true;
 }
 
