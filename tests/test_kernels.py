@@ -1669,3 +1669,36 @@ def test_bn_bwd_finalize_correct(hdu, dtype, geom):
     untouched = torch.cat([mg[6][..., :cs0] - du0[..., :cs0].double(), mg[6][..., cs0 + Cc:] - du0[..., cs0 + Cc:].double()], -1)
     assert float(untouched.abs().max()) == 0.0
     assert float((mg[6][..., cs0:cs0 + Cc] - du0[..., cs0:cs0 + Cc].double()).abs().max()) > 0.01
+
+
+def test_halo_wide_choice_is_the_whole_layers(emu_lib):
+    """A depth shard must run the kernel (family AND tile configuration) that the unsharded layer runs -- the summation order of every
+    output element, hence the bit-equality of the sharded step, depends on it (hdu_conv_desc.layer_rows).  Host-side decision only: the
+    descriptors describe the configs[4] decoder / dense-block layers at full size over dummy storage."""
+    import ctypes
+    ops = ops_mod()
+    buf = torch.zeros(64, dtype=torch.bfloat16, device=ops.device())
+    wt = torch.zeros(64, dtype=torch.bfloat16, device=ops.device())
+
+    def name(D, H, W, Cin, Cout, up, pd, world):
+        x = ops.Act(buf, 0, 1, D, H, W, Cin, Cin, BF16)
+        De, He, We = D << up[0], H << up[1], W << up[2]
+        y = ops.Act(buf, 0, 1, De + 2 * pd - 2, He, We, Cout, Cout, BF16)
+        d = ops.conv_desc(x, ctypes.c_void_p(wt.data_ptr()), y, (3, 3, 3), (1, 1, 1), (pd, 1, 1), up, shard_world=world)
+        return ops.conv_kernel_name(d, 0)
+
+    seen = set()
+    for (Dw, H, W, Cin, Cout, up) in [(32, 256, 256, 96, 64, (1, 1, 1)), (16, 128, 128, 192, 96, (1, 1, 1)), (16, 64, 64, 224, 192, (0, 1, 1)),
+                                      (16, 32, 32, 504, 224, (0, 1, 1)), (16, 16, 16, 504, 504, (0, 1, 1)), (64, 512, 512, 64, 96, (0, 0, 0)),
+                                      (16, 128, 128, 32, 128, (0, 0, 0)), (16, 128, 128, 128, 32, (0, 0, 0))]:
+        whole = name(Dw, H, W, Cin, Cout, up, 1, 1)
+        for world in (2, 4, 8):
+            # a shard stores its planes + 2 halo planes (one per side, at the STORED resolution); depth padding 0 ("valid"), or -1 behind
+            # a depth up-sampling (the up-sampled halo planes are cropped): engine.ConvLayer halo mode
+            Dl = Dw // world
+            if Dl < 1:
+                continue
+            shard = name(Dl + 2, H, W, Cin, Cout, up, 0 - up[0], world)
+            assert shard == whole, (Dw, H, W, Cin, Cout, up, world, shard, whole)
+        seen.add(whole)
+    assert any(n.startswith("conv_halo_wide_kernel") for n in seen), seen
