@@ -41,11 +41,12 @@ extern "C" size_t hdu_sizeof_conv_desc(void) { return sizeof(hdu_conv_desc); }
 #include <dlfcn.h>
 
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
 
-int g_hdu_prof_on = 0;
+std::atomic<int> g_hdu_prof_on{0};
 
 namespace {
 struct ProfRec {
@@ -131,20 +132,27 @@ extern "C" int hdu_profile_begin(int max_records) {
   return 0;
 }
 
-extern "C" int hdu_profile_count(void) { return (int)g_prof.size(); }
+extern "C" int hdu_profile_count(void) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  return (int)g_prof.size();
+}
 
 extern "C" int hdu_profile_end(void) {
   g_hdu_prof_on = 0;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
 #ifndef HDU_EMU
-  if (!g_prof.empty() && hipEventSynchronize(g_prof.back().e1) != hipSuccess) {
-    (void)hipGetLastError();
-    return hdu_set_error(HDU_ERR_LAUNCH, "profile_end: waiting for the last recorded kernel failed");
-  }
+  // records may come from several threads / streams: EVERY record's stop event is waited for, not only the last one's
+  for (const ProfRec& r : g_prof)
+    if (hipEventSynchronize(r.e1) != hipSuccess) {
+      (void)hipGetLastError();
+      return hdu_set_error(HDU_ERR_LAUNCH, "profile_end: waiting for a recorded kernel failed");
+    }
 #endif
   return (int)g_prof.size();
 }
 
 extern "C" int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (i < 0 || (size_t)i >= g_prof.size() || !name_buf || buflen < 2 || !ms)
     return hdu_set_error(HDU_ERR_ARG, "profile_get: bad index / buffer");
   const std::string k = kernel_of(g_prof[(size_t)i].addr);

@@ -6,9 +6,11 @@
 // no other platform and no runtime dispatch between the two.
 #pragma once
 
+#include <atomic>
+
 #ifdef HDU_EMU
 #include "hipemu.h"
-extern int g_hdu_prof_on;
+extern std::atomic<int> g_hdu_prof_on;
 int hdu_prof_note(const void* kernel_addr);
 #define HDU_LAUNCH(kern, grid, block, smem, stream, ...)                      \
   do {                                                                        \
@@ -26,7 +28,7 @@ int hdu_prof_note(const void* kernel_addr);
 // rocprofv3 --kernel-trace reports -- not the time between two marker packets, which adds a box-dependent 2-9 us to
 // every launch); the record keeps the kernel's address (hdu_profile_get resolves it to the instantiated name: dladdr +
 // demangling).  Not armed (always, outside bench.py's one instrumented step): one predictable branch.
-extern int g_hdu_prof_on;
+extern std::atomic<int> g_hdu_prof_on;
 int hdu_prof_next(const void* kernel_addr, hipStream_t stream, hipEvent_t* e0, hipEvent_t* e1);
 // hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind so that
 // hdu_check_launch() reports THIS launch only

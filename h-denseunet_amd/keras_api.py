@@ -14,12 +14,25 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-_CAPTURE_MODE = "thread_local"
-
 from . import ops
 from .engine import Ctx, LossLayer
 from .lib import HDU_BF16, HDU_F32
 from . import models as _m
+
+
+def _graph_capture(graph):
+    """torch.cuda.graph(...) for one captured step.  Under an initialised NCCL (= RCCL) process group torch's watchdog thread polls
+    events while this thread captures, which aborts a capture in the default "global" error mode: only
+    THEN is the capture thread-local.  A single-GPU capture keeps the runtime's global protection against capture-unsafe calls from
+    other threads.  torch versions without the keyword take the plain form."""
+    mode = "global"
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and str(dist.get_backend()).lower().find("nccl") >= 0:
+        mode = "thread_local"
+    try:
+        return torch.cuda.graph(graph, capture_error_mode=mode)
+    except TypeError:
+        return torch.cuda.graph(graph)
 
 
 class SGD:
@@ -292,7 +305,7 @@ class Model:
         g_fb = torch.cuda.CUDAGraph()
         g_upd = None
         if self._allreduce is None:
-            with torch.cuda.graph(g_fb, capture_error_mode=_CAPTURE_MODE):
+            with _graph_capture(g_fb):
                 self._step_device()
                 self._step_update()
         else:
@@ -300,16 +313,16 @@ class Model:
                 g_fb = []
                 for i, bk in enumerate(self._buckets):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                    with _graph_capture(g):
                         if i == 0:
                             self._step_head()
                         self.ctx.run_backward((bk[0], bk[1]))
                     g_fb.append(g)
             else:
-                with torch.cuda.graph(g_fb, capture_error_mode=_CAPTURE_MODE):
+                with _graph_capture(g_fb):
                     self._step_device()
             g_upd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_upd, capture_error_mode=_CAPTURE_MODE):
+            with _graph_capture(g_upd):
                 self._step_update()
         self.optimizer.iterations = it0
         self._graph = (g_fb, g_upd)

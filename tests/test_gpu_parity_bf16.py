@@ -209,7 +209,11 @@ def _log(msg):
     print(msg)
     try:
         os.makedirs(os.path.dirname(FIGURES), exist_ok=True)
+        new = not os.path.exists(FIGURES)
         with open(FIGURES, "a") as f:
+            if new:       # which tree the figures belong to: bench.py marks a quote from another tree stale
+                import importlib
+                f.write("# source_digest %s\n" % importlib.import_module("bench").source_digest())
             f.write(msg + "\n")
     except OSError:
         pass
@@ -230,7 +234,9 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols,
     # logits are decided.  The weights and the input are identical for oracle and product either way.
     x, y = U.synthetic_batch(kind, b, size, cols, seed=77 if (kind, variant) == ("hybrid", "3dpart") else 1234)
     xt, yt = torch.tensor(x), torch.tensor(y)
-    kind_tag = "%s/%s/%s" % (kind, variant, recipe)
+    # (the tag names the batch / shape too: bench.py keys its `max_dice_deficit_by_case` by it, and "2d/denseunet/mid" is run at 2 x 512^2
+    # AND at 8 x 512^2 -- VERDICT r5 W3a)
+    kind_tag = "%s/%s/%s @%dx%d%s" % (kind, variant, recipe, b, size, "x%d" % cols if cols else "")
 
     # ---- oracle: predict, float32 step, bf16-storage step (calibration)
     P, fwd, (ref_pred, ref_loss, ref_grads, ref_logits), (cal_pred, cal_loss, cal_grads, cal_logits) = \
@@ -376,9 +382,15 @@ def test_bf16_train_step_parity_full_size(hip_lib, kind, variant, b, size, cols,
     # 0.05 of the calibration's own coefficient (tighter than the 0.12 of the direct gate below); (b) where the calibration's median
     # per-tensor distance exceeds 1 (noise above signal -- the `chaotic` criterion the direct gate already uses) the pooled coefficient
     # is a random number and is not gated at all; the per-tensor gates and the direct gates below still hold there.
+    # Round 6: the noise-above-signal case is no longer exempt -- it is gated WIDE (|coef - cal_coef| <= 0.5: over rounds 3-5
+    # denseunet_3d drew 0.40 ... 1.35 for the product against 0.45 ... 1.33 for the calibration, the pairs within 0.3 of each other), so
+    # a kernel that drops half of a gradient trips it on every net.
     chaotic_cal = float(np.median(cal_rels)) > 1.0
-    assert chaotic_cal or abs(coef - 1.0) < max(3e-2, BF16_SLACK * abs(cal_coef - 1.0)) or abs(coef - cal_coef) <= 0.05, \
-        "gradient scale on the oracle's: %.4f (bf16-storage oracle %.4f)" % (coef, cal_coef)
+    if chaotic_cal:
+        assert abs(coef - cal_coef) <= 0.5, "gradient scale on the oracle's: %.4f (bf16-storage oracle %.4f; noise above signal: wide gate)" % (coef, cal_coef)
+    else:
+        assert abs(coef - 1.0) < max(3e-2, BF16_SLACK * abs(cal_coef - 1.0)) or abs(coef - cal_coef) <= 0.05, \
+            "gradient scale on the oracle's: %.4f (bf16-storage oracle %.4f)" % (coef, cal_coef)
     # NOTE on margins: every run of this test trains its OWN weights (the float atomics of the statistics / filter gradients
     # make 200 training steps diverge run to run), so the figures below scatter more than the noise of one fixed net does:
     # over five runs of round 3 on different boxes -- median ratio 0.21-0.88, closer 76.5-99.2 %, logits 0.3-0.99 x,
