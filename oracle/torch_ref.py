@@ -1,8 +1,12 @@
 """oracle/torch_ref.py -- TEST INFRASTRUCTURE: CPU restatement of the reference graphs.
 
-**parity unpinned**: the reference's arithmetic lives in TensorFlow 1.x (requirements.txt:71-72), which is
-neither vendored under /root/reference nor installable here, and the reference holds no golden vectors for
-conv / pooling / exact BN / loss / SGD.  This file restates the graphs of
+**Pinned to the reference's own code** (round 3; tests/test_oracle_ref.py): oracle/ref_keras/ executes the reference's UNMODIFIED
+Keras 2.0.8, model constructors, loss.py and SGD.get_updates on an eager torch `keras.backend`; the committed fixtures
+tests/golden/ref_keras_*.{json,npz} (generator: oracle/ref_keras/make_ref_fixtures.py) hold this file's graphs, loss, gradients,
+moving-average updates and optimizer step to them in float64 (logits 1e-9, gradients 1e-7).  Residual, stated: the reference's
+PRIMITIVE arithmetic lives in TensorFlow 1.x (requirements.txt:71-72), which is neither vendored under /root/reference nor
+installable here, and the reference holds no golden vectors for conv / pooling / exact BN -- those ~40
+backend ops are restated on torch and cross-checked against oracle/np64.py.  This file restates the graphs of
 denseunet.py / densenet.py / denseunet3d.py / hybridnet.py / loss.py layer by layer on plain torch CPU
 functional ops (float32 or float64), in the reference's own channels-last layouts (2D: N,H,W,C; 3D:
 N,H,W,D,C) and Keras weight shapes.  Op semantics are pinned by oracle/np64.py (independent float64 numpy
@@ -155,6 +159,12 @@ class ParamStore:
         # the storage precision of the product's throughput mode applied to the ORACLE's arithmetic.  The distance
         # between this run and the plain float32 run is the noise floor a bf16 implementation cannot beat.
         self.store_bf16 = False
+        # storage-point ablation (tests/bf16_storage_ablation.py): with store_bf16 on, `store_policy(tag)` -> bool says
+        # whether THIS storage point rounds (tag = the conv's layer name, or the name given at a q / qg call site); None = all round
+        self.store_policy = None
+
+    def _rounds(self, tag):
+        return self.store_bf16 and (self.store_policy is None or bool(self.store_policy(tag)))
 
     # -- creation helpers
     def _t(self, a):
@@ -182,7 +192,7 @@ class ParamStore:
             self.kind[name] = "conv"
         self.trainable[name] = trainable
         ws = self.w[name]
-        if self.store_bf16:
+        if self._rounds(name):
             w = ws[0] + (ws[0].detach().to(torch.bfloat16).to(ws[0].dtype) - ws[0].detach())   # bf16 copy, f32 gradient
             y = conv_nd(_RoundBF16.apply(x), w, strides, padding, ws[1] if use_bias else None)
             return _RoundBF16.apply(y)
@@ -222,13 +232,13 @@ class ParamStore:
         g, b = self.w[name]
         return x * g + b
 
-    def q(self, x):
+    def q(self, x, tag="q"):
         """calibration mode: a tensor the product STORES (value and its gradient in bf16); identity otherwise"""
-        return _RoundBF16.apply(x) if self.store_bf16 else x
+        return _RoundBF16.apply(x) if self._rounds(tag) else x
 
-    def qg(self, x):
+    def qg(self, x, tag="qg"):
         """calibration mode: a consumer's gradient contribution to a stored (bf16) gradient tensor; identity otherwise"""
-        return _RoundGradBF16.apply(x) if self.store_bf16 else x
+        return _RoundGradBF16.apply(x) if self._rounds(tag) else x
 
     def dropout(self, x, rate):
         # parity runs: rate 0 (TF's RNG cannot be reproduced, SURVEY.md section 7); predict: identity
@@ -293,7 +303,7 @@ def _transition2d(P, x, stage, nb_filter, compression, bn_mode, tr_conv, tr_bn, 
     x = P.scale(base + "_scale", x, trainable=tr_scale)
     x = torch.relu(x)
     x = P.conv(base, x, int(nb_filter * compression), (1, 1), use_bias=False, trainable=tr_conv)
-    return P.q(avg_pool_valid(x, (2, 2)))
+    return P.q(avg_pool_valid(x, (2, 2)), base + "_pool")
 
 
 def dense_unet_2d(P, img, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 36, 24), growth_rate=48):
@@ -315,7 +325,7 @@ def dense_unet_2d(P, img, variant="denseunet", reduction=0.5, nb_layers=(6, 12, 
     x = P.conv("conv1", x, nb_filter, (7, 7), strides=(2, 2), use_bias=False, trainable=tr_conv)
     x = P.bn("conv1_bn", x, eps=eps, mode=bn_mode, trainable=tr_bn)
     x = P.scale("conv1_scale", x, trainable=tr_scale)
-    x = P.q(torch.relu(x))
+    x = P.q(torch.relu(x), "conv1_relu")
     box.append(x)
     x = zero_pad(x, 1)
     x = max_pool_valid(x, 3, 2)
@@ -382,7 +392,7 @@ def dense_net_3d(P, img, variant="3dpart", reduction=0.5, nb_layers=(3, 4, 12, 8
     x = P.conv("3dconv1", x, nb_filter, (7, 7, 7), strides=(2, 2, 2), use_bias=False)
     x = P.bn("3dconv1_bn", x, eps=eps)
     x = P.scale("3dconv1_scale", x)
-    x = P.q(torch.relu(x))
+    x = P.q(torch.relu(x), "3dconv1_relu")
     x = zero_pad(x, 1)
     x = max_pool_valid(x, 3, 2)
     stage = 1
@@ -399,7 +409,7 @@ def dense_net_3d(P, img, variant="3dpart", reduction=0.5, nb_layers=(3, 4, 12, 8
         x = P.scale(base + "_scale", x)
         x = torch.relu(x)
         x = P.conv(base, x, int(nb_filter * compression), (1, 1, 1), use_bias=False)
-        x = P.q(avg_pool_valid(x, (2, 2, 1)))
+        x = P.q(avg_pool_valid(x, (2, 2, 1)), base + "_pool")
         nb_filter = int(nb_filter * compression)
     final_stage = stage + 1
     concat = x
@@ -443,7 +453,7 @@ def hybrid_net(P, img, variant="3dpart", nb_layers2d=(6, 12, 36, 24), nb_layers3
     input2d = torch.stack(slabs, 0)  # (D,H,W,3)
     feature2d, classifer2d = dense_unet_2d(P, input2d, variant=variant, nb_layers=nb_layers2d)
     res2d = classifer2d.permute(1, 2, 0, 3)[None]  # slice2d + concat: (1,H,W,D,3)
-    fea2d = P.q(feature2d).permute(1, 2, 0, 3)[None]
+    fea2d = P.q(feature2d, "fea2d").permute(1, 2, 0, 3)[None]
     input3d = torch.cat([img, res2d * 250], 4)
     feature3d = dense_net_3d(P, input3d, variant=variant, nb_layers=nb_layers3d)
     final = feature3d + fea2d
