@@ -39,7 +39,10 @@ FLOPS_TOLERANCE = 0.03
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3,   # MI355X_MICROARCH.md: dense MFMA peaks
                # "f32x3" = float32 storage, bf16 hi/lo split operands, THREE v_mfma_f32_16x16x16_bf16 per product (lib.set_f32_contraction):
                # the K=16 form moves half the K of the K=32 form per issue, so a product-equivalent peak of 2500 / 2 / 3
-               "f32x3": 2500.0 / 6.0}
+               "f32x3": 2500.0 / 6.0,
+               # "f32x3b" = lib.set_f32_contraction("bf16x3_bwd"): exact float32 forward (1/3 of the conv FLOPs at the f32 peak), split
+               # backward (2/3 at the f32x3 figure): the harmonic mix
+               "f32x3b": 1.0 / ((1.0 / 3.0) / 157.3 + (2.0 / 3.0) / (2500.0 / 6.0))}
 PEAK_HBM_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 PROFILE_ROUND = "r06"
 
@@ -151,7 +154,7 @@ def _conv_work(d, op, scale):
     if op == 1:
         return fl, (m_in * d.Cin + m_out * d.Cout) * esz + d.Cout * taps * d.Cin * 4.0
     nb = (m_in * d.Cin + d.Cout * taps * d.Cin) * esz + m_out * d.Cout * esz * (2 if d.accumulate else 1)
-    if d.bnb_u:          # fused BN backward: the BN input is read as well
+    if d.bnb_u:          # fused BN backward (or its sums alone): the BN input is read as well
         nb += m_out * d.Cout * esz
     return fl, nb
 
@@ -173,6 +176,9 @@ def _row_work(name, a, ctx):
         dt, M, C, acc = v(a[0]), v(a[5]), v(a[6]), v(a[24])
         e = _esz(dt)
         return [2.0 * M * C * e, (3.0 + (1 if acc else 0)) * M * C * e]
+    if name == "hdu_bn_bwd_apply_sums":  # the apply half alone (the sums came from the data-gradient epilogue)
+        dt, M, C, acc = v(a[0]), v(a[5]), v(a[6]), v(a[24])
+        return [(3.0 + (1 if acc else 0)) * M * C * _esz(dt)]
     if name == "hdu_bn_bwd_apply":
         dt, M, C, acc = v(a[0]), v(a[5]), v(a[6]), v(a[16])
         return [(3.0 + (1 if acc else 0)) * M * C * _esz(dt)]
@@ -265,7 +271,7 @@ def parity_of_timed_mode(config, dtype, batch=None):
         return None
     bounds = {"dice": 1e-3, "logits": 1e-4}
     recs, worst, digest = {}, {}, None
-    f32rec = None
+    f32rec = gradrec = exact_rec = None
     for ln in open(path):
         if ln.startswith("# source_digest"):
             digest = ln.split()[2]
@@ -279,12 +285,19 @@ def parity_of_timed_mode(config, dtype, batch=None):
                 if case not in recs or max(r["dice_deficit_per_class"]) > worst[case]:
                     recs[case] = r
                 worst[case] = max(worst.get(case, 0.0), max(r["dice_deficit_per_class"]))
-        elif dtype == "f32" and ln.startswith("[f32 absolute " + tag.split("/", 1)[0]) and tag.split("/", 1)[1] in ln:
+        elif dtype == "f32x3b" and ln.startswith("[f32 forward exact, bf16x3 backward " + tag.split("/", 1)[0]) and tag.split("/", 1)[1] in ln:
+            mm = re.search(r"gradients vs float32 oracle rel-L2 worst ([0-9.e+-]+) / median ([0-9.e+-]+).*\(exact mode: ([0-9.e+-]+) / ([0-9.e+-]+)", ln)
+            if mm:
+                gradrec = {"grad_rel_l2_worst_median": [float(mm.group(1)), float(mm.group(2))],
+                           "exact_mode_worst_median": [float(mm.group(3)), float(mm.group(4))]}
+        elif dtype in ("f32", "f32x3b") and ln.startswith("[f32 absolute " + tag.split("/", 1)[0]) and tag.split("/", 1)[1] in ln:
             mm = re.search(r"product vs float32 oracle ([0-9.e+-]+).*Dice vs oracle \[([^\]]*)\]", ln)
             if mm:
-                f32rec = {"dtype": "f32", "vs": "float32 oracle", "case": ln[1:ln.index("]")],
-                          "dice_deficit_per_class": [round(1.0 - float(v.strip(" '")), 7) for v in mm.group(2).split(",")],
-                          "logit_max_abs_err": float(mm.group(1)), "north_star_bounds": bounds}
+                exact_rec = {"dtype": "f32", "vs": "float32 oracle", "case": ln[1:ln.index("]")],
+                             "dice_deficit_per_class": [round(1.0 - float(v.strip(" '")), 7) for v in mm.group(2).split(",")],
+                             "logit_max_abs_err": float(mm.group(1)), "north_star_bounds": bounds}
+                if dtype == "f32":
+                    f32rec = exact_rec
         elif dtype == "f32x3" and ln.startswith("[f32 storage, bf16x3 contraction " + tag.split("/", 1)[0]) and tag.split("/", 1)[1] in ln:
             mm = re.search(r"product vs float32 oracle ([0-9.e+-]+).*Dice vs oracle \[([^\]]*)\]", ln)
             if mm:
@@ -292,6 +305,8 @@ def parity_of_timed_mode(config, dtype, batch=None):
                           "dice_deficit_per_class": [round(1.0 - float(v.strip(" '")), 7) for v in mm.group(2).split(",")],
                           "logit_max_abs_err": float(mm.group(1)), "north_star_bounds": bounds}
     rec = f32rec
+    if dtype == "f32x3b" and gradrec is not None and exact_rec is not None:
+        rec = dict(exact_rec, dtype="f32x3b", forward="exact float32 kernels (predict bit-equal to the f32 mode)", backward=gradrec)
     if dtype == "bf16" and recs:
         # primary figure: the case run at the benchmarked batch / shape -- for the 2D net the mid-training case at the benchmarked batch
         # (else the largest batch on file), for the shard shape its mid case; the hybrids' cases all run 224 x 224 x 12: the reference's
@@ -550,11 +565,12 @@ def top_kernels(agg, dtype, k=3):
 
 
 def run_workload(config, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline):
-    """dtype "f32x3": the float32 network with the split-bf16 contraction mode switched on for the duration of the workload"""
-    if dtype != "f32x3":
+    """dtype "f32x3": the float32 network with the split-bf16 contraction mode switched on for the duration of the workload;
+    "f32x3b": exact float32 forward (the parity mode's logits), split contraction in the backward pass only"""
+    if dtype not in ("f32x3", "f32x3b"):
         return _run_workload(config, dtype, dtype, b, size, cols, steps, warmup, rank, world, use_graph, roofline)
     lib = importlib.import_module("h-denseunet_amd").lib
-    prev = lib.set_f32_contraction("bf16x3")
+    prev = lib.set_f32_contraction("bf16x3" if dtype == "f32x3" else "bf16x3_bwd")
     try:
         return _run_workload(config, dtype, "f32", b, size, cols, steps, warmup, rank, world, use_graph, roofline)
     finally:
@@ -604,12 +620,15 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
             torch.distributed.barrier()
         _sync()
 
+    shard_mod = importlib.import_module("h-denseunet_amd.shard")
+    shard_mod.reset_counts()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         m.train_step_resident()
     barrier()
     dt = time.perf_counter() - t0
+    coll = shard_mod.counts()
     if dist_on:
         t = torch.tensor([dt], device="cpu" if DRYRUN else "cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -627,6 +646,12 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
         "step_frac_of_mfma_peak": round(gflop / ms / PEAK_TFLOPS[dtype], 4),
     }
     rec["parallelism"] = ("depth-shard%d" if config == "shard3d" else "dp%d") % world
+    if config == "shard3d" and world > 1:
+        # what one depth-sharded step exchanges (h-denseunet_amd/shard.py COUNTS over the timed steps): all of it is EXPOSED today --
+        # issued in program order, nothing computes under it
+        rec["collectives_per_step"] = {"allreduce": coll["allreduce"] // steps, "allreduce_kb": coll["allreduce_bytes"] // steps // 1024,
+                                       "neighbour_exchange": coll["neighbour_exchange"] // steps,
+                                       "neighbour_mb": round(coll["neighbour_bytes"] / steps / 2.0 ** 20, 2), "hidden": 0}
     par_rec = parity_of_timed_mode(config, dtype, b)
     if par_rec is not None:
         rec["parity"] = par_rec
@@ -683,14 +708,15 @@ def _run_workload(config, dtype, store, b, size, cols, steps, warmup, rank, worl
 def compact(rec):
     """what the ONE JSON line carries per extra workload (the driver keeps 8 KB of stdout: the whole metric must fit)"""
     out = {k: rec[k] for k in ("workload", "value", "ms_per_step", "steps", "dtype", "global_batch_slices",
-                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism", "strong_scaling") if k in rec}      # (unit: slices/s, hipGraph: as the main workload)
+                               "step_frac_of_mfma_peak", "peak_hbm_gib", "error", "parallelism", "strong_scaling",
+                               "collectives_per_step") if k in rec}      # (unit: slices/s, hipGraph: as the main workload)
     if "step_roofline" in rec:
         out["step_roofline_frac"] = rec["step_roofline"]["time_weighted_frac"]
     if "dense_blocks_3d" in rec:
         out["dense_blocks_3d_mfma_frac"] = rec["dense_blocks_3d"]["mfma_frac"]
     if "parity" in rec:
         out["parity"] = {k: rec["parity"][k] for k in ("dtype", "case", "dice_deficit_per_class", "logit_max_abs_err", "max_dice_deficit",
-                                                        "source", "stale") if k in rec["parity"]}
+                                                        "source", "stale", "backward") if k in rec["parity"]}
         out["parity"]["source"] = out["parity"]["source"].split("/")[-1].split("_")[0]      # the round tag: profiles/<round>_bf16_parity_figures.txt
         if "stale" in out["parity"]:
             out["parity"]["stale"] = True
@@ -714,7 +740,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="2d", choices=["2d", "3dpart", "end2end", "shard3d"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3", "f32x3b"])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
@@ -723,7 +749,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--extras", default=None,
                     help="comma list of extra workloads timed after the main one (config[:dtype]); default for the "
-                         "default 2d/bf16 run: 3dpart,end2end,shard3d,2d:f32,2d:f32x3 (shard3d = the 512x512x64 per-GPU shard of "
+                         "default 2d/bf16 run: 3dpart,end2end,shard3d,2d:f32,2d:f32x3b (shard3d = the 512x512x64 per-GPU shard of "
                          "BASELINE configs[4], single GPU only); 'none' disables")
     a = ap.parse_args()
 
@@ -753,7 +779,7 @@ def main():
         if default_run and not DRYRUN:
             # the 512x512x64 shard shape runs where a whole 512^3 volume cannot (one GPU); under N > 1 the driver's
             # weak-scaling run keeps to the data-parallel workloads
-            extras = "3dpart,end2end,shard3d,2d:f32,2d:f32x3" if world == 1 else "3dpart,end2end,2d:f32,2d:f32x3"
+            extras = "3dpart,end2end,shard3d,2d:f32,2d:f32x3b" if world == 1 else "3dpart,end2end,2d:f32,2d:f32x3b"
     extra_recs = []
     if extras != "none":
         for spec in extras.split(","):

@@ -850,6 +850,9 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
   const bool col_ok = cc < NCC && n < p.Cout;
   const bool sums = p.bnb_partial != nullptr;
   const bool relu = (p.bnb_relu & 1) != 0, from_z = (p.bnb_relu & 2) != 0;
+  // bit 2 (round 6): SUMS ONLY -- the tile is stored as raw dz (the apply pass that follows, hdu_bn_bwd_apply_sums, needs it), the
+  // epilogue only contributes S1 / S2: the separate reduction pass over (dz, u) of a batch-statistics BN goes
+  const bool raw = (p.bnb_relu & 4) != 0;
   float a[CH], b[CH], mu[CH], rs[CH], s1[CH], s2[CH];
   {
     // unconditional vector loads at a clamped channel index (see bnb_issue_loads): four loads in flight together instead
@@ -895,7 +898,7 @@ __device__ __forceinline__ void epilogue_bn_backward(const ConvK& p, char* smem,
         const float g = (!relu || sj > 0.f) ? dz[j] : 0.f;
         s1[j] += g;
         s2[j] += g * ((u[j] - mu[j]) * rs[j]);
-        o[j] = a[j] * g;
+        o[j] = raw ? dz[j] : a[j] * g;
       }
       if (p.accumulate) {
         float old[CH];
@@ -1867,14 +1870,17 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_pers_kernel(ConvK p, int t
 // This is the streaming form of epilogue_bn_backward: the dz round trip and the separate reduction + apply passes over the
 // O(L^2)-wide slab go (14 -> 6 bytes per element); the reduction-dependent part of du follows later as -k3 * u + k4
 // (hdu_bn_bwd_finalize / hdu_bn_bwd_correct).
-template <int KS, int BN, bool BNB = false>
+template <int KS, int BN, bool BNB = false, int NSA = 3>
 __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_per_wg) {
   typedef bf16_t T;
-  constexpr int CH = 8, BM = 64, NSA = 3;
+  constexpr int CH = 8, BM = 64;
+  constexpr int PD = NSA - 1;                          // every memory stream of the tile loop runs PD tiles ahead
   constexpr int A_SLAB = BM * 128, A_STAGE = KS * A_SLAB;
   constexpr int B_SLAB = BN * 128, B_BYTES = KS * B_SLAB;
   constexpr int WM = 32, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int CROWB = WN * 2 + 16, CST = WM * CROWB;
+  // (the 64-channel two-stage form fits two workgroups per CU in exactly 80 KB of LDS each: no bank padding of its patch rows)
+  constexpr int CROWB = WN * 2 + (BN == 64 && NSA == 2 ? 0 : 16), CST = WM * CROWB;
+  static_assert(NSA == 2 || NSA == 3, "ring depth");
   constexpr int A_IT = BM / 32, B_IT = BN / 32, LA = KS * A_IT;
   static_assert(BN % 64 == 0 && KS >= 1 && KS <= 4, "shape");
   static_assert(B_BYTES + NSA * A_STAGE + 4 * CST <= 160 * 1024, "LDS");
@@ -1923,14 +1929,11 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
       }
     }
   };
-#pragma unroll
-  for (int pre = 0; pre < NSA - 1; ++pre)
-    if (pre < ntiles) issue_tile(pre);
-
   T* __restrict__ yp = (T*)p.y;
   // ---- BNB: this lane's 8 output channels are the same for every tile: coefficients once, S1 / S2 in registers
   constexpr int NCCE = WN / CH;                        // 16-byte chunks per row of a wave's patch (8)
-  constexpr int EIT = WM * NCCE / 64;                  // chunks per lane and tile (4)
+  constexpr int EIT = WM * NCCE / 64;                  // chunks per lane and tile (4; 2 in the 64-channel form)
+  static_assert(EIT == 4 || EIT == 2, "the counted waits below name four / two registers per operand");
   const int ecc = lane % NCCE;
   const int en = n0 + wn * WN + ecc * CH;
   const bool en_ok = en < p.Cout;
@@ -1951,26 +1954,60 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
     for (int j = 0; j < CH; ++j) { bs1[j] = 0.f; bs2[j] = 0.f; }
   }
   const T* __restrict__ bup = (const T*)p.bnb_u;
-  for (int t = 0; t < ntiles; ++t) {
-    // tile t (and, the first time, the filter rows: older than every tile) has landed once at most the DMAs of ONE
-    // younger tile are outstanding.  The epilogue's global stores share the counter: they only make the wait more
-    // conservative (the bound below holds whether or not stores retire in order with the loads).
-    if (t + 1 < ntiles) hdu_wait_vmcnt_n<LA>(); else hdu_wait_vmcnt_n<0>();
-    HDU_RAW_BARRIER();
-    u32x4 euv[BNB ? EIT : 1], eov[BNB ? EIT : 1];
-    if constexpr (BNB) {      // unconditional loads at clamped addresses (see bnb_issue_loads), OLDER than the next tile's DMAs.
-      // (Requesting them one whole tile ahead instead -- 32 more registers -- measured no gain: profiles/r04_experiment_bn_backward_streaming.txt)
+
+  // Round 6 -- the tile loop is SOFTWARE-PIPELINED over its memory round trips.  Round 5's loop requested a tile's u / old-gradient
+  // chunks at the top of the tile with plain loads and stored at its end; hipcc's waitcnt bookkeeping then closed every tile with
+  // s_waitcnt vmcnt(0) (ISA, tools/disasm_kernel.py).  Measured (tools/bench_pw_bstat.py, M = 8192, C = 1584): the plain form
+  // (operand ring only, prefetch distance 2) takes 1.9 us per 64-row tile, the BN-backward form 3.3 us -- one loaded memory round
+  // trip (~3 us) per tile: the kernel is bound by the bytes it keeps in flight per CU (Little's law), not by HBM (0.33 of its roof).
+  // Now every memory stream of the loop runs TWO tiles ahead.  Per tile t (after its barrier):
+  //   1. the stores of tile t-1 are issued (their values waited in registers: the acknowledgements have a whole tile to come back),
+  //   2. the u / old chunks of tile t+2 are requested with loads the compiler does not count (HDU_ASYNC_LOAD16) into the register set
+  //      tile t-1 used (three sets, the loop is unrolled by three: no copies of registers whose loads are in flight),
+  //   3. the operand DMAs of tile t+2 are issued (dead -- zero-filling a free ring slot -- past the last tile: the counts are uniform),
+  //   4. tile t is multiplied, staged, and its epilogue waits for ITS chunks with a counted vmcnt.
+  // Counted waits (loads -- register or LDS-DMA -- retire in order among themselves, so a bound that counts only the LOADS issued
+  // after the wanted ones holds whatever the stores in between do): top of tile t: the DMAs of tile t are followed by
+  // [chunks t+1, DMAs t+1] = 2 EIT + LA loads; epilogue of tile t: its chunks are followed by [DMAs t] [chunks t+1, DMAs t+1]
+  // [chunks t+2, DMAs t+2] = 3 LA + 4 EIT loads.
+  // (u and y are addressed through raw buffer resources with 32-bit byte offsets -- launch precondition: both tensors end below
+  // 4 GiB of their base, pw_bstat_ok -- so that a chunk in flight costs its data registers only: three sets must not spill)
+  u32x4 uS[NSA][EIT], oS[NSA][EIT];                    // u / old-gradient chunks of the tiles t % NSA == 0 / 1 (/ 2)
+  u32x4 pst[EIT];                                      // the finished output chunks of the previous tile
+  unsigned poff[EIT];                                  // ... and where they go (HDU_OOB: nowhere)
 #pragma unroll
-      for (int it = 0; it < EIT; ++it) {
-        const int row = (lane + it * 64) / NCCE;
-        const long long m = m_begin + (long long)t * BM + wm * WM + row;
-        const bool ok = en_ok && m < m_end;
-        euv[it] = *(const u32x4*)(bup + (ok ? m * p.bnb_ldu + en : 0));
-        eov[it] = *(const u32x4*)(yp + ((ok && p.accumulate) ? m * p.ldy + en : 0));
-      }
-      HDU_SCHED_BARRIER();
+  for (int it = 0; it < EIT; ++it) { poff[it] = HDU_OOB; pst[it] = u32x4{0u, 0u, 0u, 0u}; }
+  const hdu_rawsrd ysrd = hdu_make_rawsrd(p.y, (unsigned)(((p.M - 1) * p.ldy + p.Cout) * 2));
+  const hdu_rawsrd usrd = hdu_make_rawsrd(BNB ? p.bnb_u : p.y, (unsigned)(((p.M - 1) * (BNB ? p.bnb_ldu : p.ldy) + p.Cout) * 2));
+  const unsigned ldu2 = (unsigned)p.bnb_ldu * 2u, ldy2 = (unsigned)p.ldy * 2u;
+  const int erow = lane / NCCE;                         // this lane's row of the wave's patch in chunk round 0 (rounds are 64 / NCCE rows apart)
+  auto issue_chunks = [&](int t, u32x4 (&uv)[EIT], u32x4 (&ov)[EIT]) {      // unconditional: a lane without a chunk reads zeros
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const long long m = m_begin + (long long)t * BM + wm * WM + erow + it * (64 / NCCE);
+      const bool ok = en_ok && m < m_end;
+      const unsigned uoff = ok ? (unsigned)m * ldu2 + (unsigned)en * 2u : HDU_OOB;
+      const unsigned ooff = (ok && p.accumulate) ? (unsigned)m * ldy2 + (unsigned)en * 2u : HDU_OOB;
+      HDU_ASYNC_BUFLOAD16(uv[it], usrd, uoff);
+      HDU_ASYNC_BUFLOAD16(ov[it], ysrd, ooff);
     }
-    if (t + NSA - 1 < ntiles) issue_tile(t + NSA - 1);      // refills the slot tile t-1 was read from (all reads are behind the barrier)
+  };
+  // prologue, in the loop's issue order: [chunks 0, DMA tile 0] ([chunks 1, DMA tile 1])
+  if constexpr (BNB) issue_chunks(0, uS[0], oS[0]);
+  issue_tile(0);
+  if constexpr (PD == 2) {
+    if constexpr (BNB) issue_chunks(1, uS[1], oS[1]);
+    issue_tile(1);
+  }
+
+  auto tile = [&](int t, u32x4 (&cuv)[EIT], u32x4 (&cov)[EIT], u32x4 (&nuv)[EIT], u32x4 (&nov)[EIT]) {
+    // the DMAs of tile t are followed by PD - 1 rounds of [chunks, DMAs]
+    if constexpr (BNB) hdu_wait_vmcnt_n<(PD - 1) * (LA + 2 * EIT)>(); else hdu_wait_vmcnt_n<(PD - 1) * LA>();
+    HDU_RAW_BARRIER();
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) hdu_bufstore16(ysrd, poff[it], pst[it]);
+    if constexpr (BNB) issue_chunks(t + PD, nuv, nov);     // into the set tile t-1 has just released
+    issue_tile(t + PD);                                // refills the slot tile t-1 was read from (all reads are behind the barrier)
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -2004,19 +2041,29 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
         Chunk<T>::store4((T*)(stg + (i * 16 + (lane & 15)) * CROWB) + j * 16 + (lane >> 4) * 4, v);
       }
     HDU_WAVE_LDS_SYNC();
-    constexpr int NCC = WN / CH;                       // 16-byte chunks per patch row
+    if constexpr (BNB) {
+      // this tile's chunks are followed by [DMAs t] and PD rounds of [chunks, DMAs]
+      constexpr int NUSE = LA + PD * (LA + 2 * EIT);
+      if constexpr (EIT == 4) {
+        hdu_wait_vmcnt_regs4<NUSE>(cuv[0], cuv[1], cuv[2], cuv[3]);
+        hdu_wait_vmcnt_regs4<NUSE>(cov[0], cov[1], cov[2], cov[3]);
+      } else {
+        hdu_wait_vmcnt_regs4<NUSE>(cuv[0], cuv[1], cov[0], cov[1]);
+      }
+    }
 #pragma unroll
-    for (int it = 0; it < WM * NCC / 64; ++it) {
+    for (int it = 0; it < EIT; ++it) {
       const int q = lane + it * 64;
-      const int row = q / NCC, cc = q % NCC;
+      const int row = q / NCCE, cc = q % NCCE;
       const long long m = m_begin + (long long)t * BM + wm * WM + row;
       const int n = n0 + wn * WN + cc * CH;
       const u32x4 v = *(const u32x4*)(stg + row * CROWB + cc * 16);
+      const bool ok = m < m_end && n < p.Cout;
+      poff[it] = ok ? (unsigned)m * ldy2 + (unsigned)n * 2u : HDU_OOB;
       if constexpr (BNB) {
-        const bool ok = m < m_end && n < p.Cout;
         float dz[CH], u[CH], o[CH];
         Chunk<T>::unpack(v, dz);
-        Chunk<T>::unpack(euv[it], u);
+        Chunk<T>::unpack(cuv[it], u);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float sj = ba[j] * u[j] + bb[j];
@@ -2027,17 +2074,32 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
         }
         if (p.accumulate) {
           float old[CH];
-          Chunk<T>::unpack(eov[it], old);
+          Chunk<T>::unpack(cov[it], old);
 #pragma unroll
           for (int j = 0; j < CH; ++j) o[j] += old[j];
         }
-        if (ok) *(u32x4*)(yp + m * p.ldy + n) = Chunk<T>::pack(o);
+        pst[it] = Chunk<T>::pack(o);
       } else {
-        if (m < m_end && n < p.Cout) *(u32x4*)(yp + m * p.ldy + n) = v;
+        pst[it] = v;
       }
     }
     HDU_WAVE_LDS_SYNC();                               // (the patch is rewritten only after the next tile's barrier + MFMAs)
+  };
+  if constexpr (NSA == 3) {
+    for (int t = 0; t < ntiles; t += 3) {
+      tile(t, uS[0], oS[0], uS[2], oS[2]);
+      if (t + 1 < ntiles) tile(t + 1, uS[1], oS[1], uS[0], oS[0]);
+      if (t + 2 < ntiles) tile(t + 2, uS[2], oS[2], uS[1], oS[1]);
+    }
+  } else {
+    for (int t = 0; t < ntiles; t += 2) {
+      tile(t, uS[0], oS[0], uS[1], oS[1]);
+      if (t + 1 < ntiles) tile(t + 1, uS[1], oS[1], uS[0], oS[0]);
+    }
   }
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) hdu_bufstore16(ysrd, poff[it], pst[it]);
+  hdu_wait_vmcnt_n<0>();                               // dead DMAs of the last tiles write LDS: they must land before the workgroup retires
   if constexpr (BNB) {
     if (bsums) {
       // lanes ecc, ecc + 8, ... of a wave own the same 8 channels: butterfly over lane bits 3..5, then lanes 0..7 add the wave's
@@ -3335,16 +3397,22 @@ static void launch_halo_fprop(const ConvK& k, hipStream_t s) {
 static bool pw_bstat_ok(const ConvK& k, int dtype) {
   return dtype == HDU_BF16 && !g_tuning[HDU_TUNE_NO_PW_BSTAT] && k.KD * k.KH * k.KW == 1 && k.sd == 1 && k.sh == 1 && k.sw == 1 &&
          (k.pd | k.ph | k.pw) == 0 && (k.ud | k.uh | k.uw) == 0 && k.pro_a == nullptr && k.skip == nullptr && k.bias == nullptr &&
-         k.epi_a == nullptr && k.stats_partial == nullptr && (k.bnb_u != nullptr ? (!g_tuning[HDU_TUNE_NO_PW_BSTAT_BNB] && !(k.bnb_relu & 2)) : !k.accumulate) &&
+         k.epi_a == nullptr && k.stats_partial == nullptr && (k.bnb_u != nullptr ? (!g_tuning[HDU_TUNE_NO_PW_BSTAT_BNB] && !(k.bnb_relu & 6)) : !k.accumulate) &&
          k.drop_scale == 0.f &&
          (k.Ktot == 128 || k.Ktot == 192) && k.Cout >= 256 && k.M >= 64 && k.x_bytes != 0 &&
+         // (round 6: the output / BN-input chunks travel through raw buffer resources with 32-bit byte offsets)
+         (k.M - 1) * k.ldy + k.Cout < (1ll << 31) && (k.bnb_u == nullptr || (k.M - 1) * k.bnb_ldu + k.Cout < (1ll << 31)) &&
          (long long)k.Cout * k.Ktot * 2 < (1ll << 31) && k.Do == k.De && k.Ho == k.He && k.Wo == k.We;
 }
 
-static void launch_pw_bstat(const ConvK& k, hipStream_t s) {
-  constexpr int BN = 128;
+// Two forms.  128 output channels per workgroup, three-slot operand ring (138 KB of LDS: ONE workgroup per CU), and -- round 6 --
+// 64 channels, two slots, exactly 80 KB: TWO workgroups per CU.  tools/bench_pw_bstat.py showed the kernel bound per CU, not
+// by memory: 64 / 128 / 256 workgroups of the one-per-CU form take 36 / 20 / 13 us on the same launch (a single 4-wave workgroup pulls
+// ~10 B/clk through its CU whatever its prefetch depth -- DESIGN.md section 3.1's streaming micro-benchmark), so the lever is waves per CU.
+// HDU_TUNE_PW_BSTAT_FORM: 0 = chosen here, 1 = always the 128-channel form, 2 = always the 64-channel form.
+template <int BN, int NSA>
+static void launch_pw_bstat_form(const ConvK& k, int target, hipStream_t s) {
   const unsigned ny = (unsigned)((k.Cout + BN - 1) / BN);
-  const int target = g_tuning[HDU_TUNE_PW_BSTAT_WGS] > 0 ? g_tuning[HDU_TUNE_PW_BSTAT_WGS] : 256;      // one workgroup per CU (138 KB of LDS)
   long long splits = target / (long long)ny;
   if (splits < 1) splits = 1;
   const long long tiles = (k.M + 63) / 64;
@@ -3352,12 +3420,27 @@ static void launch_pw_bstat(const ConvK& k, hipStream_t s) {
   const long long rows = ((tiles + splits - 1) / splits) * 64;
   const unsigned gx = (unsigned)((k.M + rows - 1) / rows);
   if (k.bnb_u != nullptr) {
-    if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN, true>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
-    else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN, true>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+    if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN, true, NSA>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+    else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN, true, NSA>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
     return;
   }
-  if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
-  else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+  if (k.Ktot == 192) HDU_LAUNCH((conv_pw_bstat_kernel<3, BN, false, NSA>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+  else HDU_LAUNCH((conv_pw_bstat_kernel<2, BN, false, NSA>), dim3(gx, ny), dim3(256), 0, s, k, (int)rows);
+}
+
+static int pw_bstat_form(const ConvK& k) {
+  const int f = g_tuning[HDU_TUNE_PW_BSTAT_FORM];
+  if (f == 1 || f == 2) return f;
+  // measured per shape (tools/bench_pw_bstat.py, profiles/r06_experiment_pw_bstat_forms.txt; us per launch, form 1 -> form 2):
+  // M = 2048: 12.5 -> 11.5; M = 8192: 30.0 -> 30.8, 18.4 -> 19.4; M = 32768: 36.9 -> 30.0; M = 131072 runs on the tile kernels.
+  // Decided on the WHOLE layer's pixel count (a depth shard picks what the unsharded launch picks).
+  return (k.M_layer > 4096 && k.M_layer <= 16384) ? 1 : 2;
+}
+
+static void launch_pw_bstat(const ConvK& k, hipStream_t s) {
+  const int wgs = g_tuning[HDU_TUNE_PW_BSTAT_WGS];
+  if (pw_bstat_form(k) == 2) launch_pw_bstat_form<64, 2>(k, wgs > 0 ? wgs : 512, s);
+  else launch_pw_bstat_form<128, 3>(k, wgs > 0 ? wgs : 256, s);
 }
 
 extern "C" int hdu_conv_fprop(const hdu_conv_desc* d, void* stream) {
@@ -3406,8 +3489,11 @@ template <typename T, int BCO>
 static void launch_wgrad(const ConvK& k, float* dw, hipStream_t s) {
   constexpr int PX = 8 * Chunk<T>::CH;
   const unsigned gx = (unsigned)((k.Ktot + 127) / 128), gy = (unsigned)((k.Cout + BCO - 1) / BCO);
-  // enough pixel splits to fill the chip (~4 workgroups per CU), each a multiple of the pixel step
-  long long want = 1024 / ((long long)gx * gy);
+  // enough pixel splits to fill the chip (~4 workgroups per CU), each a multiple of the pixel step.  HDU_TUNE_WGRAD_TARGET_WGS = 1
+  // gives ONE split per tile: every dw element then has a single writer and the launch is bit-reproducible (the float atomics of
+  // several splits arrive in any order) -- the "ordered reductions" recipe of the parity tests' weight training (tests/parity_utils.py)
+  const long long target = g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] > 0 ? g_tuning[HDU_TUNE_WGRAD_TARGET_WGS] : 1024;
+  long long want = target / ((long long)gx * gy);
   if (want < 1) want = 1;
   long long steps = (k.M + PX - 1) / PX;
   if (want > steps) want = steps;
@@ -3747,7 +3833,8 @@ extern "C" int hdu_conv_kernel_name(const hdu_conv_desc* d, int op, char* buf, s
     else if (d->dtype == HDU_BF16) snprintf(buf, buflen, "conv_wgrad_tr_kernel<%d>", choose_wgrad(k));
     else snprintf(buf, buflen, "conv_wgrad_kernel<float, %d>", choose_wgrad(k));
   } else if (pw_bstat_ok(k, d->dtype)) {
-    snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 128, %s>", k.Ktot / 64, k.bnb_u ? "true" : "false");
+    if (pw_bstat_form(k) == 2) snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 64, %s, 2>", k.Ktot / 64, k.bnb_u ? "true" : "false");
+    else snprintf(buf, buflen, "conv_pw_bstat_kernel<%d, 128, %s, 3>", k.Ktot / 64, k.bnb_u ? "true" : "false");
   } else if (hdu_halo_wide_taken(k, d->dtype)) {
     snprintf(buf, buflen, "%s", hdu_halo_wide_name(k, d->dtype));
   } else if (fprop_halo_ok(k, d->dtype)) {

@@ -284,6 +284,56 @@ __device__ __forceinline__ void hdu_bufload_lds16(const hdu_bufsrd& r, unsigned 
 #define HDU_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #endif
 
+// A 16-byte global load that hipcc does NOT count (cdna_hip_programming.md section 5.7, form (ii)): the compiler's own waitcnt
+// bookkeeping waits for a register load with vmcnt(k) where k only counts what IT issued after the load -- in a loop that also
+// keeps LDS-DMA tiles and stores in flight that comes out as vmcnt(0) at the end of every tile (ISA of round 5's
+// conv_pw_bstat_kernel: the ring's prefetch depth was drained once per tile).  HDU_ASYNC_BUFLOAD16 issues the load invisibly;
+// hdu_wait_vmcnt_regs4<N> is the counted wait that names the destination registers ("+v": no consumer is scheduled above it).
+// The CALLER counts: N = vector-memory LOADS (register or LDS-DMA) issued after the ones it wants -- loads retire in order among
+// themselves, so "at most N outstanding" then implies the wanted ones have landed whatever the stores in between do.
+// Addressing: a raw buffer resource in four SGPRs + ONE 32-bit byte offset per lane (a lane out of range reads zeros / stores
+// nothing: HDU_OOB).  Destination: ACCUMULATOR registers ("=a": gfx950 vector-memory loads may target AGPRs) -- with the MFMA
+// accumulators in VGPRs (-amdgpu-mfma-vgpr-form) the 256 AGPRs of a wave are free, so chunks in flight cost no architectural
+// VGPR.  (With "=v" destinations and three sets in flight hipcc ran out of VGPRs and parked the just-issued, NOT YET LANDED
+// destination registers in AGPRs with v_accvgpr_write -- the silent-garbage case of cdna_hip_programming.md section 5.7 item 1;
+// tools/disasm_kernel.py + the scan in DESIGN.md section 3.9 found it.)  The consumer reads them after the counted wait.
+#ifdef HDU_EMU
+struct hdu_rawsrd { char* base; unsigned nbytes; };
+__device__ __forceinline__ hdu_rawsrd hdu_make_rawsrd(const void* p, unsigned nbytes) { return hdu_rawsrd{(char*)p, nbytes}; }
+#define HDU_ASYNC_BUFLOAD16(dst, srd, off)                                                                     \
+  do {                                                                                                         \
+    if ((unsigned long long)(off) + 16ull <= (unsigned long long)(srd).nbytes) (dst) = *(const u32x4*)((srd).base + (off)); \
+    else (dst) = u32x4{0u, 0u, 0u, 0u};                                                                        \
+  } while (0)
+__device__ __forceinline__ void hdu_bufstore16(const hdu_rawsrd& r, unsigned off, u32x4 v) {
+  if ((unsigned long long)off + 16ull <= (unsigned long long)r.nbytes) *(u32x4*)(r.base + off) = v;
+}
+template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_regs4(u32x4&, u32x4&, u32x4&, u32x4&) {}
+#else
+// the same raw buffer twice: as the compiler's resource type (stores through the builtin) and as its four descriptor words,
+// wave-uniform (readfirstlane), the "s" operand of the asm load below
+struct hdu_rawsrd { __amdgpu_buffer_rsrc_t r; u32x4 w; };
+__device__ __forceinline__ hdu_rawsrd hdu_make_rawsrd(const void* p, unsigned nbytes) {
+  const unsigned long long a = (unsigned long long)p;
+  hdu_rawsrd s;
+  s.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)nbytes, 0x00020000);
+  s.w.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+  s.w.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);      // stride 0: raw buffer
+  s.w.z = __builtin_amdgcn_readfirstlane(nbytes);
+  s.w.w = __builtin_amdgcn_readfirstlane(0x00020000u);
+  return s;
+}
+#define HDU_ASYNC_BUFLOAD16(dst, srd, off) \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(dst) : "v"(off), "s"((srd).w) : "memory")
+__device__ __forceinline__ void hdu_bufstore16(const hdu_rawsrd& r, unsigned off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r.r, (int)off, 0, 0);
+}
+template <int N> __device__ __forceinline__ void hdu_wait_vmcnt_regs4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+a"(a), "+a"(b), "+a"(c), "+a"(d) : "i"(N) : "memory");
+}
+#endif
+
 // LDS hand-off INSIDE one wave (lane A writes, lane B of the same wave reads): a wave's DS instructions execute in order, so
 // the data is there once the writes have been issued and counted down; no workgroup barrier needed
 #ifdef HDU_EMU

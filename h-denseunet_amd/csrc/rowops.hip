@@ -1334,12 +1334,12 @@ extern "C" int hdu_bn_bwd_apply(int dtype, const void* dz, int64_t lddz, const v
   return hdu_check_launch("bn_bwd_apply");
 }
 
-extern "C" int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
-                                const float* a, const float* b, int relu, const float* mean, const float* rstd,
-                                int batch_stats, const float* gamma, const float* beta, const float* sgamma, float* sums,
-                                int slots, float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* dx,
-                                int64_t lddx, int accumulate, float drop_keep, uint32_t drop_seed,
-                                const uint32_t* drop_seed_dev, void* stream) {
+static int bn_bwd_fused_impl(bool reduce, int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                             const float* a, const float* b, int relu, const float* mean, const float* rstd,
+                             int batch_stats, const float* gamma, const float* beta, const float* sgamma, float* sums,
+                             int slots, float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* dx,
+                             int64_t lddx, int accumulate, float drop_keep, uint32_t drop_seed,
+                             const uint32_t* drop_seed_dev, void* stream) {
   if (!dz || !x || !a || !b || !mean || !rstd || !sums || !dx) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: null pointer");
   if (slots <= 0 || slots > 32) return hdu_set_error(HDU_ERR_ARG, "bn_bwd_fused: 1 <= slots <= 32");
   if (((uintptr_t)sums | (uintptr_t)a | (uintptr_t)b | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta |
@@ -1359,15 +1359,17 @@ extern "C" int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const v
   k.dgamma = dgamma; k.dbeta = dbeta; k.dsgamma = dsgamma; k.dsbeta = dsbeta;
   if (int e = rowk_check(dtype, k, "bn_bwd_fused: C / strides must be multiples of the 16-byte chunk")) return e;
   if (M == 0) return 0;
-  // launch 1: column sums of (g, g * xhat) into the slot rows
-  RedK r{};
-  r.x = x; r.ldx = ldx; r.dz = dz; r.lddz = lddz; r.M = M; r.C = C;
-  r.a = a; r.b = b; r.mean = mean; r.rstd = rstd; r.relu = relu;
-  r.partial = sums; r.slots = slots;
-  int rcols; unsigned rgx, rgy;
-  red_geometry(dtype, M, C, &rcols, &rgx, &rgy, &r.rows_per_block);
-  if (dtype == HDU_BF16) run_reduce<bf16_t, RED_BNBWD>(r, rcols, rgx, rgy, (hipStream_t)stream);
-  else run_reduce<float, RED_BNBWD>(r, rcols, rgx, rgy, (hipStream_t)stream);
+  // launch 1: column sums of (g, g * xhat) into the slot rows (hdu_bn_bwd_apply_sums: the caller's data-gradient epilogue did it)
+  if (reduce) {
+    RedK r{};
+    r.x = x; r.ldx = ldx; r.dz = dz; r.lddz = lddz; r.M = M; r.C = C;
+    r.a = a; r.b = b; r.mean = mean; r.rstd = rstd; r.relu = relu;
+    r.partial = sums; r.slots = slots;
+    int rcols; unsigned rgx, rgy;
+    red_geometry(dtype, M, C, &rcols, &rgx, &rgy, &r.rows_per_block);
+    if (dtype == HDU_BF16) run_reduce<bf16_t, RED_BNBWD>(r, rcols, rgx, rgy, (hipStream_t)stream);
+    else run_reduce<float, RED_BNBWD>(r, rcols, rgx, rgy, (hipStream_t)stream);
+  }
   // launch 2: coefficients from the sums + dx
   int cols; unsigned gx, gy;
   row_geometry(dtype, M, C, &cols, &gx, &gy, &k.rows_per_block);
@@ -1381,6 +1383,28 @@ extern "C" int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const v
   if (dtype == HDU_BF16) { HDU_APPLY_SUMS(bf16_t) } else { HDU_APPLY_SUMS(float) }
 #undef HDU_APPLY_SUMS
   return hdu_check_launch("bn_bwd_fused");
+}
+
+extern "C" int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                                const float* a, const float* b, int relu, const float* mean, const float* rstd,
+                                int batch_stats, const float* gamma, const float* beta, const float* sgamma, float* sums,
+                                int slots, float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* dx,
+                                int64_t lddx, int accumulate, float drop_keep, uint32_t drop_seed,
+                                const uint32_t* drop_seed_dev, void* stream) {
+  return bn_bwd_fused_impl(true, dtype, dz, lddz, x, ldx, M, C, a, b, relu, mean, rstd, batch_stats, gamma, beta, sgamma, sums, slots,
+                           dgamma, dbeta, dsgamma, dsbeta, dx, lddx, accumulate, drop_keep, drop_seed, drop_seed_dev, stream);
+}
+
+// Round 6: the apply half alone -- `sums` was filled by the epilogue of the data-gradient launch that produced dz
+// (hdu_conv_desc.bnb_relu bit 2: raw dz stored, S1 / S2 into bnb_partial = sums, bnb_slots = slots): ONE launch per BN backward.
+extern "C" int hdu_bn_bwd_apply_sums(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C,
+                                     const float* a, const float* b, int relu, const float* mean, const float* rstd,
+                                     int batch_stats, const float* gamma, const float* beta, const float* sgamma, float* sums,
+                                     int slots, float* dgamma, float* dbeta, float* dsgamma, float* dsbeta, void* dx,
+                                     int64_t lddx, int accumulate, float drop_keep, uint32_t drop_seed,
+                                     const uint32_t* drop_seed_dev, void* stream) {
+  return bn_bwd_fused_impl(false, dtype, dz, lddz, x, ldx, M, C, a, b, relu, mean, rstd, batch_stats, gamma, beta, sgamma, sums, slots,
+                           dgamma, dbeta, dsgamma, dsbeta, dx, lddx, accumulate, drop_keep, drop_seed, drop_seed_dev, stream);
 }
 
 extern "C" int hdu_bn_bwd_correct(int dtype, const void* u, int64_t ldu, int64_t M, int C, const float* corr3,

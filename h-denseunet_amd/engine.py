@@ -192,6 +192,7 @@ class Ctx:
         self.fuse_bn_bwd_mode = int(os.environ.get("HDU_FUSE_BN_BWD", "1"))
         self.fuse_bn_bwd = self.fuse_bn_bwd_mode > 0
         self.fuse_bn_bwd_pw = os.environ.get("HDU_FUSE_BN_BWD_PW", "1") == "1"
+        self.bnb_sums_epilogue = os.environ.get("HDU_BNB_SUMS_EPILOGUE", "1") == "1"      # round 6: ConvLayer._epilogue_sums
         self.fuse_bn_bwd_now = False
         self.bnb_sinks = []          # (layer, offset into bnb_acc)
         self.bnb_acc = None
@@ -547,16 +548,25 @@ class Ctx:
         order = list(reversed(self.bwd))
         if lo == 0:
             self._bnb_deferred = []
-        for f in order[lo:hi]:
-            f()
-        self.flush_pending_finalize()
-        if hi == len(self.bwd) and self._bnb_deferred:
-            keys = tuple(k for k, _ in self._bnb_deferred)
-            if self._bnb_plan is None or self._bnb_plan[0] != keys:       # (the set is fixed by the model: built once)
-                self._bnb_plan = (keys, ops.BnBwdPlan([e for _, e in self._bnb_deferred]))
-            self._bnb_plan[1].run()
-        if hi == len(self.bwd) and self.wgrad_plan is not None:
-            self.wgrad_plan.run()
+        # float32 networks in the "bf16x3_bwd" mode (lib.set_f32_contraction): the forward contracts in exact float32, the data and
+        # filter gradients of this pass with the split-bf16 contraction (read by the library at launch time)
+        split_bwd = self.dtype == HDU_F32 and ops._l.f32_split_in_backward_only()
+        if split_bwd:
+            ops._l.set_f32_split_now(True)
+        try:
+            for f in order[lo:hi]:
+                f()
+            self.flush_pending_finalize()
+            if hi == len(self.bwd) and self._bnb_deferred:
+                keys = tuple(k for k, _ in self._bnb_deferred)
+                if self._bnb_plan is None or self._bnb_plan[0] != keys:       # (the set is fixed by the model: built once)
+                    self._bnb_plan = (keys, ops.BnBwdPlan([e for _, e in self._bnb_deferred]))
+                self._bnb_plan[1].run()
+            if hi == len(self.bwd) and self.wgrad_plan is not None:
+                self.wgrad_plan.run()
+        finally:
+            if split_bwd:
+                ops._l.set_f32_split_now(False)
 
     def grad_buckets(self, fractions):
         """Cut the backward pass where the first-completed `fractions` of the trainable parameters have their final
@@ -657,8 +667,17 @@ class BNLayer:
         ops.bn_fold(self.C, *args)
         return None
 
-    def backward(self, xvar, dz_act):
-        """dz: gradient w.r.t. relu(a*x+b) at x's resolution.  Writes x.grad and the parameter gradients."""
+    def takes_epilogue_sums(self, xvar):
+        """will backward() run the two-launch form (slot table + apply) in this pass?  Then the data-gradient launch that produces
+        dz may fill the slot table in its epilogue (hdu_conv_desc.bnb_relu bit 2) and the reduction launch goes (round 6)."""
+        ctx = self.ctx
+        return bool((self.batch_now or self.any_trainable()) and not (ctx.shard is not None and ctx.shard.world > 1)
+                    and self.bsum is not None and xvar.root.needs_grad and ctx._zeroed_bwd_pass == ctx.pass_id
+                    and self._bsum_pass != ctx.pass_id)
+
+    def backward(self, xvar, dz_act, sums_ready=False):
+        """dz: gradient w.r.t. relu(a*x+b) at x's resolution.  Writes x.grad and the parameter gradients.
+        sums_ready: the launch that produced dz already added S1 / S2 to this BN's slot table (takes_epilogue_sums)."""
         ctx = self.ctx
         x = xvar.act
         need_sums = self.batch_now or self.any_trainable()
@@ -689,9 +708,11 @@ class BNLayer:
                              self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.bsum, self.BSUM_SLOTS,
                              self.gamma.grad if tr_bn else None, self.beta.grad if tr_bn else None,
                              self.sg.grad if tr_sc else None, self.sb.grad if tr_sc else None, xvar.grad, acc,
-                             drop[0] if drop else 1.0, drop[1] if drop else 0, ctx.seed_dev if drop else None)
+                             drop[0] if drop else 1.0, drop[1] if drop else 0, ctx.seed_dev if drop else None,
+                             sums_ready=sums_ready)
             return
         elif need_sums:   # reduction + coefficients + parameter gradients: two launches
+            assert not sums_ready
             ops.bn_bwd_reduce_coef(dz_act, x, self.a, self.b, self.relu, self.mean_used, self.rstd, self.batch_now,
                                    self.gamma.data, self.beta.data, self.sg.data if self.sg else None, self.s1,
                                    self.s2, self.k1, self.k2, self.k3, self.gamma.grad if tr_bn else None,
@@ -802,6 +823,7 @@ class ConvLayer:
                               and not halo and stride == (1, 1, 1) and not ctx.fuse_prologue and x.root.drop is None
                               and (ctx.fuse_bn_bwd_mode >= 2 or bn.mode != "batch" or pw_stream))
         self.bnb_off = None
+        self._sums_kernel_ok = None       # does this layer's data gradient run on a tile kernel that can take the BN sums? (_epilogue_sums)
         self._s2 = None
         self._s2_ok = (os.environ.get("HDU_STRIDE2_DGRAD", "1") == "1" and all(v in (1, 2) for v in stride)
                        and xa.D % stride[0] == 0 and xa.H % stride[1] == 0 and xa.W % stride[2] == 0 and up == (0, 0, 0)
@@ -962,6 +984,7 @@ class ConvLayer:
             return self._backward_fused_bn(dy)
         De, He, We = x.D << self.up[0], x.H << self.up[1], x.W << self.up[2]
         direct = self.bn is None and self.up == (0, 0, 0)
+        sums_ready = False
         skip_first = self.skip is not None and self.skip.root.needs_grad and not self.skip.root.written \
             and self.skip.c0 == 0
         # where does d(x_eff) go?
@@ -981,6 +1004,7 @@ class ConvLayer:
         else:
             d = ctx.conv_desc(dy, self.wd_ptr, ops.Act(tgt.buf, tgt.off, x.N, De, He, We, x.C, tgt.ld, tgt.dtype), K,
                               (1, 1, 1), (K[0] - 1 - pad[0], K[1] - 1 - pad[1], K[2] - 1 - pad[2]), accumulate=acc)
+            sums_ready = self._epilogue_sums(d)
             ops.conv_fprop(d)
         if self.skip is not None and self.skip.root.needs_grad and not skip_first:
             # generic fallback: add d(x_eff) into an already-written skip gradient
@@ -995,9 +1019,33 @@ class ConvLayer:
             dz = self._dz()
             ops.upsample_bwd(tgt, dz, self.up)
         if self.bn is not None:
-            self.bn.backward(self.x, dz)
+            self.bn.backward(self.x, dz, sums_ready=sums_ready)
         else:
             ops.upsample_bwd(dz, self.x.grad, (0, 0, 0), accumulate=self.x.grad_mode())
+
+    def _epilogue_sums(self, d):
+        """Round 6: the backward sums of this conv's input BN (S1 = sum g, S2 = sum g * uhat) ride in the
+        epilogue of the data-gradient launch `d` that produces dz -- raw dz is stored (hdu_conv_desc.bnb_relu bit 2), the BN's apply
+        launch reads the slot table (hdu_bn_bwd_apply_sums) and the reduce_rows launch between them is gone.  Taken when dz IS the
+        launch's output over the BN input's own grid (no up-sampling / skip / halo / dropout on the BN input), the launch would run on
+        an im2col tile kernel anyway (the halo-tile kernels have no such epilogue: decided once from the kernel the plain descriptor
+        picks) and the BN takes its two-launch form in this pass.  HDU_BNB_SUMS_EPILOGUE=0: off.  Returns True when taken."""
+        ctx, bn = self.ctx, self.bn
+        if not (ctx.bnb_sums_epilogue and bn is not None and self.up == (0, 0, 0) and self.skip is None and not self.halo
+                and self.x.root.drop is None and ctx.bnb_fusable() and bn.BSUM_SLOTS <= 32):
+            return False
+        if self._sums_kernel_ok is None:
+            name = ops.conv_kernel_name(d, 0)
+            self._sums_kernel_ok = name.startswith("conv_igemm_ring_kernel") or name.startswith("conv_igemm_dma_kernel")
+        if not self._sums_kernel_ok or not bn.takes_epilogue_sums(self.x):
+            return False
+        x = self.x.act
+        d.bnb_u, d.bnb_ldu = x.ptr, x.ld
+        d.bnb_a, d.bnb_b = bn.a.data_ptr(), bn.b.data_ptr()
+        d.bnb_relu = (1 if bn.relu else 0) | 4
+        d.bnb_mean, d.bnb_rstd = bn.mean_used.data_ptr(), bn.rstd.data_ptr()
+        d.bnb_partial, d.bnb_slots = bn.bsum.data_ptr(), bn.BSUM_SLOTS
+        return True
 
 
 def _conv_backward_fused_bn(self, dy):

@@ -130,6 +130,8 @@ _SIGS = {
                                  c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
     "hdu_bn_bwd_fused": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p,
                                  c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
+    "hdu_bn_bwd_apply_sums": (c_int, [c_int, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_p, c_int, c_p, c_p,
+                                      c_p, c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_int, c_f, c_u32, c_p, c_p]),
     "hdu_affine_act": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_p, c_i64, c_p]),
     "hdu_materialize": (c_int, [c_int, c_p, c_i64, c_int, c_int, c_int, c_int, c_int, c_p, c_p, c_int, c_int, c_int, c_int,
                                 c_p, c_i64, c_p, c_i64, c_p]),
@@ -187,7 +189,7 @@ class HduError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5        # include/hdu.h HDU_ABI_VERSION
+ABI_VERSION = 6        # include/hdu.h HDU_ABI_VERSION
 
 
 def product_library_path():
@@ -256,6 +258,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(19, int(os.environ["HDU_NO_PW_BSTAT"]))
     if "HDU_PW_BSTAT_WGS" in os.environ:
         lib.hdu_set_tuning(20, int(os.environ["HDU_PW_BSTAT_WGS"]))
+    if "HDU_PW_BSTAT_FORM" in os.environ:   # 1 = 128 channels per workgroup, one per CU (rounds 3-5); 2 = 64 channels, two per CU (round 6)
+        lib.hdu_set_tuning(30, int(os.environ["HDU_PW_BSTAT_FORM"]))
     if "HDU_WGRAD_NCT" in os.environ:
         lib.hdu_set_tuning(21, int(os.environ["HDU_WGRAD_NCT"]))
     if "HDU_NO_PRO_DMA" in os.environ:
@@ -321,7 +325,8 @@ def set_f32_contraction(mode):
     """how the float32 networks (dtype "f32": float32 storage, statistics, row kernels) contract in their convolutions,
     process-wide and read at launch time: "exact" (default) = float32 MFMA, the parity mode; "bf16x3" = every operand split
     into bf16 hi + lo, a.b ~ ah.bh + ah.bl + al.bh on the bf16 MFMA with the float32 accumulator (<= 3 * 2^-18 relative per
-    product).  Environment: HDU_F32_CONTRACTION=bf16x3.  Returns the previous mode."""
+    product); "bf16x3_bwd" = exact forward, split backward (the logits are the parity mode's).
+    Environment: HDU_F32_CONTRACTION=bf16x3 | bf16x3_bwd.  Returns the previous mode."""
     global _f32_contraction
     prev = _f32_contraction
     check(get().hdu_set_tuning(TUNE_F32_SPLIT, _F32_MODES[_check_f32_mode(mode)]), "hdu_set_tuning")
@@ -329,12 +334,24 @@ def set_f32_contraction(mode):
     return prev
 
 
-_F32_MODES = {"exact": 0, "bf16x3": 1}
+# "bf16x3_bwd" (round 6): the FORWARD convolutions contract in exact float32 -- predict and training-phase logits are those of the
+# parity mode, bit for bit -- and only the backward pass (data and filter gradients) uses the split contraction: engine.Ctx.run_backward
+# switches HDU_TUNE_F32_SPLIT on for its launches (read at launch time, so a captured step bakes it in per launch).
+_F32_MODES = {"exact": 0, "bf16x3": 1, "bf16x3_bwd": 0}
+
+
+def f32_split_in_backward_only():
+    return _f32_contraction == "bf16x3_bwd"
+
+
+def set_f32_split_now(on):
+    """engine hook of the "bf16x3_bwd" mode: the split contraction for the launches that follow (float32 networks only)"""
+    check(get().hdu_set_tuning(TUNE_F32_SPLIT, 1 if on else 0), "hdu_set_tuning")
 
 
 def _check_f32_mode(mode, what="f32 contraction mode"):
     if mode not in _F32_MODES:
-        raise ValueError("%s: 'exact' or 'bf16x3', not %r" % (what, mode))
+        raise ValueError("%s: 'exact', 'bf16x3' or 'bf16x3_bwd', not %r" % (what, mode))
     return mode
 
 

@@ -474,15 +474,17 @@ def bn_bwd_apply(dz, x, a, b, relu, mean, k1, k2, k3, dx, accumulate=False, drop
 
 
 def bn_bwd_fused(dz, x, a, b, relu, mean, rstd, batch_stats, gamma, beta, sgamma, sums, slots, dgamma, dbeta, dsgamma,
-                 dsbeta, dx, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None):
+                 dsbeta, dx, accumulate=False, drop_keep=1.0, drop_seed=0, drop_seed_dev=None, sums_ready=False):
     """reduction (float atomics into the zeroed [slots][2][C] table `sums`) + coefficients / parameter gradients / dx: two
-    launches (include/hdu.h: hdu_bn_bwd_fused)"""
-    check(_l.get().hdu_bn_bwd_fused(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
-                                    fptr(mean), fptr(rstd), 1 if batch_stats else 0, fptr(gamma), fptr(beta), fptr(sgamma),
-                                    fptr(sums), slots, fptr(dgamma), fptr(dbeta), fptr(dsgamma), fptr(dsbeta), dx.ptr, dx.ld,
-                                    1 if accumulate else 0, drop_keep, drop_seed,
-                                    ctypes.c_void_p(drop_seed_dev.data_ptr()) if drop_seed_dev is not None else None,
-                                    stream()), "hdu_bn_bwd_fused")
+    launches (include/hdu.h: hdu_bn_bwd_fused); sums_ready: the data-gradient epilogue that produced dz filled `sums`
+    (hdu_conv_desc.bnb_relu bit 2) -- the apply launch alone (hdu_bn_bwd_apply_sums)"""
+    fn = _l.get().hdu_bn_bwd_apply_sums if sums_ready else _l.get().hdu_bn_bwd_fused
+    check(fn(x.dtype, dz.ptr, dz.ld, x.ptr, x.ld, x.M, x.C, fptr(a), fptr(b), 1 if relu else 0,
+             fptr(mean), fptr(rstd), 1 if batch_stats else 0, fptr(gamma), fptr(beta), fptr(sgamma),
+             fptr(sums), slots, fptr(dgamma), fptr(dbeta), fptr(dsgamma), fptr(dsbeta), dx.ptr, dx.ld,
+             1 if accumulate else 0, drop_keep, drop_seed,
+             ctypes.c_void_p(drop_seed_dev.data_ptr()) if drop_seed_dev is not None else None,
+             stream()), "hdu_bn_bwd_fused")
 
 
 def bn_bwd_finalize(partial, slots, M, C, batch_stats, gamma, beta, sgamma, mean, rstd, dgamma, dbeta, dsgamma, dsbeta,

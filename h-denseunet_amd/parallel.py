@@ -107,10 +107,8 @@ def attach_depth_shard(model):
         return model
 
     def allreduce(t):
-        if sh.comm is not None:
-            sh.comm.allreduce_(t)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sh.group)
+        from . import shard as _sh
+        _sh.allreduce_sum(sh, t)        # (counted with the step's other collectives: shard.COUNTS)
 
     model.set_data_parallel(sh.world, allreduce)
     broadcast_parameters(model)

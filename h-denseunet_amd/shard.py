@@ -17,6 +17,24 @@ the transport only: the halo-gradient add and the sync-BN packing run in libhdu 
 import torch
 import torch.distributed as dist
 
+# collectives issued since reset_counts(): bench.py reports them per sharded step (`collectives_per_step`).  Every one of them is
+# EXPOSED today: issued in program order on the compute stream (or waited for right away), nothing computes under it.
+COUNTS = {"allreduce": 0, "allreduce_bytes": 0, "neighbour_exchange": 0, "neighbour_bytes": 0}
+
+
+def reset_counts():
+    for k in COUNTS:
+        COUNTS[k] = 0
+
+
+def counts():
+    return dict(COUNTS)
+
+
+def _count_exchange(*tensors):
+    COUNTS["neighbour_exchange"] += 1
+    COUNTS["neighbour_bytes"] += sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
 
 class ShardInfo:
     def __init__(self, rank, world, group=None, comm=None):
@@ -45,6 +63,7 @@ def halo_exchange(sh, act, h):
     if sh is None or sh.world == 1:
         return
     D = act.D
+    _count_exchange(_planes(act, h, h) if sh.lo is not None else None, _planes(act, D - 2 * h, h) if sh.hi is not None else None)
     if sh.comm is not None:       # one grouped RCCL exchange with both neighbours, enqueued on the compute stream
         sh.comm.sendrecv(sh.lo, _planes(act, h, h) if sh.lo is not None else None, _planes(act, 0, h) if sh.lo is not None else None,
                          sh.hi, _planes(act, D - 2 * h, h) if sh.hi is not None else None,
@@ -71,6 +90,7 @@ def halo_reduce(sh, act, h, tmp):
     ops_ = []
     r_lo = tmp[:h * plane]
     r_hi = tmp[h * plane:2 * h * plane]
+    _count_exchange(_planes(act, 0, h) if sh.lo is not None else None, _planes(act, D - h, h) if sh.hi is not None else None)
     if sh.comm is not None:
         sh.comm.sendrecv(sh.lo, _planes(act, 0, h) if sh.lo is not None else None, r_lo if sh.lo is not None else None,
                          sh.hi, _planes(act, D - h, h) if sh.hi is not None else None, r_hi if sh.hi is not None else None)
@@ -97,6 +117,8 @@ def halo_reduce(sh, act, h, tmp):
 
 def allreduce_sum(sh, t):
     if sh is not None and sh.world > 1:
+        COUNTS["allreduce"] += 1
+        COUNTS["allreduce_bytes"] += t.numel() * t.element_size()
         if sh.comm is not None:
             sh.comm.allreduce_(t)
         else:
@@ -126,6 +148,7 @@ def exchange_ct_planes(sh, vol_h, D, plane):
     plane is replicated, which is exactly the reference's first / last 2.5D slab (denseunet3d.py:399-409)."""
     first, last = vol_h[plane:2 * plane], vol_h[D * plane:(D + 1) * plane]
     lo_halo, hi_halo = vol_h[:plane], vol_h[(D + 1) * plane:(D + 2) * plane]
+    _count_exchange(first if sh.lo is not None else None, last if sh.hi is not None else None)
     if sh.comm is not None:
         if sh.lo is None:
             lo_halo.copy_(first)

@@ -45,7 +45,7 @@ const char* hdu_backend(void);
  * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*,
  * 4 = round 3 (hdu_zero_regions, hdu_comm_*), 5 = round 4 (hdu_profile_*, pointwise convs with a fused BN prologue on the
  * DMA path, hdu_wgrad_plan_shape / min_steps). */
-#define HDU_ABI_VERSION 5
+#define HDU_ABI_VERSION 6
 int hdu_abi_version(void);
 size_t hdu_sizeof_conv_desc(void);
 /* Launch profiler (measurement only; replaces nothing in the reference -- Keras has `verbose`, the reference was profiled with
@@ -81,7 +81,9 @@ int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
 #define HDU_TUNE_RING_MIN_K 14       /* small grids use the deep LDS ring when Ktot > this (default 0: always) */
 #define HDU_TUNE_WGRAD_MIN_STEPS 1   /* minimum pixel steps (of 64) per filter-gradient workgroup */
 #define HDU_TUNE_NO_PW_BSTAT 19      /* 1 = disable the filter-stationary pointwise kernel (A/B) */
-#define HDU_TUNE_PW_BSTAT_WGS 20     /* workgroups that kernel aims for (default 256) */
+#define HDU_TUNE_PW_BSTAT_WGS 20     /* workgroups that kernel aims for (default 256 / 512 by form) */
+#define HDU_TUNE_PW_BSTAT_FORM 30    /* 0 = library's choice, 1 = 128 channels per workgroup, three-slot ring, one workgroup per CU (rounds 3-5),
+                                        2 = 64 channels, two slots, 80 KB of LDS: two workgroups per CU (round 6) */
 #define HDU_TUNE_NO_PRO_DMA 22       /* 1 = a pointwise conv with a BN prologue takes the VGPR-gather kernels of rounds 1-3 (A/B) */
 #define HDU_TUNE_PERS 23             /* 0 = two-stage implicit GEMM on large grids (default: the persistent 256-row kernel was measured 10-20 %
                                         slower per launch, profiles/r04_experiment_persistent_gemm.txt), 1 = persistent kernel, one
@@ -157,7 +159,10 @@ typedef struct hdu_conv_desc {
    * Replaces, per BN, the dz round trip through HBM, the reduction pass and the full-width apply pass.
    * bnb_relu: bit 0 = the BN is followed by ReLU; bit 1 (value 2) = `bnb_u` holds the BN's OUTPUT z = relu(a*u + b) instead
    * of its input (a producer whose epilogue applied the stored-statistics BN, epi_*, never wrote u): the mask is z > 0 and
-   * the normalised input is recovered as (z - (b + a*mean)) * (rstd / a) where z > 0.  Tile kernels only. */
+   * the normalised input is recovered as (z - (b + a*mean)) * (rstd / a) where z > 0.  Tile kernels only.
+   * bit 2 (value 4, ABI 6) = SUMS ONLY: the tile is stored as raw dz and the epilogue only accumulates S1 / S2 into bnb_partial --
+   * the reduction half of a batch-statistics BN backward rides in the launch that produces dz, the apply half follows as ONE
+   * launch (hdu_bn_bwd_apply_sums with sums = bnb_partial, slots = bnb_slots).  Tile kernels only. */
   const void* bnb_u;  int64_t bnb_ldu;
   const float* bnb_a; const float* bnb_b; const float* bnb_mean; const float* bnb_rstd;
   int bnb_relu;
@@ -376,6 +381,15 @@ int hdu_bn_bwd_fused(int dtype, const void* dz, int64_t lddz, const void* x, int
                      const float* beta, const float* sgamma, float* sums, int slots, float* dgamma, float* dbeta,
                      float* dsgamma, float* dsbeta, void* dx, int64_t lddx, int accumulate, float drop_keep,
                      uint32_t drop_seed, const uint32_t* drop_seed_dev, void* stream);
+
+/* ABI 6: launch 2 of hdu_bn_bwd_fused alone.  `sums` ([slots][2][C]) already holds S1 / S2: the data-gradient launch that produced
+ * dz took them in its epilogue (hdu_conv_desc.bnb_relu bit 2 with bnb_partial = sums, bnb_slots = slots).  Replaces the
+ * reduce_rows launch of every dense-block BN_b (denseunet.py:249-251 backward): 78 launches of a DenseUNet-161 step. */
+int hdu_bn_bwd_apply_sums(int dtype, const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int C, const float* a,
+                          const float* b, int relu, const float* mean, const float* rstd, int batch_stats, const float* gamma,
+                          const float* beta, const float* sgamma, float* sums, int slots, float* dgamma, float* dbeta,
+                          float* dsgamma, float* dsbeta, void* dx, int64_t lddx, int accumulate, float drop_keep,
+                          uint32_t drop_seed, const uint32_t* drop_seed_dev, void* stream);
 
 /* materialise z = relu?(a*x+b) (needed where the activation is consumed by pooling / as a skip / HFF operand) */
 int hdu_affine_act(int dtype, const void* x, int64_t ldx, int64_t M, int C, const float* a, const float* b,

@@ -73,6 +73,9 @@ def test_bench_world2_guarded_shard3d_extra(emu_lib):
     assert rec["config"]["parallelism"] == "dp2" and len(ex) == 1 and ex[0]["parallelism"] == "depth-shard2"
     assert ex[0]["value"] > 0 and ex[0]["global_batch_slices"] == 16 and "error" not in ex[0]
     assert rec["config"]["collectives"]["ranks"] == 2
+    # what one sharded step exchanges is counted and reported (round 6): sync-BN / gradient all-reduces and neighbour (halo) exchanges
+    cps = ex[0]["collectives_per_step"]
+    assert cps["allreduce"] > 10 and cps["neighbour_exchange"] > 4 and cps["neighbour_mb"] > 0 and cps["hidden"] == 0
 
 
 def test_bench_world2_guarded_shard3d_watchdog(emu_lib):

@@ -66,6 +66,24 @@ def trained_weights(kind, variant, b, size, cols, nb2d=FULL2D, nb3d=FULL3D, step
 
 
 def _trained_weights(kind, variant, b, size, cols, nb2d, nb3d, steps2d, steps3d):
+    """Round 6: trained with the atomics-free reductions of parity_utils.ordered_reductions, so two runs of one
+    commit train BIT-EQUAL weights (the figures below no longer scatter with the draw of the weights; HDU_PARITY_ORDERED=0 restores
+    the default launch list of rounds 2-5)."""
+    if os.environ.get("HDU_PARITY_ORDERED", "1") == "1":
+        with U.ordered_reductions():
+            W = _trained_weights_impl(kind, variant, b, size, cols, nb2d, nb3d, steps2d, steps3d)
+        import hashlib
+        h = hashlib.sha256()
+        for name in W:
+            for a in W[name]:
+                h.update(np.ascontiguousarray(a).tobytes())
+        _log("[weights %s/%s @%dx%d%s, %d+%d steps, ordered reductions] sha256 %s" % (kind, variant, b, size, "x%d" % cols if cols else "",
+                                                                                        steps2d, steps3d, h.hexdigest()[:16]))
+        return W
+    return _trained_weights_impl(kind, variant, b, size, cols, nb2d, nb3d, steps2d, steps3d)
+
+
+def _trained_weights_impl(kind, variant, b, size, cols, nb2d, nb3d, steps2d, steps3d):
     if kind == "2d":
         mod = U.pkg("denseunet" if variant == "denseunet" else "densenet")
         m = mod.DenseUNet(reduction=0.5, args=U.make_args(b, size), dtype="f32", nb_layers=nb2d, seed=4321)

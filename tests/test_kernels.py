@@ -920,7 +920,7 @@ def test_conv_fused_bn_backward(hdu, cs, dtype):
     if cs["sums"]:
         d.bnb_mean, d.bnb_rstd, d.bnb_partial, d.bnb_slots = keep[2].data_ptr(), keep[3].data_ptr(), partial.data_ptr(), slots
     if cs["id"].startswith("pw_bstat") and dtype == BF16:
-        assert ops.conv_kernel_name(d, 0).startswith("conv_pw_bstat_kernel") and ops.conv_kernel_name(d, 0).endswith("true>")
+        assert ops.conv_kernel_name(d, 0).startswith("conv_pw_bstat_kernel") and ", true" in ops.conv_kernel_name(d, 0)
     ops.conv_fprop(d)
     # reference: dz = conv(dy, w) in the storage dtype (the tile is staged in it), then the masked scale
     dz = q(ref_conv(dy, w, (1, 1, 1), p, None), dtype)
@@ -956,6 +956,77 @@ def test_conv_fused_bn_backward(hdu, cs, dtype):
     ops.bn_bwd_correct(ua, c3, c4, outa)
     want = before - c3.cpu().double() * q(u, dtype) + c4.cpu().double()
     assert_close(outa.to_torch().cpu(), want, dtype, scale=float(want.abs().max()), what="correct")
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in BNB_CASES if not c["id"].startswith("pw_bstat") and c["sums"]])
+def test_conv_bn_backward_sums_in_epilogue_then_apply(hdu, cs, dtype):
+    """Round 6 (hdu_conv_desc.bnb_relu bit 2 + hdu_bn_bwd_apply_sums): the data-gradient launch stores RAW dz and adds S1 = sum g,
+    S2 = sum g*uhat to the BN's slot table in its epilogue; the apply launch derives k1 / k2 / k3 from the table and writes
+    du = k1*g - k2 - k3*(u - mean) (+ old) and the parameter gradients: together exactly tf.gradients of BN(+Scale)+ReLU (TFB:1639)
+    in float64 -- the reduce_rows launch between the two is gone.  Also: the two-launch form hdu_bn_bwd_fused on the same dz."""
+    import ctypes
+    ops = ops_mod()
+    N, D, H, W, Cdy, Cu, K, p = cs["N"], cs["D"], cs["H"], cs["W"], cs["Cdy"], cs["Cu"], cs["K"], cs["p"]
+    M = N * D * H * W
+    dy = rnd((N, D, H, W, Cdy), 1, 1.0, dtype)
+    w = rnd((Cu,) + K + (Cdy,), 5, 1.0 / np.sqrt(K[0] * K[1] * K[2] * Cdy), dtype)
+    u = rnd((N, D, H, W, Cu), 7, 1.0, dtype)
+    old = rnd((N, D, H, W, Cu), 8, 0.5, dtype)
+    gamma = (rnd((Cu,), 13, 0.5).abs() + 0.5).float().double()
+    beta = rnd((Cu,), 14, 0.3).float().double()
+    sg = (rnd((Cu,), 15, 0.5).abs() + 0.5).float().double()
+    sb = rnd((Cu,), 16, 0.3).float().double()
+    mean = rnd((Cu,), 11, 0.3).float().double()
+    rstd = (rnd((Cu,), 12, 0.5).abs() + 0.5).float().double()
+    a = (sg * gamma * rstd).float().double()                       # the folded BN(+Scale): z = relu(a*u + b)
+    b = (sg * (beta - gamma * rstd * mean) + sb).float().double()
+    dya = mkact(ops, dy, dtype)
+    ua = mkact(ops, u, dtype, cs["ldu"], 8 if cs["ldu"] else 0)
+    dza = ops.Act.alloc(N, D, H, W, Cu, dtype)
+    wt = w.to(torch.bfloat16 if dtype == BF16 else torch.float32).contiguous().to(ops.device())
+    slots = 16
+    keep = [dev(ops, t) for t in (a, b, mean, rstd, gamma, beta, sg)]
+    table = torch.zeros(slots * 2 * Cu, dtype=torch.float32, device=ops.device())
+    d = ops.conv_desc(dya, ctypes.c_void_p(wt.data_ptr()), dza, K, (1, 1, 1), p)
+    d.bnb_u, d.bnb_ldu = ua.ptr, ua.ld
+    d.bnb_a, d.bnb_b, d.bnb_relu = keep[0].data_ptr(), keep[1].data_ptr(), (1 if cs["relu"] else 0) | 4
+    d.bnb_mean, d.bnb_rstd, d.bnb_partial, d.bnb_slots = keep[2].data_ptr(), keep[3].data_ptr(), table.data_ptr(), slots
+    assert not ops.conv_kernel_name(d, 0).startswith("conv_pw_bstat"), "the streaming kernel has no sums-only form"
+    ops.conv_fprop(d)
+    dz = q(ref_conv(dy, w, (1, 1, 1), p, None), dtype)
+    assert_close(dza.to_torch().cpu(), dz, dtype, scale=float(dz.abs().max()), what="raw dz")
+    dzs = dza.to_torch().cpu().double()                        # the STORED dz: what the apply pass reads
+    uq = q(u, dtype)
+    gmask = (a * uq + b > 0) if cs["relu"] else torch.ones_like(dz, dtype=torch.bool)
+    g = torch.where(gmask, dz, torch.zeros_like(dz))
+    S = table.cpu().double().reshape(slots, 2, Cu).sum(0)
+    S1, S2 = g.reshape(M, Cu).sum(0), (g * (uq - mean) * rstd).reshape(M, Cu).sum(0)
+    tol = 2e-5 if dtype == F32 else 2e-3
+    sc = float(max(S1.abs().max(), S2.abs().max()))
+    assert float((S[0] - S1).abs().max()) <= tol * sc and float((S[1] - S2).abs().max()) <= tol * sc, "slot sums"
+    z = lambda: torch.zeros(Cu, dtype=torch.float32, device=ops.device())
+    outs = {}
+    for form in ("apply_sums", "fused"):
+        dg, db, dsg, dsb = z(), z(), z(), z()
+        outa = mkact(ops, old, dtype, cs["ldu"], 8 if cs["ldu"] else 0)
+        tbl = table.clone() if form == "apply_sums" else torch.zeros_like(table)
+        ops.bn_bwd_fused(dza, ua, keep[0], keep[1], cs["relu"], keep[2], keep[3], True, keep[4], keep[5], keep[6], tbl, slots,
+                         dg, db, dsg, dsb, outa, accumulate=cs["acc"], sums_ready=(form == "apply_sums"))
+        # reference from the stored dz (float64): du = k1*g - k2 - k3*(u - mean)
+        gs = torch.where(gmask, dzs, torch.zeros_like(dzs))
+        T1, T2 = gs.reshape(M, Cu).sum(0), (gs * (uq - mean) * rstd).reshape(M, Cu).sum(0)
+        kk = sg * gamma * rstd
+        want = kk * gs - kk * T1 / M - kk * rstd * T2 / M * (uq - mean) + (q(old, dtype) if cs["acc"] else 0.0)
+        assert_close(outa.to_torch().cpu(), want, dtype, scale=float(want.abs().max()), what="du (%s)" % form)
+        for got, ref_v, what in ((dg, sg * T2, "dgamma"), (db, sg * T1, "dbeta"), (dsg, gamma * T2 + beta * T1, "dsgamma"), (dsb, T1, "dsbeta")):
+            assert float((got.cpu().double() - ref_v).abs().max()) <= tol * max(1.0, float(ref_v.abs().max())), (what, form)
+        outs[form] = outa.to_torch().cpu().double()
+        if cs["ldu"]:
+            full = ops.Act(outa.buf, 0, N, D, H, W, cs["ldu"], cs["ldu"], dtype).to_torch().cpu()
+            assert float((full[..., :8] - 7.0).abs().max()) == 0.0 and float((full[..., 8 + Cu:] - 7.0).abs().max()) == 0.0
+    # the two forms agree to the rounding of their sums (float atomics in different orders)
+    assert_close(outs["apply_sums"], outs["fused"], dtype, scale=float(outs["fused"].abs().max()), what="epilogue sums vs reduction pass")
 
 
 @pytest.mark.parametrize("dtype", DT)
