@@ -1899,8 +1899,19 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
   char* stg = smem + B_BYTES + NSA * A_STAGE + wave * CST;
   const int r0 = tid >> 3;
   const int kcl = (tid & 7) ^ (r0 & 7);          // logical 16-byte chunk of the 128-byte slab row this lane fetches
-  const int n0 = blockIdx.y * BN;
-  const long long m_begin = (long long)blockIdx.x * rows_per_wg;
+  // workgroup -> (row range, channel group), XCD-major (round 6): the gridDim.y channel-group workgroups of ONE row range read the same
+  // dt tiles, and with the row-range index fastest in the dispatch order they landed on up to 8 different XCDs -- each XCD's L2 fetched
+  // its own copy of every tile.  xcd_tile_index gives each XCD a contiguous range of (row range, channel group) pairs, channel groups
+  // fastest (HDU_TUNE_DEBUG bit 11 restores the dispatch order)
+  unsigned brow = blockIdx.x, bcol = blockIdx.y;
+  if (!(p.debug_flags & 2048)) {
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned tix = xcd_tile_index(lin, gridDim.x * gridDim.y);
+    bcol = tix % gridDim.y;
+    brow = tix / gridDim.y;
+  }
+  const int n0 = (int)bcol * BN;
+  const long long m_begin = (long long)brow * rows_per_wg;
   long long m_end = m_begin + rows_per_wg;
   if (m_end > p.M) m_end = p.M;
   const int ntiles = (int)((m_end - m_begin + BM - 1) / BM);
@@ -2109,7 +2120,7 @@ __global__ __launch_bounds__(256) void conv_pw_bstat_kernel(ConvK p, int rows_pe
 #pragma unroll
         for (int j = 0; j < CH; ++j) { bs1[j] += __shfl_xor(bs1[j], mask); bs2[j] += __shfl_xor(bs2[j], mask); }
       }
-      float* dst = p.bnb_partial + (long long)(blockIdx.x % (unsigned)p.bnb_slots) * 2 * p.Cout;
+      float* dst = p.bnb_partial + (long long)(brow % (unsigned)p.bnb_slots) * 2 * p.Cout;
       if (lane < NCCE && en_ok) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -3431,10 +3442,11 @@ static void launch_pw_bstat_form(const ConvK& k, int target, hipStream_t s) {
 static int pw_bstat_form(const ConvK& k) {
   const int f = g_tuning[HDU_TUNE_PW_BSTAT_FORM];
   if (f == 1 || f == 2) return f;
-  // measured per shape (tools/bench_pw_bstat.py, profiles/r06_experiment_pw_bstat_forms.txt; us per launch, form 1 -> form 2):
-  // M = 2048: 12.5 -> 11.5; M = 8192: 30.0 -> 30.8, 18.4 -> 19.4; M = 32768: 36.9 -> 30.0; M = 131072 runs on the tile kernels.
-  // Decided on the WHOLE layer's pixel count (a depth shard picks what the unsharded launch picks).
-  return (k.M_layer > 4096 && k.M_layer <= 16384) ? 1 : 2;
+  // measured per shape with the XCD-major workgroup order (tools/bench_pw_bstat.py, profiles/r06_experiment_pw_bstat_forms.txt; us per
+  // launch, form 1 / form 2; round 5's kernel in brackets): BN-backward form M = 2048: 12.4 / 10.9 [12.0]; M = 8192, C = 1584:
+  // 28.4 / 24.9 [29.3]; C = 624: 15.5 / 13.7 [17.2]; M = 32768: 35.7 / 28.9 [39.8].  Plain form (store only): 5.8 / 6.2, 13.1 / 15.5,
+  // 17.2 / 19.1 -- its tile is one operand DMA and one store, the doubled operand traffic of the 64-channel form is not paid back.
+  return k.bnb_u != nullptr ? 2 : 1;
 }
 
 static void launch_pw_bstat(const ConvK& k, hipStream_t s) {
