@@ -822,6 +822,7 @@ def main():
         }
         if "peak_hbm_gib" in main_rec:
             out["config"]["peak_hbm_gib"] = main_rec["peak_hbm_gib"]
+        out["config"]["source_digest"] = source_digest()      # which kernel sources produced this line (quotes from another tree are marked stale)
         if dist_on:     # one process per GPU over RCCL (torch.distributed backend "nccl" IS RCCL on ROCm)
             out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                                             "data_plane": os.environ.get("HDU_COMM", "torch.distributed")}

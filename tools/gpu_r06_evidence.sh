@@ -19,5 +19,8 @@ for cfg in 2d 3dpart end2end shard3d; do
 done
 timeout 1500 python bench.py > gpurun_out/ev_bench.json 2> gpurun_out/ev_bench.err
 cp gpurun_out/bench_details.json gpurun_out/ev_bench_details.json 2>/dev/null
+# the N = 1 denominator of configs[4]: the whole 512 x 512 x 512 volume on ONE GPU (strong-scaling reference of bench.py --gpus N)
+timeout 900 python bench.py --config shard3d --cols 512 --steps 5 --warmup 1 --no-cpu-baseline --extras none > gpurun_out/ev_full512.json 2> gpurun_out/ev_full512.err
+cp gpurun_out/bench_details.json gpurun_out/ev_full512_details.json 2>/dev/null
 ls gpurun_out | grep "ev_" | head -40
 wc -c gpurun_out/ev_bench.json; head -c 600 gpurun_out/ev_bench.json; tail -3 gpurun_out/ev_bench.err
