@@ -206,6 +206,9 @@ def _row_work(name, a, ctx):
         return [sum(cv.kernel.numel for cv in ctx.convs) * 4.0 + ctx.Wc.numel() * ctx.Wc.element_size()]
     if name == "hdu_wce_loss":
         return [v(a[4]) * (2 * 8 * _esz(v(a[0])) + 1.0)]
+    if name == "hdu_split3_batched":     # float32 read once, three bf16 planes written (ops.Split3Plan of the float32 split modes)
+        sp = ctx._split_plan[0] if getattr(ctx, "_split_plan", None) else None
+        return [sum(src.M * src.C * (4.0 + 6.0) for src, _, _, _, _ in sp.items)] if sp is not None else None
     return None
 
 
@@ -365,15 +368,23 @@ def instrumented_step(m):
     _sync()
     work = [None] * len(recs)           # (flops, bytes) per record
     plan = ctx.wgrad_plan
+    triples = 1.0
+    if plan is None and getattr(ctx, "_split_plan", None) is not None and ctx._split_now:
+        # float32 split modes: the filter gradients run as bf16 launches over N' = 3 N images (hi / lo triples) -- the
+        # ALGORITHMIC FLOPs are the layer's, a third of what the descriptors of the triples say
+        plan, triples = ctx._split_plan[1], 3.0
     for name, args, n0, n1 in calls:
         if name in ("hdu_conv_fprop", "hdu_conv_wgrad", "hdu_conv_dgrad_strided"):
             d = args[0]._obj
             work[n0] = _conv_work(d, 1 if name == "hdu_conv_wgrad" else 0, scale)
+            if triples > 1 and name == "hdu_conv_wgrad" and d.dtype == 0 and n1 > n0:
+                work[n0] = (work[n0][0] / triples, work[n0][1])
             if dense3d(d):
                 db[0] += work[n0][0]; db[1] += sum(r[1] for r in recs[n0:n1]); db[2] += n1 - n0
         elif name == "hdu_wgrad_plan_run" and plan is not None:
             ds = plan.descs[getattr(args[0], "value", args[0])]
             ws = [_conv_work(d, 1, scale) for d in ds]
+            ws = [(w[0] / triples, w[1]) for w in ws]
             work[n0] = (sum(w[0] for w in ws), sum(w[1] for w in ws))
             fd = sum(w[0] for d, w in zip(ds, ws) if dense3d(d))
             if fd > 0:             # a batched launch covers many layers: its time is shared out by FLOPs

@@ -2050,3 +2050,119 @@ extern "C" int hdu_zero(void* ptr, uint64_t bytes, void* stream) {
              (char*)ptr, (unsigned long long)bytes);
   return hdu_check_launch("zero");
 }
+
+// ------------------------------------------------------------------ float32 -> bf16 hi / lo planes (include/hdu.h: hdu_split3_*)
+// The filter gradient of a float32 network in the split-bf16 modes: dW = sum_m dy[m] (x) x[m] with both operands contracted
+// over PIXELS.  Splitting an operand on the fly costs VALU work per consuming wave (conv_wgrad_kernel<float>: 80 TF); splitting it
+// ONCE into bf16 planes turns the layer into three bf16 products with the same contraction index -- and three products over M
+// pixels are ONE product over 3 M pixels: the operand is written as the image triple (hi, lo, hi), the gradient as (hi, hi, lo),
+// and the bf16 filter-gradient kernels (halo-tile / DMA families, ~1 PF) run unchanged on N' = 3 N images.
+// Table-driven like zero_regions: one launch splits every operand of the backward pass.  Thread (cc, rl) owns an 8-channel
+// column of its column group (the affine of a BN prologue stays in registers) and 8 rows of the block's row range.
+template <int CHL>      // channels per lane: 8 (two 16-byte loads, 16-byte stores) or 4 (one 16-byte load, 8-byte stores)
+__global__ __launch_bounds__(256) void split3_batched_kernel(const hdu_split3_entry* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block_begin <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const hdu_split3_entry e = table[lo];
+  const unsigned blk = blockIdx.x - e.block_begin;
+  const unsigned cg = blk % e.col_groups;
+  const unsigned long long rb = blk / e.col_groups;
+  const unsigned cols = e.cols, rstep = 256u / cols;
+  const unsigned cc = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const unsigned c0 = (cg * cols + cc) * CHL;
+  if (c0 >= e.C) return;
+  float a[CHL], b[CHL];
+#pragma unroll
+  for (int j = 0; j < CHL; ++j) { a[j] = e.a ? e.a[c0 + j] : 1.f; b[j] = e.a ? e.b[c0 + j] : 0.f; }
+  const float* __restrict__ sp = e.src;
+  bf16_t* __restrict__ dp = (bf16_t*)e.dst;
+  const unsigned long long plane = e.rows * (unsigned long long)e.C;
+  const unsigned long long p1 = plane, p2 = 2ull * plane;
+  const bool grad = e.pattern != 0;      // operand: (hi, lo, hi); gradient: (hi, hi, lo)
+  for (unsigned it = 0; it < e.iters; ++it) {
+    const unsigned long long r_begin = (rb * e.iters + it) * (8ull * rstep);
+    if (r_begin >= e.rows) return;
+    u32x4 v0[8], v1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned long long m = r_begin + rl + (unsigned long long)u * rstep;
+      if (m < e.rows) {
+        const float* q = sp + m * e.ld_src + c0;
+        v0[u] = *(const u32x4*)q;
+        if constexpr (CHL == 8) v1[u] = *(const u32x4*)(q + 4);
+      }
+    }
+    HDU_SCHED_BARRIER();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned long long m = r_begin + rl + (unsigned long long)u * rstep;
+      if (m >= e.rows) continue;
+      float f[8] = {hdu_u2f(v0[u].x), hdu_u2f(v0[u].y), hdu_u2f(v0[u].z), hdu_u2f(v0[u].w), 0.f, 0.f, 0.f, 0.f};
+      if constexpr (CHL == 8) { f[4] = hdu_u2f(v1[u].x); f[5] = hdu_u2f(v1[u].y); f[6] = hdu_u2f(v1[u].z); f[7] = hdu_u2f(v1[u].w); }
+      if (e.a) {
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) {
+          float s = a[j] * f[j] + b[j];
+          if (e.relu) s = s > 0.f ? s : 0.f;
+          f[j] = s;
+        }
+      }
+      unsigned hp[CHL / 2], lp[CHL / 2];
+#pragma unroll
+      for (int j = 0; j < CHL / 2; ++j) {
+        const unsigned hh = hdu_pack_bf16x2(f[2 * j], f[2 * j + 1]);
+        hp[j] = hh;
+        lp[j] = hdu_pack_bf16x2(f[2 * j] - hdu_u2f(hh << 16), f[2 * j + 1] - hdu_u2f(hh & 0xffff0000u));
+      }
+      bf16_t* o = dp + m * e.C + c0;
+      if constexpr (CHL == 8) {
+        const u32x4 h = u32x4{hp[0], hp[1], hp[2], hp[3]}, l = u32x4{lp[0], lp[1], lp[2], lp[3]};
+        *(u32x4*)o = h;
+        *(u32x4*)(o + p1) = grad ? h : l;
+        *(u32x4*)(o + p2) = grad ? l : h;
+      } else {
+        const u32x2 h = u32x2{hp[0], hp[1]}, l = u32x2{lp[0], lp[1]};
+        *(u32x2*)o = h;
+        *(u32x2*)(o + p1) = grad ? h : l;
+        *(u32x2*)(o + p2) = grad ? l : h;
+      }
+    }
+  }
+}
+
+extern "C" int hdu_split3_entry_fill(hdu_split3_entry* e, const float* src, int64_t ld_src, int64_t rows, int C, const float* a,
+                                     const float* b, int relu, int pattern, void* dst, uint32_t block_begin, uint32_t* nblocks) {
+  if (!e || !src || !dst || !nblocks || rows <= 0 || C <= 0 || C % 8 || ld_src < C || ld_src % 4 || ((a == nullptr) != (b == nullptr)))
+    return hdu_set_error(HDU_ERR_ARG, "split3_entry_fill: C must be a multiple of 8 (one 16-byte bf16 chunk), ld_src >= C a multiple of 4, a / b both or neither");
+  if (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)a | (uintptr_t)b) & 15)
+    return hdu_set_error(HDU_ERR_ARG, "split3_entry_fill: pointers must be 16-byte aligned");
+  if (pattern != HDU_SPLIT3_OPERAND && pattern != HDU_SPLIT3_GRADIENT) return hdu_set_error(HDU_ERR_ARG, "split3_entry_fill: bad pattern");
+  const int form = g_tuning[HDU_TUNE_SPLIT3_FORM];      // low nibble: channels per lane (0 = default 8; 4), bits 4..: row groups of 8 per thread (0 = 1)
+  const unsigned chl = (form & 15) == 4 ? 4u : 8u, iters = (form >> 4) > 0 ? (unsigned)(form >> 4) : 1u;
+  const unsigned cpr = (unsigned)C / chl;
+  unsigned best = 8, best_pad = ~0u;
+  for (unsigned c = 256u / chl; c >= 64u / chl; c >>= 1) {          // fewest idle lanes, ties to the wider group
+    const unsigned pad = (cpr + c - 1) / c * c;
+    if (pad < best_pad) { best = c; best_pad = pad; }
+  }
+  e->src = src; e->dst = dst; e->a = a; e->b = b;
+  e->ld_src = (uint64_t)ld_src; e->rows = (uint64_t)rows;
+  e->C = (uint32_t)C; e->relu = relu ? 1u : 0u; e->pattern = (uint32_t)pattern;
+  e->cols = best; e->col_groups = (cpr + best - 1) / best;
+  e->block_begin = block_begin; e->iters = iters; e->chl = chl;
+  const uint64_t rpb = 8ull * (256u / best) * iters;
+  const uint64_t nb = ((uint64_t)rows + rpb - 1) / rpb * e->col_groups;
+  if (nb + block_begin >= (1ull << 31)) return hdu_set_error(HDU_ERR_ARG, "split3_entry_fill: too many blocks for one launch");
+  *nblocks = (uint32_t)nb;
+  return 0;
+}
+
+extern "C" int hdu_split3_batched(const hdu_split3_entry* dev_table, int n, uint32_t total_blocks, int chl, void* stream) {
+  if (!dev_table || n <= 0 || total_blocks == 0 || (chl != 4 && chl != 8)) return hdu_set_error(HDU_ERR_ARG, "split3_batched: bad args (chl = the entries' chl: 8 or 4)");
+  if (chl == 4) HDU_LAUNCH(split3_batched_kernel<4>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n);
+  else HDU_LAUNCH(split3_batched_kernel<8>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n);
+  return hdu_check_launch("split3_batched");
+}

@@ -220,6 +220,13 @@ class Ctx:
         # (ops.WgradPlan); bf16 + materialised inputs only; off under depth sharding / bucketed data parallelism
         self.batch_wgrad = os.environ.get("HDU_BATCH_WGRAD", "1") == "1"
         self.wgrad_plan = None
+        # Round 6: float32 networks in a split-bf16 mode (lib.set_f32_contraction "bf16x3" / "bf16x3_bwd") take their filter
+        # gradients from bf16 hi / lo image triples written once per backward pass (ops.Split3Plan) and contracted by the bf16
+        # batched filter-gradient kernels on 3 N images (_build_split_wgrad_plan).  HDU_F32_SPLIT_WGRAD=0: the in-kernel split of
+        # conv_wgrad_kernel<float> (rounds 4-5) for an A/B.
+        self.split_wgrad = os.environ.get("HDU_F32_SPLIT_WGRAD", "1") == "1"
+        self._split_plan = None      # (Split3Plan, WgradPlan, [(descriptor, dw) of the layers with their own kernel])
+        self._split_now = False
         # batch statistics of a conv output taken in the conv's epilogue (hdu_conv_desc.stats_*) instead of a separate
         # reduction pass; the StatsOp then only runs hdu_bn_stats_finalize over the 32 slot rows
         self.epilogue_stats = os.environ.get("HDU_EPILOGUE_STATS", "1") == "1"
@@ -364,6 +371,55 @@ class Ctx:
         if len(plan):
             plan.finalize()
             self.wgrad_plan = plan
+
+    def split_wgrad_active(self):
+        """do the filter gradients of this pass run on the bf16 image triples? (float32 storage, a split contraction mode, one
+        device, deferred filter gradients allowed)"""
+        return bool(self.dtype == HDU_F32 and self.split_wgrad and self.batch_wgrad and self.grad_enabled and self.finalized
+                    and ops._l.f32_contraction() != "exact" and (self.shard is None or self.shard.world == 1))
+
+    def _build_split_wgrad_plan(self):
+        """x = hi + lo in bfloat16: dW ~ dyh.xh + dyh.xl + dyl.xh, and three products contracted over the pixels are ONE filter
+        gradient over three times the images -- operand triple (hi, lo, hi), gradient triple (hi, hi, lo), both written by one
+        table-driven launch at the END of the backward pass (every operand and output gradient of the pass is final and still
+        stored then, exactly what the bf16 networks' deferred plan relies on), followed by the bf16 plan's one launch per kernel
+        family.  conv_wgrad_kernel<float> split its operands per consuming wave (80 TF, 21 of the 56 ms of a 2D step); the bf16
+        kernels run at 0.7-1.1 PF.  Layers taken: the ones _build_wgrad_plan takes, with channel counts that are whole bf16 chunks
+        (the 3-channel stem input and the 3-class head keep the float32 kernel)."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the split filter-gradient plan is built by the first EAGER backward pass in a split-bf16 mode: run one "
+                               "step (or call Ctx._build_split_wgrad_plan) before capturing")
+        sp, plan, own = ops.Split3Plan(), ops.WgradPlan(int(os.environ.get("HDU_BATCH_WGRAD_TARGET", "0"))), []
+        keep = []
+        for cv in self.convs:
+            cv.in_split_plan = False
+            if not (cv.trainable and cv.out.root.needs_grad) or cv.halo or cv.cin_p % 8 or cv.cout_p % 8:
+                continue
+            if cv.xin is not None:          # materialised input
+                src, pro, relu, up = cv.xin.act, None, False, cv.conv_up
+            elif cv.bn is None and cv.skip is None:
+                src, pro, relu, up = cv.x.act, None, False, cv.up
+            elif cv.pw_fused:               # pointwise over relu(a * x + b): applied (in float32) by the split launch
+                src, pro, relu, up = cv.x.act, (cv.bn.a, cv.bn.b), cv.bn.relu, cv.up
+            else:
+                continue
+            g = cv.out.grad
+            xs = ops.Act.alloc(3 * src.N, src.D, src.H, src.W, src.C, HDU_BF16)
+            dys = ops.Act.alloc(3 * g.N, g.D, g.H, g.W, g.C, HDU_BF16)
+            d16 = ops.conv_desc(xs, cv.wf_ptr, dys, cv.K, cv.stride, cv.pad, up)
+            sp.add(src, ops._l.SPLIT3_OPERAND, xs, pro, relu)
+            sp.add(g, ops._l.SPLIT3_GRADIENT, dys)
+            if ops.conv_kernel_name(d16, 1) == "conv_stem_wgrad_kernel":
+                own.append((d16, cv.kernel.grad))
+            else:
+                plan.add(d16, cv.kernel.grad)
+            keep.append((xs, dys))
+            cv.in_split_plan = True
+        if len(sp):
+            sp.finalize()
+        if len(plan):
+            plan.finalize()
+        self._split_plan = (sp, plan, own, keep)
 
     def flush_pending_finalize(self):
         """the finalize of a fused batch-statistics BN backward is held back until the next reader of its tensor's gradient, so
@@ -548,6 +604,9 @@ class Ctx:
         order = list(reversed(self.bwd))
         if lo == 0:
             self._bnb_deferred = []
+            self._split_now = self.split_wgrad_active()
+            if self._split_now and self._split_plan is None:
+                self._build_split_wgrad_plan()
         # float32 networks in the "bf16x3_bwd" mode (lib.set_f32_contraction): the forward contracts in exact float32, the data and
         # filter gradients of this pass with the split-bf16 contraction (read by the library at launch time)
         split_bwd = self.dtype == HDU_F32 and ops._l.f32_split_in_backward_only()
@@ -564,6 +623,13 @@ class Ctx:
                 self._bnb_plan[1].run()
             if hi == len(self.bwd) and self.wgrad_plan is not None:
                 self.wgrad_plan.run()
+            if hi == len(self.bwd) and self._split_now:
+                sp, plan, own, _ = self._split_plan
+                sp.run()
+                if len(plan):
+                    plan.run()
+                for d16, dw in own:
+                    ops.conv_wgrad(d16, dw)
         finally:
             if split_bwd:
                 ops._l.set_f32_split_now(False)
@@ -961,8 +1027,8 @@ class ConvLayer:
             return
         dy = out.dy()
         x = self.x.act
-        if self.trainable and getattr(self, "in_plan", False):
-            if self.bias is not None:
+        if self.trainable and (getattr(self, "in_plan", False) or (ctx._split_now and getattr(self, "in_split_plan", False))):
+            if self.bias is not None:      # (the filter gradient itself: deferred to the end of the pass, Ctx.run_backward)
                 ops.colsum(dy, self.bias.grad, ctx.ws)
         elif self.trainable:
             if self.xin is not None:

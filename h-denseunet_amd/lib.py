@@ -86,6 +86,17 @@ class BnStatsFold(ctypes.Structure):
 ZERO_BLOCK_BYTES = 65536      # include/hdu.h HDU_ZERO_BLOCK_BYTES
 
 
+class Split3Entry(ctypes.Structure):
+    """include/hdu.h hdu_split3_entry"""
+    _fields_ = [("src", c_p), ("dst", c_p), ("a", c_p), ("b", c_p), ("ld_src", ctypes.c_uint64), ("rows", ctypes.c_uint64),
+                ("C", ctypes.c_uint32), ("relu", ctypes.c_uint32), ("pattern", ctypes.c_uint32), ("cols", ctypes.c_uint32),
+                ("col_groups", ctypes.c_uint32), ("block_begin", ctypes.c_uint32), ("iters", ctypes.c_uint32),
+                ("chl", ctypes.c_uint32)]
+
+
+SPLIT3_OPERAND, SPLIT3_GRADIENT = 0, 1      # include/hdu.h HDU_SPLIT3_*
+
+
 class FoldEntry(ctypes.Structure):
     _fields_ = [("mean", c_p), ("var", c_p), ("gamma", c_p), ("beta", c_p), ("sgamma", c_p), ("sbeta", c_p),
                 ("a", c_p), ("b", c_p), ("rstd", c_p), ("C", ctypes.c_int32), ("eps", c_f)]
@@ -168,6 +179,8 @@ _SIGS = {
     "hdu_softmax_accumulate": (c_int, [c_int, c_p, c_i64, c_i64, c_int, c_p, c_p]),
     "hdu_zero_regions": (c_int, [c_p, c_int, c_u32, c_p, c_u32, c_p]),
     "hdu_zero": (c_int, [c_p, ctypes.c_uint64, c_p]),
+    "hdu_split3_entry_fill": (c_int, [c_p, c_p, c_i64, c_i64, c_int, c_p, c_p, c_int, c_int, c_p, c_u32, ctypes.POINTER(c_u32)]),
+    "hdu_split3_batched": (c_int, [c_p, c_int, c_u32, c_int, c_p]),
     "hdu_profile_begin": (c_int, [c_int]),
     "hdu_profile_count": (c_int, []),
     "hdu_profile_end": (c_int, []),
@@ -189,7 +202,7 @@ class HduError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6        # include/hdu.h HDU_ABI_VERSION
+ABI_VERSION = 7        # include/hdu.h HDU_ABI_VERSION
 
 
 def product_library_path():
@@ -260,6 +273,8 @@ def _apply_env_tuning(lib):
         lib.hdu_set_tuning(20, int(os.environ["HDU_PW_BSTAT_WGS"]))
     if "HDU_PW_BSTAT_FORM" in os.environ:   # 1 = 128 channels per workgroup, one per CU (rounds 3-5); 2 = 64 channels, two per CU (round 6)
         lib.hdu_set_tuning(30, int(os.environ["HDU_PW_BSTAT_FORM"]))
+    if "HDU_SPLIT3_FORM" in os.environ:
+        lib.hdu_set_tuning(31, int(os.environ["HDU_SPLIT3_FORM"]))
     if "HDU_WGRAD_NCT" in os.environ:
         lib.hdu_set_tuning(21, int(os.environ["HDU_WGRAD_NCT"]))
     if "HDU_NO_PRO_DMA" in os.environ:
@@ -342,6 +357,11 @@ _F32_MODES = {"exact": 0, "bf16x3": 1, "bf16x3_bwd": 0}
 
 def f32_split_in_backward_only():
     return _f32_contraction == "bf16x3_bwd"
+
+
+def f32_contraction():
+    """the current mode of set_f32_contraction"""
+    return _f32_contraction
 
 
 def set_f32_split_now(on):

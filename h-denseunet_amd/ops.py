@@ -281,6 +281,51 @@ class ZeroPlan:
               "hdu_zero_regions")
 
 
+class Split3Plan:
+    """hdu_split3_batched: ONE launch writes the bf16 (hi, lo, hi) / (hi, hi, lo) image triples of a fixed list of float32
+    tensors (the operands and output gradients of every filter gradient of a float32 network in the split-bf16 modes).
+    add() at build time, run() once per backward pass; the table lives in device memory."""
+
+    def __init__(self):
+        self.items = []
+        self.table = None
+        self.keep = []
+
+    def add(self, src, pattern, dst, pro=None, relu=False):
+        """src: float32 Act (any pixel stride); dst: bf16 Act with N = 3 * src.N, dense; pro = (a, b) float32 vectors or None"""
+        assert src.dtype == HDU_F32 and dst.dtype == HDU_BF16 and dst.ld == dst.C == src.C and dst.M == 3 * src.M
+        self.items.append((src, pattern, dst, pro, relu))
+        self.table = None
+
+    def __len__(self):
+        return len(self.items)
+
+    def finalize(self):
+        import numpy as np
+        lib = _l.get()
+        ents, blk = [], 0
+        for src, pattern, dst, pro, relu in self.items:
+            e, nb = _l.Split3Entry(), ctypes.c_uint32(0)
+            check(lib.hdu_split3_entry_fill(ctypes.byref(e), src.ptr, src.ld, src.M, src.C, fptr(pro[0]) if pro else None,
+                                            fptr(pro[1]) if pro else None, 1 if relu else 0, pattern, dst.ptr, blk,
+                                            ctypes.byref(nb)), "hdu_split3_entry_fill")
+            ents.append(e)
+            blk += nb.value
+        self.n, self.blocks = len(ents), blk
+        self.chl = ents[0].chl
+        assert all(e.chl == self.chl for e in ents)
+        arr = (_l.Split3Entry * len(ents))(*ents)
+        self.table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device())
+
+    def run(self):
+        if not self.items:
+            return
+        if self.table is None:
+            self.finalize()
+        check(_l.get().hdu_split3_batched(ctypes.c_void_p(self.table.data_ptr()), self.n, self.blocks, self.chl, stream()),
+              "hdu_split3_batched")
+
+
 def zero_tensor(t):
     check(_l.get().hdu_zero(ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(), stream()), "hdu_zero")
 

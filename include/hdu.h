@@ -44,8 +44,8 @@ const char* hdu_backend(void);
  * entry-point set.  A binding compares hdu_abi_version() and hdu_sizeof_conv_desc() with what it was written against and
  * refuses a stale library (h-denseunet_amd/lib.py does): 1 = round 1, 2 = round 2 (splitk_*, bnb_*), 3 = epi_*,
  * 4 = round 3 (hdu_zero_regions, hdu_comm_*), 5 = round 4 (hdu_profile_*, pointwise convs with a fused BN prologue on the
- * DMA path, hdu_wgrad_plan_shape / min_steps). */
-#define HDU_ABI_VERSION 6
+ * DMA path, hdu_wgrad_plan_shape / min_steps), 6 = round 6 (hdu_bn_bwd_apply_sums, bnb_relu bit 2), 7 = round 6 (hdu_split3_*). */
+#define HDU_ABI_VERSION 7
 int hdu_abi_version(void);
 size_t hdu_sizeof_conv_desc(void);
 /* Launch profiler (measurement only; replaces nothing in the reference -- Keras has `verbose`, the reference was profiled with
@@ -98,6 +98,8 @@ int hdu_profile_get(int i, char* name_buf, size_t buflen, float* ms);
                                         0 = library heuristic (default), 1 = off (A/B: the im2col kernels of rounds 1-4), 2..8 = force
                                         configuration 8x128 / 16x64 / 16x96 / 8x64 / 8x96 / 16x128 / 16x64p (tile rows x output channels) where the shape allows;
                                         any value >= 2 also lets the stem kernels take geometries below their size thresholds (tests) */
+#define HDU_TUNE_SPLIT3_FORM 31      /* hdu_split3_entry_fill / hdu_split3_batched (developer A/B, set before a table is filled): low nibble = channels per lane
+                                      * (0 = 8, 4), bits 4.. = row groups of 8 per thread (0 = 1) */
 #define HDU_TUNE_WGRAD_NCT 21        /* 1 = one filter-row tile per pointwise filter-gradient workgroup (round 2's form; A/B) */
 int hdu_set_tuning(int key, int value);
 
@@ -530,6 +532,41 @@ int hdu_zero_regions(const hdu_zero_entry* dev_table, int n, uint32_t total_bloc
                      void* stream);
 /* one region (ptr 16-byte aligned, bytes a multiple of 4) */
 int hdu_zero(void* ptr, uint64_t bytes, void* stream);
+
+/* ------------------------------------------------------------------ float32 operands as bf16 hi / lo image triples
+ * Filter gradients of a float32 network in the split-bf16 modes (HDU_TUNE_F32_SPLIT; the reference is float32 throughout,
+ * K.backend/common.py:4, and its filter gradient is tf.nn.conv2d_backprop_filter / conv3d_backprop_filter_v2, TFB:3097-3327).
+ * x = hi + lo + r with hi, lo bfloat16 (round to nearest even), |r| <= 2^-17 |x|;  dy . x ~ dyh.xh + dyh.xl + dyl.xh, and because
+ * the filter gradient contracts over PIXELS the three products are one product over three times the images:
+ *   HDU_SPLIT3_OPERAND:  dst = [hi ; lo ; hi]   (the convolution input, optionally relu(a*x+b) of a BN prologue first)
+ *   HDU_SPLIT3_GRADIENT: dst = [hi ; hi ; lo]   (the output gradient)
+ * dst: bfloat16 [3][rows][C] dense (pixel stride C), src: float32 [rows][ld_src].  hdu_conv_wgrad / hdu_wgrad_plan_* then take a
+ * bfloat16 descriptor with N' = 3 N images over the two dst buffers and add the float32 filter gradient as for a bfloat16 layer.
+ * hdu_split3_entry_fill() fills ONE host-side table entry (block_begin = blocks of all entries before it) and returns its block
+ * count; hdu_split3_batched() runs a DEVICE copy of the table (sorted by block_begin) as one launch, chl = the entries' `chl`
+ * (one value per table: the lane layout hdu_split3_entry_fill chose).
+ * C a multiple of 8, ld_src a multiple of 4, pointers 16-byte aligned, a / b both NULL (identity) or both set. */
+#define HDU_SPLIT3_OPERAND 0
+#define HDU_SPLIT3_GRADIENT 1
+typedef struct hdu_split3_entry {
+  const float* src;
+  void* dst;
+  const float* a;
+  const float* b;
+  uint64_t ld_src;
+  uint64_t rows;
+  uint32_t C;
+  uint32_t relu;
+  uint32_t pattern;
+  uint32_t cols;           /* filled by hdu_split3_entry_fill: 8-channel columns per workgroup, column groups per row block */
+  uint32_t col_groups;
+  uint32_t block_begin;
+  uint32_t iters;          /* row groups of 8 a thread walks */
+  uint32_t chl;            /* channels per lane (8 or 4) */
+} hdu_split3_entry;
+int hdu_split3_entry_fill(hdu_split3_entry* e, const float* src, int64_t ld_src, int64_t rows, int C, const float* a,
+                          const float* b, int relu, int pattern, void* dst, uint32_t block_begin, uint32_t* nblocks);
+int hdu_split3_batched(const hdu_split3_entry* dev_table, int n, uint32_t total_blocks, int chl, void* stream);
 
 /* ------------------------------------------------------------------ collectives (RCCL over xGMI)
  * The reference's only multi-GPU mechanism is in-graph tower replication (K.utils2/multi_gpu.py:7-69: the gradient sum is

@@ -666,6 +666,66 @@ def test_conv_f32_bf16x3_contraction(hdu, cs):
         assert float(err.max()) > e_exact, (what, float(err.max()), e_exact)
 
 
+SPLIT3_CASES = [c for c in CONV_CASES if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "wide_bn128", "halo_tile_ragged_slab",
+                                                      "halo_tile_3d_two_volumes_slab", "halo_tile_up221_3d", "pw_pro_two_stage",
+                                                      "pw_pro_wide_table_splitk", "pw_pro_3d_bn128")]
+
+
+def test_split3_filter_gradients(hdu):
+    """hdu_split3_batched + the bf16 filter-gradient kernels on N' = 3 N images (round 6): float32 operands (some behind a BN
+    prologue, some slabs of a wider buffer) and float32 output gradients are written ONCE as the bf16 image triples (hi, lo, hi) /
+    (hi, hi, lo) by ONE launch; the bf16 per-layer kernel and the batched plan over the triples then give dyh.xh + dyh.xl + dyl.xh --
+    held to the same 1.2e-5 * sum |dy| |x| bound as the in-kernel split (test_conv_f32_bf16x3_contraction), and the planes
+    themselves to hi + lo = x within 2^-16 |x|."""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib
+    sp = ops.Split3Plan()
+    plan = ops.WgradPlan()
+    items = []
+    for i, cs in enumerate(SPLIT3_CASES):
+        b = build_conv_case(ops, cs, F32, seed=500 + 11 * i)
+        N, Do, Ho, Wo, Cout = b["out_dims"]
+        dy = rnd((N, Do, Ho, Wo, Cout), 940 + i, 1.0, F32)
+        dya = mkact(ops, dy, F32, cs["ldout"], 8 if cs["ldout"] else 0)
+        pro = (dev(ops, b["pro"][0]), dev(ops, b["pro"][1])) if b["pro"] else None
+        xs = ops.Act.alloc(3 * cs["N"], cs["D"], cs["H"], cs["W"], cs["Cin"], BF16)
+        dys = ops.Act.alloc(3 * N, Do, Ho, Wo, Cout, BF16)
+        sp.add(b["xa"], lib.SPLIT3_OPERAND, xs, pro, True)
+        sp.add(dya, lib.SPLIT3_GRADIENT, dys)
+        d16 = ops.conv_desc(xs, ctypes.c_void_p(b["wt"].data_ptr()), dys, cs["K"], cs["s"], cs["p"], cs["up"])
+        dw1 = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+        dw2 = torch.zeros(b["w"].shape, dtype=torch.float32, device=ops.device())
+        plan.add(d16, dw2)
+        items.append((cs, b, dy, xs, dys, d16, dw1, dw2, pro))
+    assert len(sp) == 2 * len(SPLIT3_CASES)
+    sp.run()
+    plan.run()
+    for cs, b, dy, xs, dys, d16, dw1, dw2, pro in items:
+        ops.conv_wgrad(d16, dw1)
+        xe = ref_xeff(b["x"], (0, 0, 0), None, b["pro"], True, F32)          # what the planes hold (up-sampling stays in the conv)
+        t = xs.to_torch().cpu().double()
+        n = cs["N"]
+        hi, lo, hi2 = t[:n], t[n:2 * n], t[2 * n:]
+        # (behind a prologue the kernel's float32 a*x+b may differ from the float64 restatement by a float32 ulp: compare magnitudes)
+        assert torch.equal(hi, hi2) and float((hi - xe).abs().max()) <= 2.0 ** -8 * float(xe.abs().max()), cs["id"]
+        assert float(((hi + lo) - xe).abs().max()) <= (2.0 ** -16 + (2.0 ** -22 if b["pro"] else 0)) * float(xe.abs().max()), cs["id"]
+        if not b["pro"]:
+            assert torch.equal(hi, xe.to(torch.bfloat16).double()), cs["id"]
+        g = dys.to_torch().cpu().double()
+        assert torch.equal(g[:n], g[n:2 * n]) and torch.equal(g[:n], dy.to(torch.bfloat16).double()), cs["id"]
+        assert float(((g[:n] + g[2 * n:]) - dy).abs().max()) <= 2.0 ** -16, cs["id"]
+        xr = ref_xeff(b["x"], cs["up"], None, b["pro"], True, F32).requires_grad_(False)
+        wref = b["w"].clone().requires_grad_(True)
+        (ref_conv(xr, wref, cs["s"], cs["p"], None) * dy).sum().backward()
+        wabs = b["w"].abs().clone().requires_grad_(True)
+        (ref_conv(xr.abs(), wabs, cs["s"], cs["p"], None) * dy.abs()).sum().backward()
+        lim = 1.2e-5 * wabs.grad + 1e-6 * float(wref.grad.abs().max())
+        for what, got in (("per-layer", dw1), ("plan", dw2)):
+            err = (got.cpu().double() - wref.grad).abs()
+            assert not (err > lim).any(), "%s %s: max err %.3e, max bound ratio %.3f" % (cs["id"], what, float(err.max()), float((err / lim).max()))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("cs", [pytest.param(c, id=c["id"]) for c in CONV_CASES
                                 if c["id"] in ("dense3x3_2d_slab", "bottleneck1x1", "dense3x3x3", "stem7x7s2", "wide_bn128",

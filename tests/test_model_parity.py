@@ -165,6 +165,49 @@ def test_batched_filter_gradients_equal_per_layer_launches(emu_lib):
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("kind,variant,b,size,cols", [("2d", "denseunet", 2, 32, None)])      # (end2end: the GPU tier, test_gpu_parity.py)
+def test_f32_split_filter_gradients_on_bf16_triples(emu_lib, monkeypatch, kind, variant, b, size, cols):
+    """Round 6: a float32 network in the "bf16x3_bwd" mode takes its filter gradients from bf16 hi / lo image triples (one split
+    launch + the bf16 batched filter-gradient plan at the end of the backward pass, engine.Ctx._build_split_wgrad_plan) instead of
+    conv_wgrad_kernel<float>'s in-kernel split.  One training step: every layer with whole bf16 channel chunks is in the plan; the
+    flat gradient equals the in-kernel split's (HDU_F32_SPLIT_WGRAD=0) and the exact mode's to the split's 2^-16 per product; the
+    logits are the exact mode's."""
+    monkeypatch.setenv("HIPEMU_THREADS", "1")      # (same order of the float atomics in every run)
+    lib = U.pkg("lib")
+    lossf = U.pkg("loss").weighted_crossentropy if kind != "2d" else U.pkg("loss").weighted_crossentropy_2ddense
+    x, y = U.synthetic_batch(kind, b, size, cols)
+    out = {}
+    for tag, mode, on in (("exact", "exact", "1"), ("triples", "bf16x3_bwd", "1"), ("inkernel", "bf16x3_bwd", "0")):
+        monkeypatch.setenv("HDU_F32_SPLIT_WGRAD", on)
+        prev = lib.set_f32_contraction(mode)
+        try:
+            m = U.build_pair(kind, variant, b, size, cols, "f32", NB2D, NB3D)[0]
+            m.ctx.dropout_enabled = False
+            m.compile(optimizer=U.pkg("keras_api").SGD(lr=1e-3, momentum=0.9, nesterov=True), loss=[lossf])
+            m.train_on_batch(x, y)
+            out[tag] = (m.ctx.G[:m.ctx.n_trainable].clone(), m._download_logits().clone())
+            if tag == "triples":
+                sp, plan, own, _ = m.ctx._split_plan
+                taken = [cv for cv in m.ctx.convs if getattr(cv, "in_split_plan", False)]
+                skipped = [cv.name for cv in m.ctx.convs if cv.trainable and cv.out.root.needs_grad and not getattr(cv, "in_split_plan", False)]
+                assert len(sp) == 2 * len(taken) == 2 * (len(plan) + len(own)) and len(taken) >= 20
+                assert all(("conv1" in n or "classifer" in n) for n in skipped), skipped      # 3 / 4-channel input, 3-class heads
+            else:
+                assert m.ctx._split_plan is None
+        finally:
+            lib.set_f32_contraction(prev)
+    g_ex, g_tr, g_ik = out["exact"][0], out["triples"][0], out["inkernel"][0]
+    scale = float(g_ex.abs().max())
+    assert scale > 0
+    assert torch.equal(out["triples"][1], out["exact"][1])
+    assert not torch.equal(g_tr, g_ex) and not torch.equal(g_tr, g_ik)
+    assert float((g_tr - g_ik).abs().max()) <= 1e-4 * scale and float((g_tr - g_ex).abs().max()) <= 1e-4 * scale
+    n2 = lambda t: float(t.double().norm())
+    # (both split forms sit ~4e-5 from the exact mode -- the split DATA gradients they share -- and much closer to each other)
+    assert n2(g_tr - g_ex) <= 1e-4 * n2(g_ex), (n2(g_tr - g_ex) / n2(g_ex), n2(g_ik - g_ex) / n2(g_ex))
+    assert n2(g_tr - g_ik) <= 1e-5 * n2(g_ex), n2(g_tr - g_ik) / n2(g_ex)
+
+
 @pytest.mark.parametrize("kind,variant,b,size,cols", [("3d", "3dpart", 1, 32, 8), ("2d", "denseunet", 2, 32, None)])
 def test_halo_tile_filter_gradients_equal_im2col_form(emu_lib, monkeypatch, kind, variant, b, size, cols):
     """Round 4: 3 x 3 x 3 layers and convs behind a fused up-sampling take the halo-tile filter gradient (three plane-shifted

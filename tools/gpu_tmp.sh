@@ -1,5 +1,11 @@
-#!/bin/bash
-cd "$(dirname "$0")/.."
-mkdir -p gpurun_out
-for w in 384 512 768; do echo "== HDU_PW_BSTAT_WGS=$w"; HDU_PW_BSTAT_WGS=$w python tools/bench_pw_bstat.py 2>&1 | grep -v amdgpu | awk -F'|' '{print $1 "|" $4}'; done | tee gpurun_out/c16_pw_bstat_wgs.txt
-AB_STEPS=30 tools/gpu_ab.sh r06_pwb6 2 "2d 3dpart end2end shard3d" "prev=LIB=tools/libhdu_prev.so" "new="
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+for f in 0 32 64 128 4 36 68 132; do
+  HDU_SPLIT3_FORM=$f timeout 600 python bench.py --dtype f32x3b --steps 6 --warmup 2 --no-cpu-baseline --extras none > gpurun_out/s4_f$f.json 2> gpurun_out/s4_f$f.err
+  python - <<PY
+import json
+d=json.load(open('gpurun_out/bench_details.json'))
+k=list(d['conv_kernels'].values())[0]
+r=[v for n,v in k.items() if 'split3' in n][0]
+print("form $f: split3 %.1f us %.0f GB/s; step %.3f ms" % (r['us_per_launch'], r['alg_gbs'], d['main']['ms_per_step']))
+PY
+done 2>&1 | tee gpurun_out/s4_split3_forms.txt
