@@ -355,7 +355,8 @@ def test_f32_absolute_logit_error_from_trained_weights(hip_lib, kind, variant, b
 @pytest.mark.parametrize("kind,variant,b,size,cols", [
     ("2d", "denseunet", 2, 512, None),             # BASELINE configs[1] shape family
     ("hybrid", "end2end", 1, 224, 12),             # configs[3]
-], ids=["2d-denseunet", "end2end"])
+    ("hybrid", "3dpart", 1, 224, 12),              # configs[2]
+], ids=["2d-denseunet", "end2end", "3dpart"])
 def test_f32_exact_forward_split_backward_mode(hip_lib, kind, variant, b, size, cols):
     """Round 6 (VERDICT r5 item 5 / Missing 3: "a tolerance-meeting mode that is fast"): lib.set_f32_contraction("bf16x3_bwd") --
     float32 storage, the FORWARD convolutions in exact float32 (so predict and the training-phase logits are the parity mode's: held
@@ -388,7 +389,7 @@ def test_f32_exact_forward_split_backward_mode(hip_lib, kind, variant, b, size, 
     assert e_fwd <= 2e-5 * max(1.0, float(np.abs(ex["logits"]).max())), e_fwd
     P, fwd = sp["P"], sp["fwd"]
     ref_loss, ref_grads, ref_logits = U.R.train_step(P, fwd, U.loss_fn_for(kind), xt, torch.tensor(y), {})
-    tol_worst, tol_median = {("2d", "denseunet"): (2e-2, 3e-3), ("hybrid", "end2end"): (3e-2, 5e-3)}[(kind, variant)]
+    tol_worst, tol_median = {("2d", "denseunet"): (2e-2, 3e-3), ("hybrid", "end2end"): (3e-2, 5e-3), ("hybrid", "3dpart"): (3e-2, 5e-3)}[(kind, variant)]
     rms_max = max(float(np.sqrt((g.numpy().astype(np.float64) ** 2).mean())) for g in ref_grads.values())
     fig = {}
     for mode, r in runs.items():

@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for cfg in 2d 3dpart end2end; do
-  HDU_BENCH_TRACE=1 timeout 600 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --extras none > gpurun_out/s5_$cfg.json 2> gpurun_out/s5_$cfg.err
-  cp gpurun_out/step_trace_0.json gpurun_out/s5_trace_$cfg.json
-  head -c 200 gpurun_out/s5_$cfg.json; echo
-done
+for cfg in 3dpart end2end; do for dt in f32 f32x3b; do
+  timeout 600 python bench.py --config $cfg --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --extras none > gpurun_out/s6_${cfg}_$dt.json 2> gpurun_out/s6_${cfg}_$dt.err
+  cp gpurun_out/bench_details.json gpurun_out/s6_details_${cfg}_$dt.json
+  python -c "
+import json; d=json.load(open('gpurun_out/s6_${cfg}_$dt.json')); print('$cfg $dt', d['value'], d['ms_per_step'], d.get('config',{}).get('flops_check'))"
+done; done
