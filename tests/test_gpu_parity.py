@@ -389,7 +389,7 @@ def test_f32_exact_forward_split_backward_mode(hip_lib, kind, variant, b, size, 
     assert e_fwd <= 2e-5 * max(1.0, float(np.abs(ex["logits"]).max())), e_fwd
     P, fwd = sp["P"], sp["fwd"]
     ref_loss, ref_grads, ref_logits = U.R.train_step(P, fwd, U.loss_fn_for(kind), xt, torch.tensor(y), {})
-    tol_worst, tol_median = {("2d", "denseunet"): (2e-2, 3e-3), ("hybrid", "end2end"): (3e-2, 5e-3), ("hybrid", "3dpart"): (3e-2, 5e-3)}[(kind, variant)]
+    tol_worst, tol_median = {("2d", "denseunet"): (2e-2, 3e-3), ("hybrid", "end2end"): (3e-2, 5e-3), ("hybrid", "3dpart"): (6e-2, 4e-2)}[(kind, variant)]      # (the exact mode's own gates, test_full_forward_parity_f32)
     rms_max = max(float(np.sqrt((g.numpy().astype(np.float64) ** 2).mean())) for g in ref_grads.values())
     fig = {}
     for mode, r in runs.items():
@@ -409,6 +409,9 @@ def test_f32_exact_forward_split_backward_mode(hip_lib, kind, variant, b, size, 
             fig["exact"][2], fig["bf16x3_bwd"][3], fig["bf16x3_bwd"][4]))
     assert abs(sp["loss"] - ref_loss) <= 1e-4 * abs(ref_loss), (sp["loss"], ref_loss)
     assert fig["bf16x3_bwd"][0] < tol_worst and fig["bf16x3_bwd"][1] < tol_median, fig
+    # ... and no further from the oracle than the exact mode is (3dpart's float32 gradients are 1.7 % from the oracle's in BOTH modes:
+    # the split contraction adds 1e-5 of that)
+    assert fig["bf16x3_bwd"][0] <= fig["exact"][0] + 5e-4 and fig["bf16x3_bwd"][1] <= fig["exact"][1] + 1e-4, fig
     assert abs(fig["bf16x3_bwd"][2] - 1.0) < 5e-3, fig
     assert fig["bf16x3_bwd"][4] > 0.0, "the split contraction did not run in the backward pass"
     last = {"2d": "dense167classifer", "hybrid": "2d3dclassifer"}[kind]
