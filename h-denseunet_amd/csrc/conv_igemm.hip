@@ -2974,46 +2974,93 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   }
 }
 
-// One workgroup per 32x32 (Cout x Cin) tile of one tap of one layer: coalesced read of the float32 master along
-// Cin, coalesced write of the forward copy, LDS transpose, coalesced write of the data-gradient copy along Cout.
-// tile_begin[] (in the table) maps blockIdx.x to its layer by binary search.
+// 64 x 64 (Cout x Cin) tiles of one tap of one layer: 16-byte reads of the float32 master along Cin, 8-byte (bf16) / 16-byte (float32)
+// writes of the forward copy, LDS transpose, the same store width for the data-gradient copy along Cout.  tile_begin[] (in the
+// table) maps a tile to its layer by binary search; a workgroup walks HDU_PREP_TPW consecutive tiles and searches once.
+// Round 6: the 32 x 32 / one element per lane form of rounds 2-5 ran at 1.7-2.1 TB/s -- 2-byte stores, one per lane and element.
+// Entries whose offsets or channel counts are not multiples of 4 take the element-wise path of the same tile (workgroup-uniform).
+#define HDU_PREP_TPW 2
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const hdu_prep_entry* __restrict__ table, int n,
-                                                                 const float* __restrict__ master, T* __restrict__ wc) {
-  __shared__ float tile[32][33];
+                                                                 const float* __restrict__ master, T* __restrict__ wc,
+                                                                 long long total_tiles) {
+  __shared__ float tile[2][64][65];
+  const long long t0 = (long long)blockIdx.x * HDU_PREP_TPW;
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].tile_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (table[mid].tile_begin <= t0) lo = mid; else hi = mid - 1;
   }
-  const hdu_prep_entry e = table[lo];
-  const int t_local = (int)(blockIdx.x - e.tile_begin);
-  const int nci = (e.Cin + 31) / 32, nco = (e.Cout + 31) / 32;
-  const int cib = t_local % nci;
-  const int cob = (t_local / nci) % nco;
-  const int tap = t_local / (nci * nco);
-  const float* wm = master + e.master_off;
-  T* wf = e.w_f_off >= 0 ? wc + e.w_f_off : nullptr;
-  T* wd = e.w_d_off >= 0 ? wc + e.w_d_off : nullptr;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    const int co = cob * 32 + r, ci = cib * 32 + tx;
-    float v = 0.f;
-    if (co < e.Cout && ci < e.Cin) {
-      const long long q = ((long long)co * e.T + tap) * e.Cin + ci;
-      v = wm[q];
-      if (wf) Chunk<T>::store1(wf + q, v);
+  hdu_prep_entry e = table[lo];
+  long long next_begin = lo + 1 < n ? table[lo + 1].tile_begin : total_tiles;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  for (int it = 0; it < HDU_PREP_TPW; ++it) {
+    const long long t = t0 + it;
+    if (t >= total_tiles) break;
+    while (t >= next_begin) {                // (workgroup-uniform)
+      ++lo;
+      e = table[lo];
+      next_begin = lo + 1 < n ? table[lo + 1].tile_begin : total_tiles;
     }
-    tile[r][tx] = v;
-  }
-  __syncthreads();
-  if (wd) {
+    const int t_local = (int)(t - e.tile_begin);
+    const int nci = (e.Cin + 63) / 64, nco = (e.Cout + 63) / 64;
+    const int cib = t_local % nci;
+    const int cob = (t_local / nci) % nco;
+    const int tap = t_local / (nci * nco);
+    const float* wm = master + e.master_off;
+    T* wf = e.w_f_off >= 0 ? wc + e.w_f_off : nullptr;
+    T* wd = e.w_d_off >= 0 ? wc + e.w_d_off : nullptr;
+    float (*tl)[65] = tile[it & 1];          // two buffers: ONE barrier per tile (the next tile's fill cannot overtake this tile's reads)
+    const bool vec = ((e.master_off | (e.w_f_off >= 0 ? e.w_f_off : 0) | (e.w_d_off >= 0 ? e.w_d_off : 0) | (long long)e.Cin | (long long)e.Cout) & 3) == 0 &&
+                     (((uintptr_t)master | (uintptr_t)wc) & 15) == 0;
+    if (vec) {
 #pragma unroll
-    for (int r = ty; r < 32; r += 8) {
-      const int ci = cib * 32 + r, co = cob * 32 + tx;
-      if (co < e.Cout && ci < e.Cin)
-        Chunk<T>::store1(wd + ((long long)ci * e.T + (e.T - 1 - tap)) * e.Cout + co, tile[tx][r]);
+      for (int k = 0; k < 4; ++k) {
+        const int r = ty + 16 * k;
+        const int co = cob * 64 + r, ci = cib * 64 + tx * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (co < e.Cout && ci < e.Cin) {       // (Cin a multiple of 4: the quad is inside the row)
+          const long long q = ((long long)co * e.T + tap) * e.Cin + ci;
+          const f32x4 m = *(const f32x4*)(wm + q);
+          v[0] = m.x; v[1] = m.y; v[2] = m.z; v[3] = m.w;
+          if (wf) Chunk<T>::store4(wf + q, v);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tl[r][tx * 4 + j] = v[j];
+      }
+      __syncthreads();
+      if (wd) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = ty + 16 * k;
+          const int ci = cib * 64 + r, co = cob * 64 + tx * 4;
+          if (co < e.Cout && ci < e.Cin) {
+            const float v[4] = {tl[tx * 4 + 0][r], tl[tx * 4 + 1][r], tl[tx * 4 + 2][r], tl[tx * 4 + 3][r]};
+            Chunk<T>::store4(wd + ((long long)ci * e.T + (e.T - 1 - tap)) * e.Cout + co, v);
+          }
+        }
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        const int co = cob * 64 + r, ci = cib * 64 + c;
+        float v = 0.f;
+        if (co < e.Cout && ci < e.Cin) {
+          const long long q = ((long long)co * e.T + tap) * e.Cin + ci;
+          v = wm[q];
+          if (wf) Chunk<T>::store1(wf + q, v);
+        }
+        tl[r][c] = v;
+      }
+      __syncthreads();
+      if (wd) {
+        for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+          const int r = idx >> 6, c = idx & 63;
+          const int ci = cib * 64 + r, co = cob * 64 + c;
+          if (co < e.Cout && ci < e.Cin)
+            Chunk<T>::store1(wd + ((long long)ci * e.T + (e.T - 1 - tap)) * e.Cout + co, tl[c][r]);
+        }
+      }
     }
   }
 }
@@ -3883,11 +3930,11 @@ extern "C" int hdu_weight_prep_batched(int dtype, const hdu_prep_entry* table, i
   if (!table || n <= 0 || total_tiles <= 0 || !master_base || !wc_base)
     return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad args");
   if (dtype == HDU_BF16)
-    HDU_LAUNCH((weight_prep_batched_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
-               table, n, master_base, (bf16_t*)wc_base);
+    HDU_LAUNCH((weight_prep_batched_kernel<bf16_t>), dim3((unsigned)((total_tiles + HDU_PREP_TPW - 1) / HDU_PREP_TPW)), dim3(256), 0,
+               (hipStream_t)stream, table, n, master_base, (bf16_t*)wc_base, (long long)total_tiles);
   else if (dtype == HDU_F32)
-    HDU_LAUNCH((weight_prep_batched_kernel<float>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
-               table, n, master_base, (float*)wc_base);
+    HDU_LAUNCH((weight_prep_batched_kernel<float>), dim3((unsigned)((total_tiles + HDU_PREP_TPW - 1) / HDU_PREP_TPW)), dim3(256), 0,
+               (hipStream_t)stream, table, n, master_base, (float*)wc_base, (long long)total_tiles);
   else
     return hdu_set_error(HDU_ERR_ARG, "weight_prep_batched: bad dtype");
   return hdu_check_launch("weight_prep_batched");

@@ -548,7 +548,7 @@ class Ctx:
             if wf < 0 and wd < 0:
                 continue
             ents.append(PrepEntry(cv.kernel.offset, wf, wd, tiles, cv.cout_p, cv.T, cv.cin_p, 0))
-            tiles += cv.T * ((cv.cout_p + 31) // 32) * ((cv.cin_p + 31) // 32)
+            tiles += cv.T * ((cv.cout_p + 63) // 64) * ((cv.cin_p + 63) // 64)      # include/hdu.h HDU_PREP_TILE
         self._prep_n = len(ents)
         self._prep_tiles = tiles
         if ents:

@@ -282,8 +282,10 @@ int hdu_weight_prep(int dtype, const float* w_master, int Cout, int T, int Cin, 
 
 /* all layers of a model in ONE launch: `table` is a device array of n hdu_prep_entry (element offsets into the flat
  * float32 master buffer and into the flat compute-dtype filter buffer; w_f_off / w_d_off < 0 = not wanted).  Work
- * is split in 32x32 (Cout x Cin) tiles per tap; tile_begin is the running tile count (exclusive prefix sum of
- * T*ceil(Cout/32)*ceil(Cin/32)), total_tiles the grand total. */
+ * is split in 64x64 (Cout x Cin) tiles per tap (HDU_PREP_TILE; 32 until ABI 6); tile_begin is the running tile count (exclusive
+ * prefix sum of T*ceil(Cout/64)*ceil(Cin/64)), total_tiles the grand total.  Offsets and channel counts that are multiples of 4 take
+ * 16-byte reads / 8-16-byte writes; others are copied element-wise. */
+#define HDU_PREP_TILE 64
 typedef struct hdu_prep_entry {
   int64_t master_off, w_f_off, w_d_off, tile_begin;
   int32_t Cout, T, Cin, pad_;

@@ -1641,6 +1641,50 @@ def test_stride2_dgrad_parity_classes(hdu, dtype, shape):
     assert_close(dx.to_torch().cpu(), 2 * xe.grad, dtype, scale=2 * float(xe.grad.abs().max()), what="stride-2 dgrad accumulate")
 
 
+def test_weight_prep_batched_equals_per_layer(hdu):
+    """hdu_weight_prep_batched (one launch, 64 x 64 tiles, 16-byte reads / 8-byte bf16 writes, a workgroup walks consecutive tiles across
+    layer boundaries: round 6; one layer with a channel count that is not a multiple of 4 on the element-wise path) ==
+    hdu_weight_prep per layer, bit for bit, for both copies and both dtypes; layers with ragged channel counts, one tile, many
+    taps, forward-only and data-gradient-only entries; the bytes around every copy stay untouched."""
+    import ctypes
+    ops = ops_mod()
+    lib = hdu.lib
+    layers = [(48, 9, 192, True, True), (192, 1, 2208, True, True), (8, 1, 64, True, False), (96, 343, 8, True, True), (40, 27, 24, False, True),
+              (32, 1, 32, True, True), (3 * 8, 9, 8, True, True), (136, 3, 72, True, True), (16, 1, 16, True, True), (64, 27, 96, True, True),
+              (70, 3, 66, True, True), (200, 1, 130, True, True)]
+    for dtype in (BF16, F32):
+        tdt = torch.bfloat16 if dtype == BF16 else torch.float32
+        n_master = sum(co * t * ci for co, t, ci, _, _ in layers)
+        master = (torch.rand(n_master + 16, generator=torch.Generator().manual_seed(5 + dtype)) * 2 - 1).to(ops.device())
+        ents, refs, tiles, moff, woff = [], [], 0, 0, 8
+        for co, t, ci, want_f, want_d in layers:
+            numel = co * t * ci
+            wf = woff if want_f else -1
+            woff += (numel + 8) if want_f else 0
+            wd = woff if want_d else -1
+            woff += (numel + 8) if want_d else 0
+            ents.append(lib.PrepEntry(moff, wf, wd, tiles, co, t, ci, 0))
+            tiles += t * ((co + 63) // 64) * ((ci + 63) // 64)
+            refs.append((moff, wf, wd, co, t, ci, numel))
+            moff += numel
+        wc = torch.full((woff + 8,), 3.0, dtype=tdt, device=ops.device())
+        arr = (lib.PrepEntry * len(ents))(*ents)
+        table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(ops.device())
+        ops.weight_prep_batched(dtype, table, len(ents), tiles, master, wc)
+        covered = torch.zeros(woff + 8, dtype=torch.bool)
+        for moff_, wf, wd, co, t, ci, numel in refs:
+            rf = torch.zeros(numel, dtype=tdt, device=ops.device())
+            rd = torch.zeros(numel, dtype=tdt, device=ops.device())
+            ops.weight_prep(dtype, master[moff_:moff_ + numel], co, t, ci, rf, rd)
+            if wf >= 0:
+                assert torch.equal(wc[wf:wf + numel], rf), (dtype, co, t, ci, "forward copy")
+                covered[wf:wf + numel] = True
+            if wd >= 0:
+                assert torch.equal(wc[wd:wd + numel], rd), (dtype, co, t, ci, "data-gradient copy")
+                covered[wd:wd + numel] = True
+        assert float((wc.cpu().float()[~covered] - 3.0).abs().max()) == 0.0
+
+
 def test_zero_regions(hdu):
     """hdu_zero_regions / hdu_zero: the one-launch re-initialisation of a step's accumulators -- every region cleared
     exactly (multi-block regions, a 4-byte-granular tail, a region smaller than one block), neighbours untouched, the

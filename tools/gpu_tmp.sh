@@ -1,5 +1,13 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "split_backward_mode and 3dpart" 2>&1 | tail -8 ) > gpurun_out/s7_tests.log 2>&1
-( time python bench.py ) > gpurun_out/s7_bench.json 2> gpurun_out/s7_bench.err
-cp gpurun_out/bench_details.json gpurun_out/s7_bench_details.json
-cat gpurun_out/s7_tests.log; grep -h "f32 forward exact" gpurun_out/bf16_parity_figures.txt | tail -1; wc -c gpurun_out/s7_bench.json; tail -4 gpurun_out/s7_bench.err
+( timeout 600 python -m pytest tests/test_kernels.py -m gpu -x -q -k "weight_prep_batched or split3" 2>&1 | tail -3 ) > gpurun_out/s8_tests.log 2>&1
+cat gpurun_out/s8_tests.log
+for cfg in 2d 3dpart end2end; do
+  timeout 600 python bench.py --config $cfg --steps 20 --warmup 3 --no-cpu-baseline --extras none > gpurun_out/s8_$cfg.json 2> gpurun_out/s8_$cfg.err
+  python - <<PY
+import json
+d=json.load(open('gpurun_out/bench_details.json'))
+k=list(d['conv_kernels'].values())[0]
+r=[v for n,v in k.items() if 'weight_prep' in n][0]
+print("$cfg: weight_prep %.1f us %.0f GB/s; step %.3f ms" % (r['us_per_launch'], r['alg_gbs'], d['main']['ms_per_step']))
+PY
+done
