@@ -1170,7 +1170,7 @@ def _conv_backward_fused_bn(self, dy):
 
 
 ConvLayer._backward_fused_bn = _conv_backward_fused_bn
-ConvLayer.BNB_SLOTS = 32
+ConvLayer.BNB_SLOTS = int(os.environ.get("HDU_BNB_SLOTS", "16"))      # slot rows of the fused BN backward in a data-gradient epilogue (<= 32).  Round 6 sweep (profiles/r06_experiment_knob_sweep.txt): 16 beats the 32 of rounds 3-5 by 0.1-0.35 % on all three workloads (half the finalize reads), 8 and 4 lose it again to atomic contention
 
 
 def _conv_backward_halo(self, dy):
