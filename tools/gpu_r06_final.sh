@@ -7,4 +7,5 @@ mkdir -p gpurun_out
 bash tools/gpu_r06_tier.sh > /dev/null 2>&1
 cp gpurun_out/bf16_parity_figures.txt profiles/r06_bf16_parity_figures.txt
 tail -4 gpurun_out/tier_gpu.txt
+( time python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/ev_smoke.txt 2>&1; tail -5 gpurun_out/ev_smoke.txt
 bash tools/gpu_r06_evidence.sh
