@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-out=gpurun_out/s9_bnb_slots.txt; : > $out
-for v in 32 16 8 4 32 16; do
-  for cfg in 2d 3dpart end2end; do
-    ms=$(HDU_BNB_SLOTS=$v timeout 300 python bench.py --config $cfg --steps 30 --warmup 3 --no-cpu-baseline --no-roofline --extras none 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null)
-    echo "BNB_SLOTS=$v $cfg $ms" >> $out
-  done
+: > gpurun_out/s10_replay.txt
+for v in 16 32 16 32 16 32 16 32 16 32 16 32; do
+  HDU_BNB_SLOTS=$v timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -s -k "graph_replay_equals_eager_steps and end2end" 2>&1 | grep -E "graph replay vs eager|passed|failed" | cut -c1-420 | sed "s/^/slots=$v /" >> gpurun_out/s10_replay.txt
 done
-cat $out
+cat gpurun_out/s10_replay.txt
