@@ -780,7 +780,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(RowK p) {
   for (; m < r_end; m += ROWS) body(m, *(const u32x4*)(xp + m * p.ldx + c0));
 }
 
-template <typename T, int COLS, bool SUMS = false>
+// PRE (round 6; SUMS launches whose threads own at most ROW_UNROLL rows -- the M <= 8192 dense layers, 60 of the 2D net's 78): the
+// thread's rows are requested BEFORE the slot-table round trip, so the launch is ONE memory round trip instead of two or three (with
+// 2 rows per thread the main loop below never ran and its tail loop took the rows one round trip at a time).  Its own instantiation:
+// the 24-36 registers the rows occupy during the prologue cost the LARGE layers an occupancy step (measured in round 3: 2D +0.3 ms when
+// every launch did it) -- a launch of <= 512 workgroups of this size has no occupancy to lose.
+template <typename T, int COLS, bool SUMS = false, bool PRE = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int ROWS = 256 / COLS;
@@ -797,6 +802,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
   if (r_end > p.M) r_end = p.M;
   const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
   long long m = r_begin + rl;
+  u32x4 pxv[PRE ? ROW_UNROLL : 1], pgv[PRE ? ROW_UNROLL : 1], pov[PRE ? ROW_UNROLL : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      const long long mm = m + u * ROWS;
+      const bool ok = active && mm < r_end;
+      pxv[u] = ok ? *(const u32x4*)(xp + mm * p.ldx + c0) : z4;
+      pgv[u] = ok ? *(const u32x4*)(dzp + mm * p.lddz + c0) : z4;
+      pov[u] = (ok && p.accumulate) ? *(const u32x4*)(op + mm * p.ldo + c0) : z4;
+    }
+  }
   // dx = k1*g - k2 - k3*(x-mean) = k1*g - k3*x + k4,  k4 = k3*mean - k2
   float a[CH], b[CH], k1[CH], k3[CH], k4[CH];
   if constexpr (SUMS) {
@@ -870,6 +886,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(RowK p) {
     }
     *(u32x4*)(op + m * p.ldo + c0) = Chunk<T>::pack(o);
   };
+  if constexpr (PRE) {                        // (the host launches this form only when ROW_UNROLL rows per thread cover the row block)
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u)
+      if (m + u * ROWS < r_end) body(m + u * ROWS, pxv[u], pgv[u], pov[u]);
+    return;
+  }
   for (; m + (ROW_UNROLL - 1) * ROWS < r_end; m += ROW_UNROLL * ROWS) {
     u32x4 xv[ROW_UNROLL], gv[ROW_UNROLL], ov[ROW_UNROLL];
 #pragma unroll
@@ -1012,6 +1034,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_correct_kernel(FinCorK p)
     k3[j] = o3[j] + kk3;
     k4[j] = o4[j] + (kk3 * mu[j] - k2);
   }
+  // (Round 6: requesting the first ROW_UNROLL rows before the slot sums meet, as bn_bwd_apply_kernel's PRE form does, was measured
+  // here too -- same-box A/B, profiles/r06_experiment_rows_first.txt: 2D +0.18 ms against the gain of the other two kernels; not kept.)
   const T* __restrict__ xp = (const T*)p.u;
   T* __restrict__ op = (T*)p.du;
   const long long r_begin = (long long)(blockIdx.x - p.nfin) * p.rows_per_block;
@@ -1088,7 +1112,8 @@ struct MatK {
   float* fa; float* fb; float* frstd; float* mov_mean; float* mov_var;
 };
 
-template <typename T, int COLS, bool STATS = false>
+// PRE: as bn_bwd_apply_kernel's -- STATS launches without up-sampling / skip whose threads own at most ROW_UNROLL rows
+template <typename T, int COLS, bool STATS = false, bool PRE = false>
 __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int ROWS = 256 / COLS;
@@ -1134,8 +1159,18 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
     }
   };
   const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
+  u32x4 pxv[PRE ? ROW_UNROLL : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u) {
+      const long long mm = m + u * ROWS;
+      pxv[u] = (active && mm < r_end) ? *(const u32x4*)(xp + mm * p.ldx + c0) : z4;
+    }
+  }
   float a[CH], b[CH];
   if constexpr (STATS) {
+    // (Round 3: requesting the thread's first data rows BEFORE the workgroup meets in EVERY launch -- round 6 does it in the PRE
+    // instantiation, for the small launches only.  The round-3 note:)
     // (Requesting the thread's first data rows BEFORE the workgroup meets, so that the two round trips overlap, was measured
     // slower in three forms -- branch-guarded, unconditional, and unconditional behind the slot rows with a raw barrier and a
     // scheduling barrier: the 16-32 extra live registers cost the large layers an occupancy step; 2D 20.46 -> 20.74 ms.)
@@ -1209,6 +1244,12 @@ __global__ __launch_bounds__(256) void materialize_kernel(MatK p) {
     }
     *(u32x4*)(op + mo * p.ldo + c0) = Chunk<T>::pack(f);
   };
+  if constexpr (PRE) {
+#pragma unroll
+    for (int u = 0; u < ROW_UNROLL; ++u)
+      if (m + u * ROWS < r_end) body(m + u * ROWS, pxv[u], z4);
+    return;
+  }
   while (m + (ROW_UNROLL - 1) * ROWS < r_end) {
     u32x4 xv[ROW_UNROLL], sv[ROW_UNROLL];
     long long mo[ROW_UNROLL];
@@ -1299,14 +1340,17 @@ extern "C" int hdu_materialize_stats(int dtype, const void* x, int64_t ldx, int 
   k.fa = f->a; k.fb = f->b; k.frstd = f->rstd; k.mov_mean = f->mov_mean; k.mov_var = f->mov_var;
   int cols; unsigned gx, gy;
   row_geometry(dtype, k.Mo, C, &cols, &gx, &gy, &k.rows_per_block);
-#define HDU_MAT_STATS(T)                                                                                                   \
-  switch (cols) {                                                                                                          \
-    case 4: HDU_LAUNCH((materialize_kernel<T, 4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
-    case 8: HDU_LAUNCH((materialize_kernel<T, 8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
-    case 16: HDU_LAUNCH((materialize_kernel<T, 16, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;     \
-    default: HDU_LAUNCH((materialize_kernel<T, 32, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;     \
+  const bool pre = k.rows_per_block <= (long long)ROW_UNROLL * (256 / cols) && !(ud | uh | uw) && skip == nullptr &&
+                   !(g_tuning[HDU_TUNE_DEBUG] & 2048);
+#define HDU_MAT_STATS(T, PRE)                                                                                                   \
+  switch (cols) {                                                                                                               \
+    case 4: HDU_LAUNCH((materialize_kernel<T, 4, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
+    case 8: HDU_LAUNCH((materialize_kernel<T, 8, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;       \
+    case 16: HDU_LAUNCH((materialize_kernel<T, 16, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;     \
+    default: HDU_LAUNCH((materialize_kernel<T, 32, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;     \
   }
-  if (dtype == HDU_BF16) { HDU_MAT_STATS(bf16_t) } else { HDU_MAT_STATS(float) }
+  if (dtype == HDU_BF16) { if (pre) { HDU_MAT_STATS(bf16_t, true) } else { HDU_MAT_STATS(bf16_t, false) } }
+  else { if (pre) { HDU_MAT_STATS(float, true) } else { HDU_MAT_STATS(float, false) } }
 #undef HDU_MAT_STATS
   return hdu_check_launch("materialize_stats");
 }
@@ -1373,14 +1417,17 @@ static int bn_bwd_fused_impl(bool reduce, int dtype, const void* dz, int64_t ldd
   // launch 2: coefficients from the sums + dx
   int cols; unsigned gx, gy;
   row_geometry(dtype, M, C, &cols, &gx, &gy, &k.rows_per_block);
-#define HDU_APPLY_SUMS(T)                                                                                                    \
-  switch (cols) {                                                                                                            \
-    case 4: HDU_LAUNCH((bn_bwd_apply_kernel<T, 4, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;        \
-    case 8: HDU_LAUNCH((bn_bwd_apply_kernel<T, 8, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;        \
-    case 16: HDU_LAUNCH((bn_bwd_apply_kernel<T, 16, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;      \
-    default: HDU_LAUNCH((bn_bwd_apply_kernel<T, 32, true>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;      \
+  // few rows per thread: the form that requests them before the slot rows (bn_bwd_apply_kernel PRE); HDU_TUNE_DEBUG bit 11: off (A/B)
+  const bool pre = k.rows_per_block <= (long long)ROW_UNROLL * (256 / cols) && !(g_tuning[HDU_TUNE_DEBUG] & 2048);
+#define HDU_APPLY_SUMS(T, PRE)                                                                                                    \
+  switch (cols) {                                                                                                                 \
+    case 4: HDU_LAUNCH((bn_bwd_apply_kernel<T, 4, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;        \
+    case 8: HDU_LAUNCH((bn_bwd_apply_kernel<T, 8, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;        \
+    case 16: HDU_LAUNCH((bn_bwd_apply_kernel<T, 16, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;      \
+    default: HDU_LAUNCH((bn_bwd_apply_kernel<T, 32, true, PRE>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, k); break;      \
   }
-  if (dtype == HDU_BF16) { HDU_APPLY_SUMS(bf16_t) } else { HDU_APPLY_SUMS(float) }
+  if (dtype == HDU_BF16) { if (pre) { HDU_APPLY_SUMS(bf16_t, true) } else { HDU_APPLY_SUMS(bf16_t, false) } }
+  else { if (pre) { HDU_APPLY_SUMS(float, true) } else { HDU_APPLY_SUMS(float, false) } }
 #undef HDU_APPLY_SUMS
   return hdu_check_launch("bn_bwd_fused");
 }

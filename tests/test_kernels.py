@@ -806,11 +806,24 @@ def test_bn_stats_finalize_fold_next(hdu):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("seg", ["whole", "tail"])
-def test_materialize_stats(hdu, dtype, seg):
+@pytest.mark.parametrize("form", ["up-skip", "plain", "plain-rows-loop"])
+def test_materialize_stats(hdu, dtype, seg, form):
     """hdu_materialize_stats == hdu_bn_stats_finalize(_fold_next) followed by hdu_materialize: the output tensor and
     everything the finalize launch would have published (a, b, rstd, the segment's moments, the moving averages), with an
-    up-sampled input and a skip add, several column groups and row blocks"""
+    up-sampled input and a skip add, several column groups and row blocks.  Round 6: "plain" = no up-sampling / skip (the dense
+    layers' call) -- at this size the launch takes the form that requests its rows before the slot-table round trip
+    (materialize_kernel PRE); "plain-rows-loop" = the same call with that form switched off (HDU_TUNE_DEBUG bit 11)."""
     ops = ops_mod()
+    up = (0, 1, 1) if form == "up-skip" else (0, 0, 0)
+    if form == "plain-rows-loop":
+        hdu.lib.get().hdu_set_tuning(4, 2048)
+    try:
+        _materialize_stats_case(hdu, ops, dtype, seg, up)
+    finally:
+        hdu.lib.get().hdu_set_tuning(4, 0)
+
+
+def _materialize_stats_case(hdu, ops, dtype, seg, up):
     dev_ = ops.device()
     N, D, H, W = 2, 1, 12, 20
     C = 304 if seg == "tail" else 192                  # tail: a dense-block slab, the last 48 channels just written
@@ -819,8 +832,8 @@ def test_materialize_stats(hdu, dtype, seg):
     g = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float32)
     x = q(rnd((N, D, H, W, C), 21, 2.0, dtype) + 0.3, dtype)
-    skip = q(rnd((N, D, 2 * H, 2 * W, C), 22, 1.0, dtype), dtype)
-    xa, ska = mkact(ops, x, dtype), mkact(ops, skip, dtype)
+    skip = q(rnd((N, D, 2 * H, 2 * W, C), 22, 1.0, dtype), dtype) if up != (0, 0, 0) else None
+    xa, ska = mkact(ops, x, dtype), (mkact(ops, skip, dtype) if skip is not None else None)
     shift0 = rn(C) * 0.5
     # slot sums of (y - shift), (y - shift)^2 over the segment channels, spread over the slot rows like a conv epilogue
     xs = x.reshape(-1, C)[:, c0:c0 + Cseg] - shift0[c0:c0 + Cseg].double()
@@ -837,15 +850,15 @@ def test_materialize_stats(hdu, dtype, seg):
         a, b, r = (torch.zeros(C, device=dev_) for _ in range(3))
         mm, mv = torch.full((C,), 0.5, device=dev_), torch.full((C,), 2.0, device=dev_)
         fold = (gamma, beta, 1.1e-5, sg, sb, a, b, r, mm, mv, 0.99)
-        out = ops.Act.alloc(N, D, 2 * H, 2 * W, C, dtype)
+        out = ops.Act.alloc(N, D, H << up[1], W << up[2], C, dtype)
         if fused:
-            ops.materialize_stats(xa, (partial, slots, M, Cseg, c0, shift, mean, var, fold), True, (0, 1, 1), ska, out)
+            ops.materialize_stats(xa, (partial, slots, M, Cseg, c0, shift, mean, var, fold), True, up, ska, out)
         else:
             if seg == "tail":
                 ops.bn_stats_finalize_fold_next(partial, slots, M, Cseg, c0, C, shift, mean, var, fold)
             else:
                 ops.bn_stats_finalize(partial, slots, M, C, shift, mean, var, fold)
-            ops.materialize(xa, a, b, True, (0, 1, 1), ska, out)
+            ops.materialize(xa, a, b, True, up, ska, out)
         outs.append([t.cpu() for t in (mean, var, a, b, r, mm, mv)] + [out.to_torch().cpu().float()])
     names = ["mean", "var", "a", "b", "rstd", "mov_mean", "mov_var", "out"]
     for nm, u, v in zip(names, *outs):
@@ -856,7 +869,7 @@ def test_materialize_stats(hdu, dtype, seg):
     assert float((outs[0][0][c0:c0 + Cseg].double() - xm.mean(0)).abs().max()) < 1e-4
     assert float((outs[0][1][c0:c0 + Cseg].double() - xm.var(0, unbiased=False)).abs().max()) < 1e-3
     with pytest.raises(hdu.lib.HduError):
-        ops.materialize_stats(xa, (partial, slots, M, Cseg, c0 + 4, shift, mean, var, fold), True, (0, 1, 1), ska, out)
+        ops.materialize_stats(xa, (partial, slots, M, Cseg, c0 + 4, shift, mean, var, fold), True, up, ska, out)
 
 
 def test_conv_wgrad_batched_plan(hdu):
@@ -1395,10 +1408,21 @@ def test_bn_backward(hdu, dtype, batch_stats):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_bn_backward_fused_wide(hdu, dtype):
+@pytest.mark.parametrize("form", ["rows-first", "rows-loop"])
+def test_bn_backward_fused_wide(hdu, dtype, form):
     """hdu_bn_bwd_fused over several column groups and many row blocks (C = 328 channels: 2 groups of 32 chunks in bf16, a
-    partial last group; M = 4096 rows) against the three-launch form of the same library"""
+    partial last group; M = 4096 rows) against the three-launch form of the same library.  Round 6: at this size the apply launch
+    requests its rows before the slot-table round trip (bn_bwd_apply_kernel PRE); "rows-loop" = that form switched off."""
     ops = ops_mod()
+    if form == "rows-loop":
+        hdu.lib.get().hdu_set_tuning(4, 2048)
+    try:
+        _bn_backward_fused_wide_case(hdu, ops, dtype)
+    finally:
+        hdu.lib.get().hdu_set_tuning(4, 0)
+
+
+def _bn_backward_fused_wide_case(hdu, ops, dtype):
     N, D, H, W, C = 1, 1, 64, 64, 328
     x = q(rnd((N, D, H, W, C), 13, 2.0, dtype) + 0.25, dtype)
     dz = rnd((N, D, H, W, C), 14, 1.0, dtype)
